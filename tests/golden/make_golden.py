@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Generate golden vectors from the LIVE reference generator (build container only).
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+The reference (`/root/reference`, `harana.models.FastSVCGenerator`, fastsvc.py:235-383) holds no
+known-answer tests for this path, so parity is pinned by vectors produced here by
+importing and running the reference itself.  Only DATA is stored: inputs, expected outputs and
+intermediate taps.  Weights and large inputs are regenerated on every machine from the integer-hash
+generator in ``svcc23_fastsvc_amd/synth.py`` (bit-identical everywhere), so the fixtures stay small.
+
+Fixtures written:
+  tiny_forward.npz      tiny-width generator (8 -> [16,8,8,4]), B=2, F=24: state dict, inputs, output
+                        with / without speaker embedding, per-stage taps (down nets, FiLM, up blocks)
+  full_forward_f7.npz   yaml-width generator, B=2, F=7  (shorter than the d=27 receptive field)
+  full_forward_f300.npz yaml-width generator, B=1, F=300 (BASELINE cfg1): full output
+  full_forward_cfg2.npz yaml-width generator, B=8, F=600 (BASELINE cfg2): 16 slices + checksums
+  inference_f40.npz     ``inference()`` call sequence with the reference SignalGenerator, noise_amp=0
+  weight_norm_fold.npz  torch ``remove_weight_norm`` result for three layers (g, v -> w)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle.refimport import import_reference, import_reference_signal_generator  # noqa: E402
+from svcc23_fastsvc_amd import synth as S  # noqa: E402
+
+warnings.filterwarnings("ignore")
+torch.set_num_threads(8)
+
+
+def build_reference(M, cfg: S.GeneratorConfig, seed: int):
+    g = M.FastSVCGenerator(
+        in_channels=cfg.in_channels, mid_channels=list(cfg.mid_channels),
+        upsampling_scales=list(cfg.upsampling_scales), out_channels=cfg.out_channels,
+        spk_emb_size=cfg.spk_emb_size, use_spk_emb=cfg.use_spk_emb)
+    sd = S.synth_state_dict(cfg, seed)
+    assert list(g.state_dict().keys()) == S.state_dict_keys(cfg)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return g.eval(), sd
+
+
+def run(g, b: S.SynthBatch, with_spk=True):
+    with torch.no_grad():
+        return g(torch.from_numpy(b.ppg), torch.from_numpy(b.sine), torch.from_numpy(b.lft),
+                 torch.from_numpy(b.spk_emb) if with_spk else None).numpy()
+
+
+def tiny(M):
+    cfg, seed_w, seed_x, B, F = S.TINY_CONFIG, 101, 102, 2, 24
+    g, sd = build_reference(M, cfg, seed_w)
+    b = S.synth_batch(cfg, B, F, seed_x)
+    taps = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            if isinstance(out, tuple):
+                taps[name + ".scale"] = out[0].detach().numpy().copy()
+                taps[name + ".shift"] = out[1].detach().numpy().copy()
+            else:
+                taps[name] = out.detach().numpy().copy()
+        return fn
+
+    hs = []
+    for k in range(cfg.n_stages):
+        hs.append(g.downsampling_lft[k].register_forward_hook(hook(f"down_lft.{k}")))
+        hs.append(g.downsampling_sine[k].register_forward_hook(hook(f"down_sine.{k}")))
+        hs.append(g.film_lft[k].register_forward_hook(hook(f"film_lft.{k}")))
+        hs.append(g.film_sine[k].register_forward_hook(hook(f"film_sine.{k}")))
+        hs.append(g.upsampling_nets[k].register_forward_hook(hook(f"up.{k}.out")))
+    y = run(g, b, True)
+    for h in hs:
+        h.remove()
+    y_nospk = run(g, b, False)
+    out = {"y": y, "y_nospk": y_nospk, "ppg": b.ppg, "sine": b.sine, "lft": b.lft,
+           "spk_emb": b.spk_emb, "meta": np.array([seed_w, seed_x, B, F])}
+    out.update({"tap/" + k: v for k, v in taps.items()})
+    out.update({"sd/" + k: v for k, v in sd.items()})
+    np.savez_compressed(os.path.join(HERE, "tiny_forward.npz"), **out)
+    print("tiny", y.shape, float(np.abs(y).max()), len(taps), "taps")
+
+
+def full(M):
+    cfg, seed_w = S.FULL_CONFIG, 201
+    g, _ = build_reference(M, cfg, seed_w)
+    # F = 7: every stage shorter than the dilation-27 receptive field
+    b = S.synth_batch(cfg, 2, 7, 202)
+    np.savez_compressed(os.path.join(HERE, "full_forward_f7.npz"), y=run(g, b, True),
+                        y_nospk=run(g, b, False), meta=np.array([seed_w, 202, 2, 7]))
+    # cfg1
+    w = S.WORKLOADS["cfg1"]
+    b = S.synth_batch(cfg, w["B"], w["F"], w["seed"])
+    y = run(g, b, True)
+    np.savez_compressed(os.path.join(HERE, "full_forward_f300.npz"), y=y.astype(np.float32),
+                        meta=np.array([seed_w, w["seed"], w["B"], w["F"]]))
+    print("cfg1", y.shape, float(y.std()), float(np.abs(y).max()))
+    # cfg2: slices + checksums
+    w = S.WORKLOADS["cfg2"]
+    b = S.synth_batch(cfg, w["B"], w["F"], w["seed"])
+    y = run(g, b, True)
+    T = y.shape[-1]
+    starts = np.array([0, 17, 4093, 11111, 23999, 31337, 40000, 47999, 48000, 60001,
+                       70707, 80000, 88888, 95000, 95700, T - 256])
+    slices = np.stack([y[i % w["B"], 0, st:st + 256] for i, st in enumerate(starts)])
+    np.savez_compressed(os.path.join(HERE, "full_forward_cfg2.npz"), starts=starts, slices=slices,
+                        sum=y.astype(np.float64).sum(axis=-1), sumsq=(y.astype(np.float64) ** 2).sum(axis=-1),
+                        absmax=np.abs(y).max(axis=-1), meta=np.array([seed_w, w["seed"], w["B"], w["F"]]))
+    print("cfg2", y.shape, float(y.std()), float(np.abs(y).max()))
+
+
+def inference(M):
+    """decode_fastsvc.py:187-189 call sequence: time-major inputs, reference SignalGenerator
+    with noise_amp=0 (deterministic), pad_fn = ReplicationPad1d(0)."""
+    SignalGenerator = import_reference_signal_generator()
+    cfg, seed_w, F = S.FULL_CONFIG, 201, 40
+    g, _ = build_reference(M, cfg, seed_w)
+    g.remove_weight_norm()                       # decode_fastsvc.py:142
+    b = S.synth_batch(cfg, 1, F, 301)
+    sg = SignalGenerator(sample_rate=24000, hop_size=cfg.hop, sine_amp=0.1, noise_amp=0.0,
+                         signal_types=["sine"])
+    pad_fn = torch.nn.ReplicationPad1d(0)
+    ppg_tm = torch.from_numpy(b.ppg[0].T.copy())          # (F, 144)
+    f0_tm = torch.from_numpy(b.f0[0].T.copy())            # (F, 1)
+    lft_tm = torch.from_numpy(b.lft[0].T.copy())          # (T, 1)
+    emb = torch.from_numpy(b.spk_emb)                     # (1, 512)
+    with torch.no_grad():
+        y = g.inference(ppg_tm, f0_tm, lft_tm, sg, pad_fn, emb).numpy()
+        sine = sg(f0_tm.transpose(1, 0).unsqueeze(0)).numpy()
+    np.savez_compressed(os.path.join(HERE, "inference_f40.npz"), y=y, sine=sine, f0=b.f0,
+                        meta=np.array([seed_w, 301, 1, F]))
+    print("inference", y.shape, sine.shape)
+
+
+def fold(M):
+    cfg = S.TINY_CONFIG
+    g, sd = build_reference(M, cfg, 101)
+    g.remove_weight_norm()
+    sd2 = g.state_dict()
+    names = ["upsampling_nets.0.conv_first", "downsampling_sine.1.downsample_block.4", "conv_last"]
+    out = {}
+    for n in names:
+        out[n + ".weight"] = sd2[n + ".weight"].numpy()
+        out[n + ".weight_g"] = sd[n + ".weight_g"]
+        out[n + ".weight_v"] = sd[n + ".weight_v"]
+    np.savez_compressed(os.path.join(HERE, "weight_norm_fold.npz"), **out)
+
+
+if __name__ == "__main__":
+    M = import_reference()
+    tiny(M)
+    full(M)
+    inference(M)
+    fold(M)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
