@@ -1,0 +1,120 @@
+/*
+ * fastsvc_hip.h - C ABI of the MI355X-native FastSVC generator forward pass (gfx950 / CDNA4).
+ *
+ * Drop-in boundary for ONE path of lesterphillip/SVCC23_FastSVC (package `harana`):
+ *
+ *     harana/models/fastsvc.py:305-332   FastSVCGenerator.forward(x, s, l, spk_emb=None)
+ *
+ * plus the weight preparation that `decode_fastsvc.py:140-143` performs before it
+ * (`load_model` -> `remove_weight_norm()` -> `.to(device)`).  The reference is pure Python on
+ * PyTorch, so there is no FFI in it today; these entry points are what a ctypes / torch C++
+ * binding inside `FastSVCGenerator.forward` binds (see INTEGRATION.md, and the binding shipped in
+ * svcc23_fastsvc_amd/engine.py).
+ *
+ * Conventions
+ *   - plain C types only; no torch types.  All tensors are contiguous float32, channel-major
+ *     (B, C, T) exactly as the reference passes them (fastsvc.py:305-316).
+ *   - device memory is owned by the caller (PyTorch's caching allocator in the shipped host
+ *     code): the packed weight blob, the workspace, the inputs and the output.  The plan object
+ *     is host-only and immutable after creation, so one plan may serve several devices/streams.
+ *   - every launch goes to the hipStream_t passed in; no hidden synchronisation, no allocation
+ *     inside fastsvc_forward (hipGraph-capturable).
+ *   - return value 0 = success; negative = FASTSVC_E_*; fastsvc_last_error() gives the text.
+ */
+#ifndef FASTSVC_HIP_H
+#define FASTSVC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTSVC_ABI_VERSION 1
+#define FASTSVC_MAX_STAGES 8
+
+enum {
+    FASTSVC_OK = 0,
+    FASTSVC_E_INVALID = -1,      /* bad argument / shape invariant violated (reference: ValueError / RuntimeError) */
+    FASTSVC_E_MISSING = -2,      /* a state-dict tensor is missing or has the wrong element count */
+    FASTSVC_E_WORKSPACE = -3,    /* workspace too small */
+    FASTSVC_E_HIP = -4,          /* a HIP runtime call or kernel launch failed */
+    FASTSVC_E_UNSUPPORTED = -5   /* valid in the reference, not implemented here yet (e.g. ragged lengths) */
+};
+
+/* Constructor kwargs of FastSVCGenerator (fastsvc.py:238-246; egs/svcc23/fastsvc1/conf/fastsvc.yaml:23-29). */
+typedef struct fastsvc_config {
+    int32_t in_channels;                              /* 144 */
+    int32_t n_stages;                                 /* len(mid_channels) == len(upsampling_scales) = 4 */
+    int32_t mid_channels[FASTSVC_MAX_STAGES];         /* 192, 96, 48, 24 */
+    int32_t upsampling_scales[FASTSVC_MAX_STAGES];    /* 2, 4, 4, 5 */
+    int32_t out_channels;                             /* 1 */
+    int32_t spk_emb_size;                             /* 512 */
+    int32_t use_spk_emb;                              /* 1 */
+} fastsvc_config;
+
+/* One entry of the generator's state_dict, host memory, float32.  `name` is the reference key
+ * (SURVEY.md 8(b)), e.g. "upsampling_nets.0.conv_first.weight_g". */
+typedef struct fastsvc_tensor {
+    const char* name;
+    const float* data;
+    int64_t numel;
+} fastsvc_tensor;
+
+typedef struct fastsvc_plan fastsvc_plan;   /* opaque, host-only */
+
+int fastsvc_abi_version(void);
+const char* fastsvc_last_error(void);       /* thread-local text of the last failure */
+
+/* Replaces FastSVCGenerator.__init__ (fastsvc.py:238-303): builds the layer table, the packed
+ * weight-blob layout and the workspace layout.  No GPU needed. */
+int fastsvc_plan_create(const fastsvc_config* cfg, fastsvc_plan** out_plan);
+void fastsvc_plan_destroy(fastsvc_plan* plan);
+
+/* Size in bytes of the packed weight blob (device resident; also what rank 0 broadcasts over RCCL). */
+size_t fastsvc_weight_blob_bytes(const fastsvc_plan* plan);
+
+/* Replaces load_state_dict + remove_weight_norm (harana/utils/utils.py:243-280, fastsvc.py:342-352):
+ * takes the state dict in EITHER layout - `<layer>.weight_g` + `<layer>.weight_v` (checkpoint
+ * layout, folded here as w = g * v / ||v|| per output channel) or `<layer>.weight` (after
+ * remove_weight_norm) - plus `<layer>.bias`, and writes the kernel-layout blob (MFMA fragment
+ * order, FiLM heads concatenated, zero padded) into `host_blob` (fastsvc_weight_blob_bytes bytes,
+ * host memory).  Pure host code; the caller uploads the blob.  strict: every tensor must be present. */
+int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors, int32_t n_tensors,
+                         void* host_blob);
+
+/* Device scratch needed by one forward of B utterances of F frames each (T = F * prod(scales)). */
+size_t fastsvc_workspace_bytes(const fastsvc_plan* plan, int32_t B, int32_t F);
+
+/* Replaces FastSVCGenerator.forward (fastsvc.py:305-332).
+ *   ppg      (B, in_channels, F)   device
+ *   sine     (B, 1, T)             device   T = F * prod(upsampling_scales)
+ *   lft      (B, 1, T)             device
+ *   spk_emb  (B, spk_emb_size)     device, or NULL (reference: spk_emb=None skips InstanceNorm and
+ *                                  the speaker bias, fastsvc.py:134-140)
+ *   out      (B, out_channels, T)  device, written
+ *   lengths  must be NULL (all utterances F frames); per-utterance lengths -> FASTSVC_E_UNSUPPORTED
+ *   dev_blob packed weights on the same device; workspace >= fastsvc_workspace_bytes(B, F)
+ *   stream   hipStream_t (void* to keep this header free of HIP includes)
+ * Launches are asynchronous on `stream`; the caller synchronises. */
+int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
+                    const float* ppg, const float* sine, const float* lft, const float* spk_emb,
+                    float* out, int32_t B, int32_t F, const int32_t* lengths,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Test / profiling support: location of a named intermediate tensor inside the workspace after a
+ * forward (names as in oracle/fastsvc_oracle.py taps: "down_lft.0", "scale.2", "up.1.xmid", ...).
+ * Returns 0 and fills byte offset / element count / shape (up to 3 dims: B, C, T). */
+int fastsvc_workspace_tap(const fastsvc_plan* plan, int32_t B, int32_t F, const char* tap_name,
+                          size_t* byte_offset, int64_t* numel, int64_t shape3[3]);
+
+/* Number of kernel launches one forward enqueues and algorithmic FLOPs (2*MAC of every conv /
+ * linear, de-duplicated dataflow) per output sample - used by bench.py's roofline accounting. */
+int fastsvc_forward_launch_count(const fastsvc_plan* plan, int32_t with_spk_emb);
+double fastsvc_flops_per_sample(const fastsvc_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTSVC_HIP_H */

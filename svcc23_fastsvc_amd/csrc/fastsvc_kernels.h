@@ -1,0 +1,98 @@
+// fastsvc_kernels.h - launch-side interface between the plan/orchestration code (fastsvc_plan.cpp)
+// and the gfx950 kernels (fastsvc_kernels.hip).  Internal; the public ABI is include/fastsvc_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fastsvc {
+
+// input index modes of the generic convolution (how output-rate column t maps to the source row)
+enum : int {
+    MODE_DIRECT = 0,    // src = t
+    MODE_DECIMATE = 1,  // src = t * s        Squeeze2d == x[..., ::s]        (upsample.py:53-74)
+    MODE_STRETCH = 2    // src = t / s        Stretch2d == repeat_interleave  (upsample.py:21-50)
+};
+
+enum : int {
+    F_PRE_LRELU = 1,    // LeakyReLU(0.2) on the (transformed) input before the conv
+    F_PRE_AFFINE = 2,   // u = scale * x + shift             (fastsvc.py:131-132)
+    F_PRE_NORM = 4,     // u = (u - mean) * rstd + p         (fastsvc.py:134-139), needs F_PRE_AFFINE
+    F_POST_LRELU = 8,   // LeakyReLU(0.2) on conv + bias
+    F_STATS = 16        // accumulate sum / sum-of-squares of (scale_out * y + shift_out) per (b, co)
+};
+
+constexpr float LRELU_SLOPE = 0.2f;
+constexpr double IN_EPS = 1e-5;
+
+// All strides are in float elements.  "sig" is the conditioning-signal index (0 = lft, 1 = sine)
+// for the dual-signal launches of the down-sampling / FiLM chains; nsig == 1 otherwise.
+struct ConvParams {
+    // source tensor (nsig, B, CIN, x_T)
+    const float* x;
+    long x_sig, x_b;
+    int x_T;
+    int CIN, KC, nchunks;        // KC = channels staged per chunk (multiple of 4); nchunks*KC >= CIN
+    // packed weights / bias
+    const float* w;
+    long w_sig;
+    const float* bias;
+    long bias_sig;
+    int Q;                       // k-steps per 16*MW-row group = ntaps * nchunks * KC / 4
+    int ngroups;                 // number of 16*MW-row groups
+    // destination (nsig, B, COUT, T)
+    float* y;
+    long y_sig, y_b;
+    int T, COUT;
+    // optional residual, same geometry as y
+    const float* res;
+    long res_sig, res_b;
+    // optional rank-1 residual r[co][t] = r1w[co] * r1x[t] + r1b[co] (1x1 conv with C_in == 1)
+    const float* r1x;
+    long r1x_sig, r1x_b;
+    const float* r1w;
+    const float* r1b;
+    long r1_sig;
+    // FiLM / InstanceNorm prologue on the input channels
+    const float* ss_in;          // (B, 2*CIN, x_T): rows [0,CIN) scale, [CIN,2CIN) shift
+    long ss_in_b;
+    const double* st_in;         // (B, CIN, 2): sum, sum of squares over x_T
+    const float* spk;            // (B, CIN) speaker bias p
+    // statistics epilogue on the output channels
+    const float* ss_out;         // (B, 2*COUT, T)
+    long ss_out_b;
+    double* st_out;              // (B, COUT, 2)
+    int ntaps, dil, mode, s, flags;
+    int B;                       // batch per signal; gridDim.z = nsig * B
+    int xs;                      // LDS row stride in floats (== 16 mod 32, >= NT + 2*halo)
+    int vec;                     // 1: T % 4 == 0 and all row bases 16-byte aligned -> float4 epilogue
+};
+
+struct ConvLaunch {
+    int MW;      // 16-row co-tiles per wave (1, 2 or 3), fixed by the packed weight layout
+    int NW;      // 16-column time tiles per wave (1, 2 or 4)
+    int nsig;
+};
+
+// generic k in {1,3} dilated conv, MFMA f32 16x16x4
+hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
+
+// down-sampling stage 0, first conv (C_in = 1, k = 3, d = 1, LeakyReLU on the input):
+//   y[sig][b][co][t] = bias[co] + sum_tap w[co][tap] * lrelu(x[sig][b][t + tap - 1])
+hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, long w_sig, long b_sig,
+                           float* y, int nsig, int B, int C, int T, hipStream_t stream);
+
+// conv_last: 1x1, y[b][o][t] = bias[o] + sum_c w[o][c] * x[b][c][t]
+hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
+                                int B, int C, int O, int T, hipStream_t stream);
+
+// speaker bias for all up blocks: p[blk][b][c] = bias + W[c] . (e / max(||e||, 1e-12))
+struct SpkBlock {
+    const float* w;     // (C, E)
+    const float* bias;  // (C)
+    float* out;         // (B, C)
+    int C;
+};
+hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks, int B, int E,
+                           hipStream_t stream);
+
+}  // namespace fastsvc

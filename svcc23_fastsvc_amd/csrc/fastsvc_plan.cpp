@@ -1,0 +1,658 @@
+// fastsvc_plan.cpp - host side of the C ABI (include/fastsvc_hip.h): layer table, weight-norm fold,
+// MFMA-fragment weight packing, workspace layout and the launch sequence of one forward pass.
+//
+// Dataflow = SURVEY.md Appendix B (the de-duplicated restatement of
+// harana/models/fastsvc.py:305-340): each conditioning chain is evaluated once, the 1x1 residual
+// conv is commuted past the decimation, the two FiLM heads of the two signals are one
+// (2C -> 2C) convolution whose K dimension concatenates [u_lft ; u_sine] so that
+// scale = scale_lft + scale_sine falls out of the accumulation (fastsvc.py:129-130), and the
+// InstanceNorm statistics are produced by the epilogue of the kernel that writes the tensor.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "fastsvc_hip.h"
+#include "fastsvc_kernels.h"
+
+using namespace fastsvc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// A convolution whose weights live in the blob in MFMA fragment order.
+struct PackedConv {
+    int cin = 0, cout = 0, ntaps = 3, dil = 1;
+    int MW = 1, KC = 4, nchunks = 1, Q = 0, ngroups = 1;
+    size_t w_off = 0, b_off = 0;      // float offsets into the blob
+    size_t w_floats = 0, b_floats = 0;
+};
+
+// Source description used by the packer: virtual weight W[co][ci][tap] assembled from up to four
+// state-dict layers (FiLM heads) or one.
+struct PackSource {
+    // pieces: (layer name, co offset, ci offset); all pieces share ntaps
+    struct Piece { std::string layer; int co_off; int ci_off; };
+    std::vector<Piece> pieces;
+};
+
+struct RawParam {            // weights kept in plain row-major layout (VALU kernels)
+    std::string layer;
+    size_t w_off = 0, b_off = 0;
+    size_t w_floats = 0, b_floats = 0;
+};
+
+struct DownStage {
+    int C = 0, Cin = 0, scale = 1;
+    // k == 0: c1 and the 1x1 are raw (C_in == 1); k >= 1: packed
+    RawParam c1_raw[2], r_raw[2];
+    PackedConv r[2], c1[2], c2[2], c3[2];
+    PackedConv film[2];
+    PackedConv heads;
+};
+
+struct UpStage {
+    int C = 0, Cin = 0, scale = 1;
+    PackedConv first, res, up, d3, d9, d27;
+    RawParam emb;
+};
+
+struct BufferSpec { std::string name; size_t off_bytes; int64_t numel; int64_t shape[3]; };
+
+int choose_mw(int cout) {
+    if (cout % 48 == 0) return 3;
+    if (cout <= 16) return 1;
+    if (cout <= 32) return 2;
+    return 3;
+}
+
+}  // namespace
+
+struct fastsvc_plan {
+    fastsvc_config cfg;
+    int n = 0;
+    std::vector<int> down_scales;       // [1, s_{n-1}, ..., s_1]   (fastsvc.py:270-272)
+    std::vector<DownStage> down;
+    std::vector<UpStage> up;
+    RawParam last;
+    size_t blob_floats = 0;
+    std::vector<std::pair<PackedConv*, PackSource>> pack_jobs;
+    std::vector<RawParam*> raw_jobs;
+    double flops_per_sample = 0.0;
+
+    size_t alloc(size_t nfloats) {
+        size_t off = blob_floats;
+        blob_floats += align_up(nfloats, 64);     // 256-byte granules
+        return off;
+    }
+
+    void plan_conv(PackedConv& c, int cin, int cout, int ntaps, int dil) {
+        c.cin = cin; c.cout = cout; c.ntaps = ntaps; c.dil = dil;
+        c.MW = choose_mw(cout);
+        const int cinp = (cin + 3) / 4 * 4;
+        c.KC = cinp < 24 ? cinp : 24;
+        c.nchunks = (cinp + c.KC - 1) / c.KC;
+        c.Q = ntaps * c.nchunks * (c.KC / 4);
+        c.ngroups = (cout + 16 * c.MW - 1) / (16 * c.MW);
+        c.w_floats = (size_t)c.ngroups * c.Q * 64 * c.MW;
+        c.b_floats = (size_t)c.ngroups * 16 * c.MW;
+    }
+
+    // allocate one or two (paired lft/sine) packed convs at a constant stride
+    void add_conv(PackedConv* c, int npair, int cin, int cout, int ntaps, int dil,
+                  const std::vector<PackSource>& src) {
+        for (int i = 0; i < npair; ++i) plan_conv(c[i], cin, cout, ntaps, dil);
+        for (int i = 0; i < npair; ++i) c[i].w_off = alloc(c[i].w_floats);
+        for (int i = 0; i < npair; ++i) c[i].b_off = alloc(c[i].b_floats);
+        for (int i = 0; i < npair; ++i) pack_jobs.emplace_back(&c[i], src[i]);
+    }
+
+    void add_raw(RawParam* r, int npair, const std::vector<std::string>& layers, size_t wf, size_t bf) {
+        for (int i = 0; i < npair; ++i) { r[i].layer = layers[i]; r[i].w_floats = wf; r[i].b_floats = bf; }
+        for (int i = 0; i < npair; ++i) r[i].w_off = alloc(wf);
+        for (int i = 0; i < npair; ++i) r[i].b_off = alloc(bf);
+        for (int i = 0; i < npair; ++i) raw_jobs.push_back(&r[i]);
+    }
+};
+
+namespace {
+
+const char* SIG_NAME[2] = {"lft", "sine"};
+
+PackSource single(const std::string& layer) {
+    PackSource s;
+    s.pieces.push_back({layer, 0, 0});
+    return s;
+}
+
+int build_plan(fastsvc_plan& P) {
+    const fastsvc_config& c = P.cfg;
+    const int n = c.n_stages;
+    P.n = n;
+    P.down_scales.assign(n, 1);
+    for (int k = 1; k < n; ++k) P.down_scales[k] = c.upsampling_scales[n - k];
+    P.down.resize(n);
+    P.up.resize(n);
+    double flops = 0.0;          // per output sample
+    double rate = 1.0;           // columns per output sample at the current stage
+
+    // ---- conditioning chains (both signals), stage k runs at T / prod(down_scales[0..k]) ----
+    int cin = 1;
+    for (int k = 0; k < n; ++k) {
+        DownStage& d = P.down[k];
+        d.C = c.mid_channels[n - 1 - k];
+        d.Cin = cin;
+        d.scale = P.down_scales[k];
+        rate /= d.scale;
+        const std::string pl = "downsampling_lft." + std::to_string(k);
+        const std::string ps = "downsampling_sine." + std::to_string(k);
+        if (k == 0) {
+            P.add_raw(d.r_raw, 2, {pl + ".residual_block.0", ps + ".residual_block.0"}, (size_t)d.C * cin, d.C);
+            P.add_raw(d.c1_raw, 2, {pl + ".downsample_block.2", ps + ".downsample_block.2"}, (size_t)d.C * cin * 3, d.C);
+        } else {
+            P.add_conv(d.r, 2, cin, d.C, 1, 1, {single(pl + ".residual_block.0"), single(ps + ".residual_block.0")});
+            P.add_conv(d.c1, 2, cin, d.C, 3, 1, {single(pl + ".downsample_block.2"), single(ps + ".downsample_block.2")});
+        }
+        P.add_conv(d.c2, 2, d.C, d.C, 3, 2, {single(pl + ".downsample_block.4"), single(ps + ".downsample_block.4")});
+        P.add_conv(d.c3, 2, d.C, d.C, 3, 4, {single(pl + ".downsample_block.6"), single(ps + ".downsample_block.6")});
+        const std::string fl = "film_lft." + std::to_string(k);
+        const std::string fs = "film_sine." + std::to_string(k);
+        P.add_conv(d.film, 2, d.C, d.C, 3, 1, {single(fl + ".conv"), single(fs + ".conv")});
+        PackSource heads;
+        heads.pieces = {{fl + ".conv_scale", 0, 0}, {fs + ".conv_scale", 0, d.C},
+                        {fl + ".conv_shift", d.C, 0}, {fs + ".conv_shift", d.C, d.C}};
+        P.add_conv(&d.heads, 1, 2 * d.C, 2 * d.C, 3, 1, {heads});
+        // 2*MAC per column: 1x1 + k3 first + two k3 (C->C) + three FiLM k3 convs, two signals
+        const double per_col = 2.0 * ((double)cin * d.C + 3.0 * cin * d.C + 2.0 * 3.0 * d.C * d.C + 3.0 * 3.0 * d.C * d.C);
+        flops += 2.0 * per_col * rate;
+        cin = d.C;
+    }
+
+    // ---- up blocks ----
+    cin = c.in_channels;
+    double in_rate = 1.0;
+    for (int i = 0; i < n; ++i) in_rate /= c.upsampling_scales[i];   // ppg frames per sample
+    for (int i = 0; i < n; ++i) {
+        UpStage& u = P.up[i];
+        u.C = c.mid_channels[i];
+        u.Cin = cin;
+        u.scale = c.upsampling_scales[i];
+        const std::string p = "upsampling_nets." + std::to_string(i);
+        P.add_conv(&u.first, 1, cin, u.C, 3, 1, {single(p + ".conv_first")});
+        P.add_conv(&u.res, 1, u.C, u.C, 3, 1, {single(p + ".residual_block.1")});
+        P.add_conv(&u.up, 1, u.C, u.C, 3, 1, {single(p + ".upsample_block0.2")});
+        P.add_conv(&u.d3, 1, u.C, u.C, 3, 3, {single(p + ".conv_block1.1")});
+        P.add_conv(&u.d9, 1, u.C, u.C, 3, 9, {single(p + ".conv_block2.1")});
+        P.add_conv(&u.d27, 1, u.C, u.C, 3, 27, {single(p + ".conv_block3.1")});
+        if (c.use_spk_emb) P.add_raw(&u.emb, 1, {p + ".emb_projector"}, (size_t)u.C * c.spk_emb_size, u.C);
+        const double out_rate = in_rate * u.scale;
+        flops += 2.0 * 3.0 * cin * u.C * in_rate + 5.0 * 2.0 * 3.0 * u.C * u.C * out_rate;
+        in_rate = out_rate;
+        cin = u.C;
+    }
+    P.add_raw(&P.last, 1, {"conv_last"}, (size_t)c.out_channels * cin, c.out_channels);
+    flops += 2.0 * cin * c.out_channels;
+    P.flops_per_sample = flops;
+    return FASTSVC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight lookup / fold
+// ------------------------------------------------------------------------------------------
+struct HostLayer { std::vector<float> w; std::vector<float> b; };
+
+int fetch_layer(const std::unordered_map<std::string, const fastsvc_tensor*>& sd, const std::string& layer,
+                int cout, size_t per_out, HostLayer& out) {
+    auto bi = sd.find(layer + ".bias");
+    if (bi == sd.end() || bi->second->numel != cout)
+        return fail(FASTSVC_E_MISSING, "missing or mis-sized tensor: " + layer + ".bias");
+    out.b.assign(bi->second->data, bi->second->data + cout);
+    const int64_t wn = (int64_t)cout * (int64_t)per_out;
+    auto wi = sd.find(layer + ".weight");
+    if (wi != sd.end()) {
+        if (wi->second->numel != wn) return fail(FASTSVC_E_MISSING, "mis-sized tensor: " + layer + ".weight");
+        out.w.assign(wi->second->data, wi->second->data + wn);
+        return FASTSVC_OK;
+    }
+    auto gi = sd.find(layer + ".weight_g");
+    auto vi = sd.find(layer + ".weight_v");
+    if (gi == sd.end() || vi == sd.end())
+        return fail(FASTSVC_E_MISSING, "missing tensor: " + layer + ".weight (or .weight_g/.weight_v)");
+    if (gi->second->numel != cout || vi->second->numel != wn)
+        return fail(FASTSVC_E_MISSING, "mis-sized tensor: " + layer + ".weight_g/.weight_v");
+    // legacy torch.nn.utils.weight_norm, dim=0: w = v * (g / ||v||), norm over everything but dim 0
+    out.w.resize(wn);
+    const float* v = vi->second->data;
+    const float* g = gi->second->data;
+    for (int co = 0; co < cout; ++co) {
+        float ss = 0.f;
+        for (size_t i = 0; i < per_out; ++i) ss += v[co * per_out + i] * v[co * per_out + i];
+        const float sc = g[co] / std::sqrt(ss);
+        for (size_t i = 0; i < per_out; ++i) out.w[co * per_out + i] = v[co * per_out + i] * sc;
+    }
+    return FASTSVC_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int fastsvc_abi_version(void) { return FASTSVC_ABI_VERSION; }
+const char* fastsvc_last_error(void) { return g_err.c_str(); }
+
+int fastsvc_plan_create(const fastsvc_config* cfg, fastsvc_plan** out_plan) {
+    if (!cfg || !out_plan) return fail(FASTSVC_E_INVALID, "null argument");
+    if (cfg->n_stages < 1 || cfg->n_stages > FASTSVC_MAX_STAGES)
+        return fail(FASTSVC_E_INVALID, "n_stages out of range");
+    if (cfg->in_channels < 1 || cfg->out_channels < 1)
+        return fail(FASTSVC_E_INVALID, "channel counts must be positive");
+    for (int i = 0; i < cfg->n_stages; ++i)
+        if (cfg->mid_channels[i] < 1 || cfg->upsampling_scales[i] < 1)
+            return fail(FASTSVC_E_INVALID, "mid_channels / upsampling_scales must be positive");
+    if (cfg->use_spk_emb && cfg->spk_emb_size < 1) return fail(FASTSVC_E_INVALID, "spk_emb_size must be positive");
+    fastsvc_plan* P = new fastsvc_plan();
+    P->cfg = *cfg;
+    const int rc = build_plan(*P);
+    if (rc != FASTSVC_OK) { delete P; return rc; }
+    *out_plan = P;
+    return FASTSVC_OK;
+}
+
+void fastsvc_plan_destroy(fastsvc_plan* plan) { delete plan; }
+
+size_t fastsvc_weight_blob_bytes(const fastsvc_plan* plan) { return plan ? plan->blob_floats * sizeof(float) : 0; }
+
+double fastsvc_flops_per_sample(const fastsvc_plan* plan) { return plan ? plan->flops_per_sample : 0.0; }
+
+int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors, int32_t n_tensors,
+                         void* host_blob) {
+    if (!plan || !tensors || !host_blob) return fail(FASTSVC_E_INVALID, "null argument");
+    std::unordered_map<std::string, const fastsvc_tensor*> sd;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name || !tensors[i].data) return fail(FASTSVC_E_INVALID, "tensor entry with null name/data");
+        sd[tensors[i].name] = &tensors[i];
+    }
+    float* blob = static_cast<float*>(host_blob);
+    std::memset(blob, 0, plan->blob_floats * sizeof(float));
+
+    for (const auto& job : plan->pack_jobs) {
+        const PackedConv& c = *job.first;
+        const PackSource& src = job.second;
+        // virtual dense weight W[co][ci][tap] and bias
+        std::vector<float> W((size_t)c.cout * c.cin * c.ntaps, 0.f);
+        std::vector<float> bias(c.cout, 0.f);
+        const int npieces = (int)src.pieces.size();
+        // piece geometry: heads use 4 pieces of (C x C); single uses the whole matrix
+        const int pc_out = npieces == 1 ? c.cout : c.cout / 2;
+        const int pc_in = npieces == 1 ? c.cin : c.cin / 2;
+        for (const auto& pc : src.pieces) {
+            HostLayer L;
+            const int rc = fetch_layer(sd, pc.layer, pc_out, (size_t)pc_in * c.ntaps, L);
+            if (rc != FASTSVC_OK) return rc;
+            for (int co = 0; co < pc_out; ++co) {
+                for (int ci = 0; ci < pc_in; ++ci)
+                    for (int t = 0; t < c.ntaps; ++t)
+                        W[((size_t)(co + pc.co_off) * c.cin + ci + pc.ci_off) * c.ntaps + t] =
+                            L.w[((size_t)co * pc_in + ci) * c.ntaps + t];
+                bias[co + pc.co_off] += L.b[co];     // lft + sine biases add (fastsvc.py:129-130)
+            }
+        }
+        // fragment order: [group][q][lane][m],  q = (chunk * ntaps + tap) * (KC/4) + g
+        //   value = W[co = (group*MW + m)*16 + (lane & 15)][ci = chunk*KC + 4g + (lane >> 4)][tap]
+        float* wp = blob + c.w_off;
+        const int kg = c.KC / 4;
+        for (int grp = 0; grp < c.ngroups; ++grp)
+            for (int ch = 0; ch < c.nchunks; ++ch)
+                for (int tap = 0; tap < c.ntaps; ++tap)
+                    for (int g = 0; g < kg; ++g) {
+                        const int q = (ch * c.ntaps + tap) * kg + g;
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int ci = ch * c.KC + 4 * g + (lane >> 4);
+                            for (int m = 0; m < c.MW; ++m) {
+                                const int co = (grp * c.MW + m) * 16 + (lane & 15);
+                                float v = 0.f;
+                                if (co < c.cout && ci < c.cin) v = W[((size_t)co * c.cin + ci) * c.ntaps + tap];
+                                wp[(((size_t)grp * c.Q + q) * 64 + lane) * c.MW + m] = v;
+                            }
+                        }
+                    }
+        float* bp = blob + c.b_off;
+        for (int co = 0; co < c.cout; ++co) bp[co] = bias[co];
+    }
+    for (const RawParam* r : plan->raw_jobs) {
+        HostLayer L;
+        const int cout = (int)r->b_floats;
+        const int rc = fetch_layer(sd, r->layer, cout, r->w_floats / cout, L);
+        if (rc != FASTSVC_OK) return rc;
+        std::memcpy(blob + r->w_off, L.w.data(), r->w_floats * sizeof(float));
+        std::memcpy(blob + r->b_off, L.b.data(), r->b_floats * sizeof(float));
+    }
+    return FASTSVC_OK;
+}
+
+}  // extern "C"
+
+// ==========================================================================================
+// workspace layout
+// ==========================================================================================
+namespace {
+
+struct Workspace {
+    std::vector<BufferSpec> bufs;
+    size_t bytes = 0;
+    std::map<std::string, int> index;
+
+    size_t add(const std::string& name, int64_t d0, int64_t d1, int64_t d2, size_t elem = sizeof(float)) {
+        BufferSpec b;
+        b.name = name;
+        b.off_bytes = bytes;
+        b.numel = d0 * d1 * d2;
+        b.shape[0] = d0; b.shape[1] = d1; b.shape[2] = d2;
+        bytes += align_up((size_t)b.numel * elem, 256);
+        index[name] = (int)bufs.size();
+        bufs.push_back(b);
+        return b.off_bytes;
+    }
+    const BufferSpec* find(const std::string& name) const {
+        auto it = index.find(name);
+        return it == index.end() ? nullptr : &bufs[it->second];
+    }
+};
+
+// Every intermediate gets its own buffer (no aliasing yet): all taps stay readable after a forward.
+Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
+    Workspace ws;
+    const int n = P.n;
+    int64_t hop = 1;
+    for (int i = 0; i < n; ++i) hop *= P.cfg.upsampling_scales[i];
+    const int64_t T = hop * F;
+    ws.add("sig", 2, B, T);                                   // [lft ; sine] raw signals
+    int64_t Tk = T;
+    for (int k = 0; k < n; ++k) {
+        const DownStage& d = P.down[k];
+        Tk = Tk / d.scale;
+        const std::string s = std::to_string(k);
+        if (k > 0) ws.add("down_r." + s, 2 * B, d.C, Tk);
+        ws.add("down_c1." + s, 2 * B, d.C, Tk);
+        ws.add("down_c2." + s, 2 * B, d.C, Tk);
+        ws.add("down_h." + s, 2 * B, d.C, Tk);               // [lft batch ; sine batch]
+        ws.add("film_u." + s, B, 2 * d.C, Tk);               // channels [lft ; sine]
+        ws.add("ss." + s, B, 2 * d.C, Tk);                   // channels [scale ; shift]
+    }
+    int64_t Tin = F;
+    for (int i = 0; i < n; ++i) {
+        const UpStage& u = P.up[i];
+        const int64_t Tout = Tin * u.scale;
+        const std::string s = std::to_string(i);
+        ws.add("up." + s + ".a", B, u.C, Tin);
+        ws.add("up." + s + ".xr", B, u.C, Tout);
+        ws.add("up." + s + ".t0", B, u.C, Tout);
+        ws.add("up." + s + ".xmid", B, u.C, Tout);
+        ws.add("up." + s + ".t2", B, u.C, Tout);
+        ws.add("up." + s + ".out", B, u.C, Tout);
+        ws.add("up." + s + ".spk", B, u.C, 1);
+        ws.add("up." + s + ".stats", 3 * B, u.C, 2, sizeof(double));
+        Tin = Tout;
+    }
+    return ws;
+}
+
+hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int nsig, long pair_w_stride,
+                    long pair_b_stride, hipStream_t stream) {
+    p.CIN = c.cin; p.KC = c.KC; p.nchunks = c.nchunks;
+    p.w = blob + c.w_off; p.w_sig = pair_w_stride;
+    p.bias = blob + c.b_off; p.bias_sig = pair_b_stride;
+    p.Q = c.Q; p.ngroups = c.ngroups; p.COUT = c.cout;
+    p.ntaps = c.ntaps; p.dil = c.dil;
+    // tile choice: biggest time tile that still gives the 256 CUs a few workgroups each
+    const long zb = (long)nsig * p.B * c.ngroups;
+    int NW = 4;
+    while (NW > 1 && ((p.T + 64 * NW - 1) / (64 * NW)) * zb < 768) NW >>= 1;
+    const int NT = 64 * NW;
+    const int halo = c.ntaps == 3 ? c.dil : 0;
+    const int W = NT + 2 * halo;
+    p.xs = (W + 15) / 32 * 32 + 16;
+    p.vec = (p.T % 4 == 0) ? 1 : 0;
+    ConvLaunch L{c.MW, NW, nsig};
+    return launch_conv(p, L, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fastsvc_workspace_bytes(const fastsvc_plan* plan, int32_t B, int32_t F) {
+    if (!plan || B < 1 || F < 1) return 0;
+    return layout_workspace(*plan, B, F).bytes;
+}
+
+int fastsvc_workspace_tap(const fastsvc_plan* plan, int32_t B, int32_t F, const char* tap_name,
+                          size_t* byte_offset, int64_t* numel, int64_t shape3[3]) {
+    if (!plan || !tap_name || !byte_offset || !numel || !shape3) return fail(FASTSVC_E_INVALID, "null argument");
+    const Workspace ws = layout_workspace(*plan, B, F);
+    const BufferSpec* b = ws.find(tap_name);
+    if (!b) return fail(FASTSVC_E_INVALID, std::string("unknown tap: ") + tap_name);
+    *byte_offset = b->off_bytes;
+    *numel = b->numel;
+    for (int i = 0; i < 3; ++i) shape3[i] = b->shape[i];
+    return FASTSVC_OK;
+}
+
+int fastsvc_forward_launch_count(const fastsvc_plan* plan, int32_t with_spk_emb) {
+    if (!plan) return 0;
+    const int n = plan->n;
+    // kernels only: [speaker projection] + down stage 0 (3) + stages >= 1 (4 each)
+    // + FiLM (2 per stage) + up blocks (6 each) + conv_last
+    return (with_spk_emb ? 1 : 0) + 3 + 4 * (n - 1) + 2 * n + 6 * n + 1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(FASTSVC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
+                    const float* ppg, const float* sine, const float* lft, const float* spk_emb,
+                    float* out, int32_t B, int32_t F, const int32_t* lengths,
+                    void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!plan || !dev_blob || !ppg || !sine || !lft || !out || !workspace)
+        return fail(FASTSVC_E_INVALID, "null argument");
+    if (B < 1 || F < 1) return fail(FASTSVC_E_INVALID, "B and F must be >= 1");
+    if (lengths) return fail(FASTSVC_E_UNSUPPORTED, "per-utterance lengths are not supported yet: bucket by length on the host");
+    const fastsvc_plan& P = *plan;
+    if (spk_emb && !P.cfg.use_spk_emb)
+        return fail(FASTSVC_E_INVALID, "spk_emb given but the generator was built with use_spk_emb=False");
+    const Workspace ws = layout_workspace(P, B, F);
+    if (workspace_bytes < ws.bytes) return fail(FASTSVC_E_WORKSPACE, "workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const float* blob = static_cast<const float*>(dev_blob);
+    unsigned char* wsb = static_cast<unsigned char*>(workspace);
+    auto buf = [&](const std::string& name) -> float* {
+        return reinterpret_cast<float*>(wsb + ws.find(name)->off_bytes);
+    };
+    const int n = P.n;
+    int64_t hop = 1;
+    for (int i = 0; i < n; ++i) hop *= P.cfg.upsampling_scales[i];
+    const long T = (long)hop * F;
+    if (T > 0x7fffffffL / 4) return fail(FASTSVC_E_INVALID, "utterance too long");
+    const bool spk = spk_emb != nullptr;
+
+    // ---- raw signals side by side: sig 0 = lft, sig 1 = sine ----
+    float* sigbuf = buf("sig");
+    HIP_TRY(hipMemcpyAsync(sigbuf, lft, sizeof(float) * B * T, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(sigbuf + (long)B * T, sine, sizeof(float) * B * T, hipMemcpyDeviceToDevice, stream));
+
+    // ---- speaker bias for all blocks + zeroed InstanceNorm accumulators ----
+    if (spk) {
+        const BufferSpec* s0 = ws.find("up.0.stats");
+        const BufferSpec* sl = ws.find("up." + std::to_string(n - 1) + ".stats");
+        const size_t span = sl->off_bytes + align_up((size_t)sl->numel * sizeof(double), 256) - s0->off_bytes;
+        // the stats buffers are not contiguous (other up.* buffers sit between them): zero each
+        (void)span;
+        for (int i = 0; i < n; ++i) {
+            const BufferSpec* sb = ws.find("up." + std::to_string(i) + ".stats");
+            HIP_TRY(hipMemsetAsync(wsb + sb->off_bytes, 0, (size_t)sb->numel * sizeof(double), stream));
+        }
+        SpkBlock blocks[FASTSVC_MAX_STAGES];
+        for (int i = 0; i < n; ++i) {
+            blocks[i].w = blob + P.up[i].emb.w_off;
+            blocks[i].bias = blob + P.up[i].emb.b_off;
+            blocks[i].out = buf("up." + std::to_string(i) + ".spk");
+            blocks[i].C = P.up[i].C;
+        }
+        HIP_TRY(launch_spk_proj(spk_emb, blocks, n, B, P.cfg.spk_emb_size, stream));
+    }
+
+    // ---- conditioning chains: both signals per launch (gridDim.z = 2B) ----
+    long Tk = T;
+    const float* hprev = sigbuf;
+    int Cprev = 1;
+    long Tprev = T;
+    for (int k = 0; k < n; ++k) {
+        const DownStage& d = P.down[k];
+        Tk = Tk / d.scale;
+        const std::string s = std::to_string(k);
+        float* c1 = buf("down_c1." + s);
+        float* c2 = buf("down_c2." + s);
+        float* h = buf("down_h." + s);
+        const long tsig = (long)B * d.C * Tk;     // signal stride of the (2B, C, Tk) buffers
+        const long tb = (long)d.C * Tk;
+        ConvParams base;
+        std::memset(&base, 0, sizeof(base));
+        base.B = B; base.T = (int)Tk; base.s = 1; base.mode = MODE_DIRECT;
+        if (k == 0) {
+            HIP_TRY(launch_in1_conv(sigbuf, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
+                                    (long)(d.c1_raw[1].w_off - d.c1_raw[0].w_off),
+                                    (long)(d.c1_raw[1].b_off - d.c1_raw[0].b_off), c1, 2, B, d.C, (int)Tk, stream));
+        } else {
+            float* r = buf("down_r." + s);
+            ConvParams p = base;                                   // r = conv1x1(h_{k-1}[::s])
+            p.x = hprev; p.x_sig = (long)B * Cprev * Tprev; p.x_b = (long)Cprev * Tprev; p.x_T = (int)Tprev;
+            p.mode = MODE_DECIMATE; p.s = d.scale;
+            p.y = r; p.y_sig = tsig; p.y_b = tb;
+            HIP_TRY(run_conv(d.r[0], blob, p, 2, (long)(d.r[1].w_off - d.r[0].w_off), (long)(d.r[1].b_off - d.r[0].b_off), stream));
+            p.flags = F_PRE_LRELU;                                 // c1 = conv3_d1(lrelu(h_{k-1}[::s]))
+            p.y = c1;
+            HIP_TRY(run_conv(d.c1[0], blob, p, 2, (long)(d.c1[1].w_off - d.c1[0].w_off), (long)(d.c1[1].b_off - d.c1[0].b_off), stream));
+        }
+        {
+            ConvParams p = base;                                   // c2 = conv3_d2(lrelu(c1))
+            p.x = c1; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
+            p.flags = F_PRE_LRELU;
+            p.y = c2; p.y_sig = tsig; p.y_b = tb;
+            HIP_TRY(run_conv(d.c2[0], blob, p, 2, (long)(d.c2[1].w_off - d.c2[0].w_off), (long)(d.c2[1].b_off - d.c2[0].b_off), stream));
+            p.x = c2; p.y = h;                                     // h = conv3_d4(lrelu(c2)) + r
+            if (k == 0) {
+                p.r1x = sigbuf; p.r1x_sig = (long)B * T; p.r1x_b = T;
+                p.r1w = blob + d.r_raw[0].w_off; p.r1b = blob + d.r_raw[0].b_off;
+                p.r1_sig = (long)(d.r_raw[1].w_off - d.r_raw[0].w_off);
+                if ((d.r_raw[1].b_off - d.r_raw[0].b_off) != (d.r_raw[1].w_off - d.r_raw[0].w_off))
+                    return fail(FASTSVC_E_INVALID, "internal: rank-1 pair strides");
+            } else {
+                p.res = buf("down_r." + s); p.res_sig = tsig; p.res_b = tb;
+            }
+            HIP_TRY(run_conv(d.c3[0], blob, p, 2, (long)(d.c3[1].w_off - d.c3[0].w_off), (long)(d.c3[1].b_off - d.c3[0].b_off), stream));
+        }
+        {
+            float* u = buf("film_u." + s);                         // (B, 2C, Tk): [lft ; sine] channels
+            ConvParams p = base;
+            p.x = h; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
+            p.flags = F_POST_LRELU;
+            p.y = u; p.y_sig = tb; p.y_b = 2 * tb;
+            HIP_TRY(run_conv(d.film[0], blob, p, 2, (long)(d.film[1].w_off - d.film[0].w_off), (long)(d.film[1].b_off - d.film[0].b_off), stream));
+            ConvParams q = base;                                   // [scale ; shift] summed over both signals
+            q.x = u; q.x_sig = 0; q.x_b = 2 * tb; q.x_T = (int)Tk;
+            q.y = buf("ss." + s); q.y_sig = 0; q.y_b = 2 * tb;
+            HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, stream));
+        }
+        hprev = h; Cprev = d.C; Tprev = Tk;
+    }
+
+    // ---- up blocks ----
+    const float* x = ppg;
+    int Cx = P.cfg.in_channels;
+    long Tin = F;
+    for (int i = 0; i < n; ++i) {
+        const UpStage& u = P.up[i];
+        const int k = n - 1 - i;
+        const long Tout = Tin * u.scale;
+        const std::string s = std::to_string(i);
+        float* a = buf("up." + s + ".a");
+        float* xr = buf("up." + s + ".xr");
+        float* t0 = buf("up." + s + ".t0");
+        float* xm = buf("up." + s + ".xmid");
+        float* t2 = buf("up." + s + ".t2");
+        float* xo = buf("up." + s + ".out");
+        float* pb = buf("up." + s + ".spk");
+        double* st = reinterpret_cast<double*>(buf("up." + s + ".stats"));
+        const float* ss = buf("ss." + std::to_string(k));
+        const long cb = (long)u.C * Tout;
+        const long stn = (long)B * u.C * 2;
+        ConvParams base;
+        std::memset(&base, 0, sizeof(base));
+        base.B = B; base.s = 1; base.mode = MODE_DIRECT;
+
+        ConvParams p = base;                                       // a = conv_first(x)
+        p.x = x; p.x_b = (long)Cx * Tin; p.x_T = (int)Tin;
+        p.y = a; p.y_b = (long)u.C * Tin; p.T = (int)Tin;
+        HIP_TRY(run_conv(u.first, blob, p, 1, 0, 0, stream));
+
+        p = base;                                                  // xr = conv_res(stretch(a))
+        p.x = a; p.x_b = (long)u.C * Tin; p.x_T = (int)Tin;
+        p.mode = MODE_STRETCH; p.s = u.scale;
+        p.y = xr; p.y_b = cb; p.T = (int)Tout;
+        HIP_TRY(run_conv(u.res, blob, p, 1, 0, 0, stream));
+
+        p.flags = F_PRE_LRELU | F_POST_LRELU;                      // t0 = lrelu(conv_up(stretch(lrelu(a))))
+        p.y = t0;
+        if (spk) { p.flags |= F_STATS; p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st; }
+        HIP_TRY(run_conv(u.up, blob, p, 1, 0, 0, stream));
+
+        const int aff = F_PRE_AFFINE | F_PRE_LRELU | (spk ? F_PRE_NORM : 0);
+        p = base;                                                  // xmid = conv_d3(lrelu(aff(t0))) + xr
+        p.x = t0; p.x_b = cb; p.x_T = (int)Tout; p.T = (int)Tout;
+        p.flags = aff; p.ss_in = ss; p.ss_in_b = 2 * cb; p.st_in = st; p.spk = pb;
+        p.res = xr; p.res_b = cb;
+        p.y = xm; p.y_b = cb;
+        if (spk) { p.flags |= F_STATS; p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn; }
+        HIP_TRY(run_conv(u.d3, blob, p, 1, 0, 0, stream));
+
+        p.x = xm; p.st_in = st + stn; p.res = nullptr;             // t2 = conv_d9(lrelu(aff(xmid)))
+        p.y = t2;
+        if (spk) p.st_out = st + 2 * stn;
+        HIP_TRY(run_conv(u.d9, blob, p, 1, 0, 0, stream));
+
+        p.x = t2; p.st_in = st + 2 * stn;                          // out = conv_d27(lrelu(aff(t2))) + xmid
+        p.flags = aff; p.ss_out = nullptr; p.st_out = nullptr;
+        p.res = xm; p.res_b = cb;
+        p.y = xo;
+        HIP_TRY(run_conv(u.d27, blob, p, 1, 0, 0, stream));
+
+        x = xo; Cx = u.C; Tin = Tout;
+    }
+
+    // ---- conv_last ----
+    HIP_TRY(launch_pointwise_out(x, blob + P.last.w_off, blob + P.last.b_off, out, B, Cx,
+                                 P.cfg.out_channels, (int)T, stream));
+    return FASTSVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+"""ctypes binding of the C ABI in ``include/fastsvc_hip.h`` (``libfastsvc_hip.so``).
+
+PyTorch is used for plumbing only: device memory (weight blob, workspace, outputs) comes from its
+caching allocator and kernels are enqueued on its current HIP stream.  There is NO CPU fallback:
+if the shared library is missing or the tensors are not on a GPU, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .synth import GeneratorConfig
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfastsvc_hip.so")
+MAX_STAGES = 8
+
+# every symbol include/fastsvc_hip.h declares (checked by tests/test_boundary.py)
+ABI_SYMBOLS = (
+    "fastsvc_abi_version", "fastsvc_last_error", "fastsvc_plan_create", "fastsvc_plan_destroy",
+    "fastsvc_weight_blob_bytes", "fastsvc_pack_weights", "fastsvc_workspace_bytes",
+    "fastsvc_forward", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
+    "fastsvc_flops_per_sample",
+)
+
+
+class FastSVCError(RuntimeError):
+    pass
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [
+        ("in_channels", ctypes.c_int32),
+        ("n_stages", ctypes.c_int32),
+        ("mid_channels", ctypes.c_int32 * MAX_STAGES),
+        ("upsampling_scales", ctypes.c_int32 * MAX_STAGES),
+        ("out_channels", ctypes.c_int32),
+        ("spk_emb_size", ctypes.c_int32),
+        ("use_spk_emb", ctypes.c_int32),
+    ]
+
+
+class _Tensor(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.POINTER(ctypes.c_float)), ("numel", ctypes.c_int64)]
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree gfx950 library; raise (never fall back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise FastSVCError(
+            f"{_LIB_PATH} not found: build it with `python -m svcc23_fastsvc_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp, sz, i32, i64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int64
+    lib.fastsvc_abi_version.restype = ctypes.c_int
+    lib.fastsvc_last_error.restype = ctypes.c_char_p
+    lib.fastsvc_plan_create.argtypes = [ctypes.POINTER(_Config), ctypes.POINTER(vp)]
+    lib.fastsvc_plan_create.restype = ctypes.c_int
+    lib.fastsvc_plan_destroy.argtypes = [vp]
+    lib.fastsvc_plan_destroy.restype = None
+    lib.fastsvc_weight_blob_bytes.argtypes = [vp]
+    lib.fastsvc_weight_blob_bytes.restype = sz
+    lib.fastsvc_pack_weights.argtypes = [vp, ctypes.POINTER(_Tensor), i32, vp]
+    lib.fastsvc_pack_weights.restype = ctypes.c_int
+    lib.fastsvc_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.fastsvc_workspace_bytes.restype = sz
+    lib.fastsvc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    lib.fastsvc_forward.restype = ctypes.c_int
+    lib.fastsvc_workspace_tap.argtypes = [vp, i32, i32, ctypes.c_char_p, ctypes.POINTER(sz),
+                                          ctypes.POINTER(i64), ctypes.POINTER(i64 * 3)]
+    lib.fastsvc_workspace_tap.restype = ctypes.c_int
+    lib.fastsvc_forward_launch_count.argtypes = [vp, i32]
+    lib.fastsvc_forward_launch_count.restype = ctypes.c_int
+    lib.fastsvc_flops_per_sample.argtypes = [vp]
+    lib.fastsvc_flops_per_sample.restype = ctypes.c_double
+    if lib.fastsvc_abi_version() != 1:
+        raise FastSVCError("libfastsvc_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def _check(lib, rc: int, what: str):
+    if rc != 0:
+        msg = lib.fastsvc_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise FastSVCError(f"{what} failed ({rc}): {msg}")
+
+
+class Plan:
+    """Host-only plan (layer table + blob / workspace layout) for one generator configuration."""
+
+    def __init__(self, cfg: GeneratorConfig):
+        self.cfg = cfg
+        self.lib = load_library()
+        if cfg.n_stages > MAX_STAGES or len(cfg.upsampling_scales) != cfg.n_stages:
+            raise ValueError("mid_channels / upsampling_scales must have equal length <= 8")
+        c = _Config()
+        c.in_channels = cfg.in_channels
+        c.n_stages = cfg.n_stages
+        for i in range(cfg.n_stages):
+            c.mid_channels[i] = cfg.mid_channels[i]
+            c.upsampling_scales[i] = cfg.upsampling_scales[i]
+        c.out_channels = cfg.out_channels
+        c.spk_emb_size = cfg.spk_emb_size
+        c.use_spk_emb = 1 if cfg.use_spk_emb else 0
+        handle = ctypes.c_void_p()
+        _check(self.lib, self.lib.fastsvc_plan_create(ctypes.byref(c), ctypes.byref(handle)), "fastsvc_plan_create")
+        self._h = handle
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.fastsvc_plan_destroy(h)
+            self._h = None
+
+    @property
+    def blob_bytes(self) -> int:
+        return int(self.lib.fastsvc_weight_blob_bytes(self._h))
+
+    @property
+    def flops_per_sample(self) -> float:
+        return float(self.lib.fastsvc_flops_per_sample(self._h))
+
+    def launch_count(self, with_spk: bool = True) -> int:
+        return int(self.lib.fastsvc_forward_launch_count(self._h, 1 if with_spk else 0))
+
+    def workspace_bytes(self, B: int, F: int) -> int:
+        return int(self.lib.fastsvc_workspace_bytes(self._h, B, F))
+
+    def pack(self, state_dict: Mapping[str, object]) -> torch.Tensor:
+        """Fold weight-norm and pack a state dict (either key layout) into the kernel blob.
+
+        Returns a CPU float32 tensor of ``blob_bytes`` bytes (upload or broadcast it)."""
+        keep = []
+        arr = (_Tensor * len(state_dict))()
+        for i, (k, v) in enumerate(state_dict.items()):
+            if isinstance(v, torch.Tensor):
+                v = v.detach().to("cpu", torch.float32).contiguous().numpy()
+            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+            name = k.encode("utf-8")
+            keep.append((a, name))
+            arr[i].name = name
+            arr[i].data = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            arr[i].numel = a.size
+        blob = torch.empty(self.blob_bytes // 4, dtype=torch.float32)
+        rc = self.lib.fastsvc_pack_weights(self._h, arr, len(state_dict), ctypes.c_void_p(blob.data_ptr()))
+        if rc == -2:
+            raise KeyError(self.lib.fastsvc_last_error().decode())
+        _check(self.lib, rc, "fastsvc_pack_weights")
+        return blob
+
+    def tap_info(self, name: str, B: int, F: int) -> Tuple[int, int, Tuple[int, int, int]]:
+        off = ctypes.c_size_t()
+        numel = ctypes.c_int64()
+        shape = (ctypes.c_int64 * 3)()
+        _check(self.lib, self.lib.fastsvc_workspace_tap(self._h, B, F, name.encode(), ctypes.byref(off),
+                                                        ctypes.byref(numel), ctypes.byref(shape)),
+               "fastsvc_workspace_tap")
+        return int(off.value), int(numel.value), (int(shape[0]), int(shape[1]), int(shape[2]))
+
+    def tap(self, name: str, B: int, F: int, workspace: torch.Tensor) -> torch.Tensor:
+        """View of a named intermediate inside ``workspace`` (valid after a forward)."""
+        off, numel, shape = self.tap_info(name, B, F)
+        if name.endswith(".stats"):
+            return workspace[off: off + numel * 8].view(torch.float64).view(shape)
+        return workspace[off: off + numel * 4].view(torch.float32).view(shape)
+
+    def forward(self, blob: torch.Tensor, ppg: torch.Tensor, sine: torch.Tensor, lft: torch.Tensor,
+                spk_emb: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Enqueue one forward on the current HIP stream of ``ppg.device``; returns (B, O, T)."""
+        cfg = self.cfg
+        if not ppg.is_cuda:
+            raise FastSVCError("FastSVC HIP path needs GPU tensors (no CPU fallback); got " + str(ppg.device))
+        dev = ppg.device
+        for name, t in (("sine", sine), ("lft", lft), ("spk_emb", spk_emb), ("blob", blob)):
+            if t is not None and t.device != dev:
+                raise ValueError(f"{name} is on {t.device}, expected {dev}")
+        if ppg.dim() != 3 or ppg.shape[1] != cfg.in_channels:
+            raise ValueError(f"ppg must be (B, {cfg.in_channels}, F), got {tuple(ppg.shape)}")
+        B, _, F = ppg.shape
+        T = F * cfg.hop
+        for name, t in (("sine", sine), ("lft", lft)):
+            if tuple(t.shape) != (B, 1, T):
+                raise ValueError(f"{name} must be (B, 1, F*{cfg.hop}) = {(B, 1, T)}, got {tuple(t.shape)}")
+        if spk_emb is not None and tuple(spk_emb.shape) != (B, cfg.spk_emb_size):
+            raise ValueError(f"spk_emb must be {(B, cfg.spk_emb_size)}, got {tuple(spk_emb.shape)}")
+        ppg, sine, lft = (t.to(torch.float32).contiguous() for t in (ppg, sine, lft))
+        if spk_emb is not None:
+            spk_emb = spk_emb.to(torch.float32).contiguous()
+        need = self.workspace_bytes(B, F)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        if out is None:
+            out = torch.empty((B, cfg.out_channels, T), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = self.lib.fastsvc_forward(
+                self._h, ctypes.c_void_p(blob.data_ptr()),
+                ctypes.c_void_p(ppg.data_ptr()), ctypes.c_void_p(sine.data_ptr()),
+                ctypes.c_void_p(lft.data_ptr()),
+                ctypes.c_void_p(spk_emb.data_ptr()) if spk_emb is not None else None,
+                ctypes.c_void_p(out.data_ptr()), B, F, None,
+                ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), ctypes.c_void_p(stream))
+        _check(self.lib, rc, "fastsvc_forward")
+        self._last_workspace = workspace      # keep alive until the stream has consumed it
+        return out
