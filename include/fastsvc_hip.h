@@ -109,6 +109,25 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
 int fastsvc_workspace_tap(const fastsvc_plan* plan, int32_t B, int32_t F, const char* tap_name,
                           size_t* byte_offset, int64_t* numel, int64_t shape3[3]);
 
+/* Per-launch timing of one forward (bench.py roofline accounting).  Same arguments as
+ * fastsvc_forward; brackets every kernel launch with hipEvents on `stream`, synchronises the
+ * stream at the end and fills one record per launch: the layer it computes, the kernel symbol
+ * (template instance) it ran, its algorithmic FLOPs (2*MAC, padding excluded) and algorithmic HBM
+ * bytes (each operand tensor once + packed weights once), and the measured duration. */
+typedef struct fastsvc_launch_record {
+    char layer[64];
+    char kernel[40];
+    double flops;
+    double bytes;
+    float ms;
+} fastsvc_launch_record;
+
+int fastsvc_forward_profile(const fastsvc_plan* plan, const void* dev_blob,
+                            const float* ppg, const float* sine, const float* lft, const float* spk_emb,
+                            float* out, int32_t B, int32_t F, const int32_t* lengths,
+                            void* workspace, size_t workspace_bytes, void* stream,
+                            fastsvc_launch_record* records, int32_t max_records, int32_t* n_records);
+
 /* Number of kernel launches one forward enqueues and algorithmic FLOPs (2*MAC of every conv /
  * linear, de-duplicated dataflow) per output sample - used by bench.py's roofline accounting. */
 int fastsvc_forward_launch_count(const fastsvc_plan* plan, int32_t with_spk_emb);

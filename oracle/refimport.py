@@ -48,6 +48,11 @@ def import_reference():
         sys.modules["torchaudio.functional"].spectrogram = None
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+    # drop any stand-in `harana` namespace (svcc23_fastsvc_amd.install_into_harana creates one
+    # when the real package is not importable) so that the real package is the one imported
+    if "harana" in sys.modules and not getattr(sys.modules["harana"], "__file__", None):
+        for name in [m for m in sys.modules if m == "harana" or m.startswith("harana.")]:
+            del sys.modules[name]
     import harana.models as ref_models  # noqa: E402
 
     return ref_models

@@ -413,8 +413,43 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
     return ws;
 }
 
+// Optional per-launch instrumentation (fastsvc_forward_profile): hipEvents on the launch stream.
+struct Profiler {
+    hipStream_t stream = nullptr;
+    std::vector<fastsvc_launch_record> recs;
+    std::vector<hipEvent_t> ev;
+    hipError_t begin(const std::string& layer, const std::string& kernel, double flops, double bytes) {
+        fastsvc_launch_record r;
+        std::memset(&r, 0, sizeof(r));
+        std::snprintf(r.layer, sizeof(r.layer), "%s", layer.c_str());
+        std::snprintf(r.kernel, sizeof(r.kernel), "%s", kernel.c_str());
+        r.flops = flops; r.bytes = bytes;
+        recs.push_back(r);
+        hipEvent_t e0, e1;
+        hipError_t e = hipEventCreate(&e0); if (e != hipSuccess) return e;
+        e = hipEventCreate(&e1); if (e != hipSuccess) return e;
+        ev.push_back(e0); ev.push_back(e1);
+        return hipEventRecord(e0, stream);
+    }
+    hipError_t end() { return hipEventRecord(ev.back(), stream); }
+    hipError_t finish() {
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        for (size_t i = 0; i < recs.size(); ++i) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+            if (e != hipSuccess) return e;
+            recs[i].ms = ms;
+        }
+        for (hipEvent_t x : ev) hipEventDestroy(x);
+        ev.clear();
+        return hipSuccess;
+    }
+};
+
 hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int nsig, long pair_w_stride,
-                    long pair_b_stride, hipStream_t stream) {
+                    long pair_b_stride, hipStream_t stream, Profiler* prof = nullptr,
+                    const char* layer = "") {
     p.CIN = c.cin; p.KC = c.KC; p.nchunks = c.nchunks;
     p.w = blob + c.w_off; p.w_sig = pair_w_stride;
     p.bias = blob + c.b_off; p.bias_sig = pair_b_stride;
@@ -430,6 +465,25 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
     p.xs = (W + 15) / 32 * 32 + 16;
     p.vec = (p.T % 4 == 0) ? 1 : 0;
     ConvLaunch L{c.MW, NW, nsig};
+    if (prof) {
+        const double cols = (double)p.T * p.B * nsig;
+        const double flops = 2.0 * c.ntaps * c.cin * c.cout * cols;
+        double in_cols = (double)p.T;                       // source columns actually needed
+        if (p.mode == MODE_STRETCH) in_cols = (double)p.x_T;
+        double el = (double)c.cin * in_cols + (double)c.cout * p.T;
+        if (p.flags & F_PRE_AFFINE) el += 2.0 * c.cin * p.T;
+        if (p.res) el += (double)c.cout * p.T;
+        if (p.r1x) el += (double)p.T;
+        if ((p.flags & F_STATS) && !((p.flags & F_PRE_AFFINE) && p.ss_in == p.ss_out)) el += 2.0 * c.cout * p.T;
+        const double bytes = 4.0 * (el * p.B * nsig + (double)(c.w_floats + c.b_floats) * nsig);
+        char kname[40];
+        std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d>", c.MW, NW);
+        hipError_t e = prof->begin(layer, kname, flops, bytes);
+        if (e != hipSuccess) return e;
+        e = launch_conv(p, L, stream);
+        if (e != hipSuccess) return e;
+        return prof->end();
+    }
     return launch_conv(p, L, stream);
 }
 
@@ -469,10 +523,10 @@ int fastsvc_forward_launch_count(const fastsvc_plan* plan, int32_t with_spk_emb)
             return fail(FASTSVC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
 
-int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
+static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                     const float* ppg, const float* sine, const float* lft, const float* spk_emb,
                     float* out, int32_t B, int32_t F, const int32_t* lengths,
-                    void* workspace, size_t workspace_bytes, void* stream_) {
+                    void* workspace, size_t workspace_bytes, void* stream_, Profiler* prof) {
     if (!plan || !dev_blob || !ppg || !sine || !lft || !out || !workspace)
         return fail(FASTSVC_E_INVALID, "null argument");
     if (B < 1 || F < 1) return fail(FASTSVC_E_INVALID, "B and F must be >= 1");
@@ -518,7 +572,11 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
             blocks[i].out = buf("up." + std::to_string(i) + ".spk");
             blocks[i].C = P.up[i].C;
         }
+        double spk_c = 0; for (int i = 0; i < n; ++i) spk_c += P.up[i].C;
+        if (prof) HIP_TRY(prof->begin("spk_proj", "spk_proj", 2.0 * spk_c * P.cfg.spk_emb_size * B,
+                                      4.0 * (spk_c * P.cfg.spk_emb_size + (double)B * P.cfg.spk_emb_size + spk_c * B)));
         HIP_TRY(launch_spk_proj(spk_emb, blocks, n, B, P.cfg.spk_emb_size, stream));
+        if (prof) HIP_TRY(prof->end());
     }
 
     // ---- conditioning chains: both signals per launch (gridDim.z = 2B) ----
@@ -539,26 +597,29 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
         std::memset(&base, 0, sizeof(base));
         base.B = B; base.T = (int)Tk; base.s = 1; base.mode = MODE_DIRECT;
         if (k == 0) {
+            if (prof) HIP_TRY(prof->begin("down.0.c1", "in1_conv", 2.0 * 3 * d.C * (double)Tk * B * 2,
+                                          4.0 * (1.0 + d.C) * (double)Tk * B * 2));
             HIP_TRY(launch_in1_conv(sigbuf, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
                                     (long)(d.c1_raw[1].w_off - d.c1_raw[0].w_off),
                                     (long)(d.c1_raw[1].b_off - d.c1_raw[0].b_off), c1, 2, B, d.C, (int)Tk, stream));
+            if (prof) HIP_TRY(prof->end());
         } else {
             float* r = buf("down_r." + s);
             ConvParams p = base;                                   // r = conv1x1(h_{k-1}[::s])
             p.x = hprev; p.x_sig = (long)B * Cprev * Tprev; p.x_b = (long)Cprev * Tprev; p.x_T = (int)Tprev;
             p.mode = MODE_DECIMATE; p.s = d.scale;
             p.y = r; p.y_sig = tsig; p.y_b = tb;
-            HIP_TRY(run_conv(d.r[0], blob, p, 2, (long)(d.r[1].w_off - d.r[0].w_off), (long)(d.r[1].b_off - d.r[0].b_off), stream));
+            HIP_TRY(run_conv(d.r[0], blob, p, 2, (long)(d.r[1].w_off - d.r[0].w_off), (long)(d.r[1].b_off - d.r[0].b_off), stream, prof, ("down." + s + ".res1x1").c_str()));
             p.flags = F_PRE_LRELU;                                 // c1 = conv3_d1(lrelu(h_{k-1}[::s]))
             p.y = c1;
-            HIP_TRY(run_conv(d.c1[0], blob, p, 2, (long)(d.c1[1].w_off - d.c1[0].w_off), (long)(d.c1[1].b_off - d.c1[0].b_off), stream));
+            HIP_TRY(run_conv(d.c1[0], blob, p, 2, (long)(d.c1[1].w_off - d.c1[0].w_off), (long)(d.c1[1].b_off - d.c1[0].b_off), stream, prof, ("down." + s + ".c1").c_str()));
         }
         {
             ConvParams p = base;                                   // c2 = conv3_d2(lrelu(c1))
             p.x = c1; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
             p.flags = F_PRE_LRELU;
             p.y = c2; p.y_sig = tsig; p.y_b = tb;
-            HIP_TRY(run_conv(d.c2[0], blob, p, 2, (long)(d.c2[1].w_off - d.c2[0].w_off), (long)(d.c2[1].b_off - d.c2[0].b_off), stream));
+            HIP_TRY(run_conv(d.c2[0], blob, p, 2, (long)(d.c2[1].w_off - d.c2[0].w_off), (long)(d.c2[1].b_off - d.c2[0].b_off), stream, prof, ("down." + s + ".c2_d2").c_str()));
             p.x = c2; p.y = h;                                     // h = conv3_d4(lrelu(c2)) + r
             if (k == 0) {
                 p.r1x = sigbuf; p.r1x_sig = (long)B * T; p.r1x_b = T;
@@ -569,7 +630,7 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
             } else {
                 p.res = buf("down_r." + s); p.res_sig = tsig; p.res_b = tb;
             }
-            HIP_TRY(run_conv(d.c3[0], blob, p, 2, (long)(d.c3[1].w_off - d.c3[0].w_off), (long)(d.c3[1].b_off - d.c3[0].b_off), stream));
+            HIP_TRY(run_conv(d.c3[0], blob, p, 2, (long)(d.c3[1].w_off - d.c3[0].w_off), (long)(d.c3[1].b_off - d.c3[0].b_off), stream, prof, ("down." + s + ".c3_d4").c_str()));
         }
         {
             float* u = buf("film_u." + s);                         // (B, 2C, Tk): [lft ; sine] channels
@@ -577,11 +638,11 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
             p.x = h; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
             p.flags = F_POST_LRELU;
             p.y = u; p.y_sig = tb; p.y_b = 2 * tb;
-            HIP_TRY(run_conv(d.film[0], blob, p, 2, (long)(d.film[1].w_off - d.film[0].w_off), (long)(d.film[1].b_off - d.film[0].b_off), stream));
+            HIP_TRY(run_conv(d.film[0], blob, p, 2, (long)(d.film[1].w_off - d.film[0].w_off), (long)(d.film[1].b_off - d.film[0].b_off), stream, prof, ("film." + s + ".conv").c_str()));
             ConvParams q = base;                                   // [scale ; shift] summed over both signals
             q.x = u; q.x_sig = 0; q.x_b = 2 * tb; q.x_T = (int)Tk;
             q.y = buf("ss." + s); q.y_sig = 0; q.y_b = 2 * tb;
-            HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, stream));
+            HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, stream, prof, ("film." + s + ".heads").c_str()));
         }
         hprev = h; Cprev = d.C; Tprev = Tk;
     }
@@ -613,18 +674,18 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
         ConvParams p = base;                                       // a = conv_first(x)
         p.x = x; p.x_b = (long)Cx * Tin; p.x_T = (int)Tin;
         p.y = a; p.y_b = (long)u.C * Tin; p.T = (int)Tin;
-        HIP_TRY(run_conv(u.first, blob, p, 1, 0, 0, stream));
+        HIP_TRY(run_conv(u.first, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".conv_first").c_str()));
 
         p = base;                                                  // xr = conv_res(stretch(a))
         p.x = a; p.x_b = (long)u.C * Tin; p.x_T = (int)Tin;
         p.mode = MODE_STRETCH; p.s = u.scale;
         p.y = xr; p.y_b = cb; p.T = (int)Tout;
-        HIP_TRY(run_conv(u.res, blob, p, 1, 0, 0, stream));
+        HIP_TRY(run_conv(u.res, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".res_stretch").c_str()));
 
         p.flags = F_PRE_LRELU | F_POST_LRELU;                      // t0 = lrelu(conv_up(stretch(lrelu(a))))
         p.y = t0;
         if (spk) { p.flags |= F_STATS; p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st; }
-        HIP_TRY(run_conv(u.up, blob, p, 1, 0, 0, stream));
+        HIP_TRY(run_conv(u.up, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".up_stretch").c_str()));
 
         const int aff = F_PRE_AFFINE | F_PRE_LRELU | (spk ? F_PRE_NORM : 0);
         p = base;                                                  // xmid = conv_d3(lrelu(aff(t0))) + xr
@@ -633,25 +694,54 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
         p.res = xr; p.res_b = cb;
         p.y = xm; p.y_b = cb;
         if (spk) { p.flags |= F_STATS; p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn; }
-        HIP_TRY(run_conv(u.d3, blob, p, 1, 0, 0, stream));
+        HIP_TRY(run_conv(u.d3, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d3").c_str()));
 
         p.x = xm; p.st_in = st + stn; p.res = nullptr;             // t2 = conv_d9(lrelu(aff(xmid)))
         p.y = t2;
         if (spk) p.st_out = st + 2 * stn;
-        HIP_TRY(run_conv(u.d9, blob, p, 1, 0, 0, stream));
+        HIP_TRY(run_conv(u.d9, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d9").c_str()));
 
         p.x = t2; p.st_in = st + 2 * stn;                          // out = conv_d27(lrelu(aff(t2))) + xmid
         p.flags = aff; p.ss_out = nullptr; p.st_out = nullptr;
         p.res = xm; p.res_b = cb;
         p.y = xo;
-        HIP_TRY(run_conv(u.d27, blob, p, 1, 0, 0, stream));
+        HIP_TRY(run_conv(u.d27, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d27").c_str()));
 
         x = xo; Cx = u.C; Tin = Tout;
     }
 
     // ---- conv_last ----
+    if (prof) HIP_TRY(prof->begin("conv_last", "pointwise_out", 2.0 * Cx * P.cfg.out_channels * (double)T * B,
+                                  4.0 * (Cx + P.cfg.out_channels) * (double)T * B));
     HIP_TRY(launch_pointwise_out(x, blob + P.last.w_off, blob + P.last.b_off, out, B, Cx,
                                  P.cfg.out_channels, (int)T, stream));
+    if (prof) HIP_TRY(prof->end());
+    return FASTSVC_OK;
+}
+
+int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
+                    const float* ppg, const float* sine, const float* lft, const float* spk_emb,
+                    float* out, int32_t B, int32_t F, const int32_t* lengths,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_impl(plan, dev_blob, ppg, sine, lft, spk_emb, out, B, F, lengths, workspace,
+                        workspace_bytes, stream, nullptr);
+}
+
+int fastsvc_forward_profile(const fastsvc_plan* plan, const void* dev_blob,
+                            const float* ppg, const float* sine, const float* lft, const float* spk_emb,
+                            float* out, int32_t B, int32_t F, const int32_t* lengths,
+                            void* workspace, size_t workspace_bytes, void* stream,
+                            fastsvc_launch_record* records, int32_t max_records, int32_t* n_records) {
+    if (!records || !n_records || max_records < 1) return fail(FASTSVC_E_INVALID, "null argument");
+    Profiler prof;
+    prof.stream = static_cast<hipStream_t>(stream);
+    const int rc = forward_impl(plan, dev_blob, ppg, sine, lft, spk_emb, out, B, F, lengths, workspace,
+                                workspace_bytes, stream, &prof);
+    if (rc != FASTSVC_OK) return rc;
+    HIP_TRY(prof.finish());
+    const int n = (int)prof.recs.size() < max_records ? (int)prof.recs.size() : max_records;
+    for (int i = 0; i < n; ++i) records[i] = prof.recs[i];
+    *n_records = n;
     return FASTSVC_OK;
 }
 

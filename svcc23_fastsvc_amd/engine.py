@@ -23,7 +23,7 @@ MAX_STAGES = 8
 ABI_SYMBOLS = (
     "fastsvc_abi_version", "fastsvc_last_error", "fastsvc_plan_create", "fastsvc_plan_destroy",
     "fastsvc_weight_blob_bytes", "fastsvc_pack_weights", "fastsvc_workspace_bytes",
-    "fastsvc_forward", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
+    "fastsvc_forward", "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
     "fastsvc_flops_per_sample",
 )
 
@@ -42,6 +42,11 @@ class _Config(ctypes.Structure):
         ("spk_emb_size", ctypes.c_int32),
         ("use_spk_emb", ctypes.c_int32),
     ]
+
+
+class _LaunchRecord(ctypes.Structure):
+    _fields_ = [("layer", ctypes.c_char * 64), ("kernel", ctypes.c_char * 40),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double), ("ms", ctypes.c_float)]
 
 
 class _Tensor(ctypes.Structure):
@@ -77,6 +82,9 @@ def load_library():
     lib.fastsvc_workspace_bytes.restype = sz
     lib.fastsvc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.fastsvc_forward.restype = ctypes.c_int
+    lib.fastsvc_forward_profile.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp,
+                                            ctypes.POINTER(_LaunchRecord), i32, ctypes.POINTER(i32)]
+    lib.fastsvc_forward_profile.restype = ctypes.c_int
     lib.fastsvc_workspace_tap.argtypes = [vp, i32, i32, ctypes.c_char_p, ctypes.POINTER(sz),
                                           ctypes.POINTER(i64), ctypes.POINTER(i64 * 3)]
     lib.fastsvc_workspace_tap.restype = ctypes.c_int
@@ -179,8 +187,11 @@ class Plan:
 
     def forward(self, blob: torch.Tensor, ppg: torch.Tensor, sine: torch.Tensor, lft: torch.Tensor,
                 spk_emb: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
-                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Enqueue one forward on the current HIP stream of ``ppg.device``; returns (B, O, T)."""
+                workspace: Optional[torch.Tensor] = None, profile: Optional[list] = None) -> torch.Tensor:
+        """Enqueue one forward on the current HIP stream of ``ppg.device``; returns (B, O, T).
+
+        With ``profile`` (a list) the launches are bracketed by hipEvents on that stream, the
+        stream is synchronised and one dict per kernel launch is appended to the list."""
         cfg = self.cfg
         if not ppg.is_cuda:
             raise FastSVCError("FastSVC HIP path needs GPU tensors (no CPU fallback); got " + str(ppg.device))
@@ -207,13 +218,23 @@ class Plan:
             out = torch.empty((B, cfg.out_channels, T), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = self.lib.fastsvc_forward(
+            common = (
                 self._h, ctypes.c_void_p(blob.data_ptr()),
                 ctypes.c_void_p(ppg.data_ptr()), ctypes.c_void_p(sine.data_ptr()),
                 ctypes.c_void_p(lft.data_ptr()),
                 ctypes.c_void_p(spk_emb.data_ptr()) if spk_emb is not None else None,
                 ctypes.c_void_p(out.data_ptr()), B, F, None,
                 ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), ctypes.c_void_p(stream))
+            if profile is None:
+                rc = self.lib.fastsvc_forward(*common)
+            else:
+                recs = (_LaunchRecord * 256)()
+                n = ctypes.c_int32(0)
+                rc = self.lib.fastsvc_forward_profile(*common, recs, 256, ctypes.byref(n))
+                if rc == 0:
+                    for i in range(n.value):
+                        profile.append(dict(layer=recs[i].layer.decode(), kernel=recs[i].kernel.decode(),
+                                            flops=recs[i].flops, bytes=recs[i].bytes, ms=recs[i].ms))
         _check(self.lib, rc, "fastsvc_forward")
         self._last_workspace = workspace      # keep alive until the stream has consumed it
         return out

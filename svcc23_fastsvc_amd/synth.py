@@ -183,7 +183,8 @@ def state_dict_keys(cfg: GeneratorConfig, weight_norm: bool = True) -> List[str]
         elif weight_norm:
             keys += [f"{L.name}.bias", f"{L.name}.weight_g", f"{L.name}.weight_v"]
         else:
-            keys += [f"{L.name}.weight", f"{L.name}.bias"]
+            # remove_weight_norm re-registers .weight after .bias
+            keys += [f"{L.name}.bias", f"{L.name}.weight"]
     return keys
 
 

@@ -1,0 +1,174 @@
+"""CPU-side tests of the drop-in boundary: the C-ABI library loads and exports every symbol the
+header declares, the host-only plan/pack entry points behave, and the nn.Module mirrors the
+reference surface (constructor, state_dict keys, weight-norm handling, error behaviour).
+No compute kernels are launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import svcc23_fastsvc_amd as A
+from svcc23_fastsvc_amd import synth as S
+from svcc23_fastsvc_amd.engine import ABI_SYMBOLS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from svcc23_fastsvc_amd.build import build
+    build()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "fastsvc_hip.h")).read()
+    declared = set(re.findall(r"\b(fastsvc_[a-z_]+)\s*\(", header))
+    assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
+    lib = ctypes.CDLL(A.library_path())
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.fastsvc_abi_version() == 1
+
+
+def test_plan_sizes_and_flops():
+    plan = A.Plan(S.FULL_CONFIG)
+    assert plan.blob_bytes % 256 == 0 and plan.blob_bytes >= 2_744_353 * 4
+    # de-duplicated dataflow, 1x1 convs after the decimation: ~193 kFLOP per output sample
+    assert 185e3 < plan.flops_per_sample < 203e3
+    assert plan.workspace_bytes(2, 10) < plan.workspace_bytes(4, 10) < plan.workspace_bytes(4, 20)
+    assert plan.launch_count(True) == plan.launch_count(False) + 1
+
+
+def test_plan_rejects_bad_config():
+    with pytest.raises(ValueError):
+        A.Plan(S.GeneratorConfig(in_channels=0))
+    with pytest.raises(ValueError):
+        A.Plan(S.GeneratorConfig(mid_channels=(8, 4), upsampling_scales=(2, 2, 2)))
+
+
+def _unpack_conv(blob, w_off, cout, cin, ntaps, MW, KC):
+    """Inverse of the documented fragment order (fastsvc_plan.cpp): returns W[co][ci][tap]."""
+    cinp = (cin + 3) // 4 * 4
+    nchunks = (cinp + KC - 1) // KC
+    kg = KC // 4
+    Q = ntaps * nchunks * kg
+    W = np.zeros((cout, cin, ntaps), np.float32)
+    for co in range(cout):
+        grp, m, l15 = co // (16 * MW), (co % (16 * MW)) // 16, co % 16
+        for ci in range(cin):
+            ch, g, lhi = ci // KC, (ci % KC) // 4, ci % 4
+            for tap in range(ntaps):
+                q = (ch * ntaps + tap) * kg + g
+                lane = lhi * 16 + l15
+                W[co, ci, tap] = blob[w_off + ((grp * Q + q) * 64 + lane) * MW + m]
+    return W
+
+
+def test_pack_first_layer_fragment_order_and_fold():
+    """The first allocation in the blob is down stage 0's raw 1x1 pair, then raw c1 pair, then the
+    packed c2 pair: check the packed c2 (24->24, MW=2, KC=24) of the lft chain against the folded
+    reference-layout weight."""
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 5)
+    plan = A.Plan(cfg)
+    blob = plan.pack(sd).numpy()
+    folded = S.fold_weight_norm(sd)
+    # raw section: r_raw[2] w (24 -> 64 each), b (64 each), c1_raw w (72 -> 128 each), b (64 each)
+    assert np.array_equal(blob[0:24], folded["downsampling_lft.0.residual_block.0.weight"].ravel())
+    assert np.array_equal(blob[64:88], folded["downsampling_sine.0.residual_block.0.weight"].ravel())
+    off_c1 = 4 * 64
+    assert np.allclose(blob[off_c1:off_c1 + 72], folded["downsampling_lft.0.downsample_block.2.weight"].ravel(), atol=2e-7)
+    off_c2 = off_c1 + 2 * 128 + 2 * 64
+    W = _unpack_conv(blob, off_c2, 24, 24, 3, 2, 24)
+    assert np.abs(W - folded["downsampling_lft.0.downsample_block.4.weight"]).max() <= 2e-7
+    # both key layouts pack to the same blob
+    blob2 = plan.pack(folded).numpy()
+    assert np.abs(blob - blob2).max() <= 2e-7
+
+
+def test_pack_is_strict():
+    cfg = S.TINY_CONFIG
+    sd = S.synth_state_dict(cfg, 5)
+    plan = A.Plan(cfg)
+    bad = dict(sd)
+    bad.pop("film_sine.2.conv_shift.bias")
+    with pytest.raises(KeyError):
+        plan.pack(bad)
+    bad = dict(sd)
+    bad["conv_last.weight_v"] = bad["conv_last.weight_v"][..., :0]
+    with pytest.raises(KeyError):
+        plan.pack(bad)
+
+
+def test_module_surface_matches_reference():
+    g = A.FastSVCGenerator()
+    assert list(g.state_dict().keys()) == S.state_dict_keys(S.FULL_CONFIG, weight_norm=True)
+    assert sum(v.numel() for v in g.state_dict().values()) == 2_751_554
+    assert g.in_channels == 144 and list(g.mid_channels) == [192, 96, 48, 24]
+    assert list(g.upsampling_scales) == [2, 4, 4, 5]
+    g.remove_weight_norm()
+    assert list(g.state_dict().keys()) == S.state_dict_keys(S.FULL_CONFIG, weight_norm=False)
+    assert sum(v.numel() for v in g.state_dict().values()) == 2_744_353
+    g.apply_weight_norm()
+    assert list(g.state_dict().keys()) == S.state_dict_keys(S.FULL_CONFIG, weight_norm=True)
+    for name in ("forward", "inference", "remove_weight_norm", "apply_weight_norm", "state_dict",
+                 "load_state_dict", "parameters", "eval", "train", "to"):
+        assert callable(getattr(g, name))
+    assert "FastSVCGenerator" in repr(g)
+
+
+def test_constructor_does_not_mutate_arguments_and_accepts_yaml_kwargs():
+    mid, scales = [192, 96, 48, 24], [2, 4, 4, 5]
+    params = dict(in_channels=144, out_channels=1, mid_channels=mid, upsampling_scales=scales,
+                  spk_emb_size=512, use_spk_emb=True)                       # fastsvc.yaml:23-29
+    g = A.FastSVCGenerator(**params)
+    assert mid == [192, 96, 48, 24] and scales == [2, 4, 4, 5]
+    g2 = A.FastSVCGenerator(use_spk_emb=False)
+    assert not any("emb_projector" in k for k in g2.state_dict())
+
+
+def test_reference_style_checkpoint_loads_strict():
+    sd = S.synth_state_dict(S.FULL_CONFIG, 11)
+    g = A.FastSVCGenerator()
+    res = g.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    # conv2d weights stay 4-D, weight_g keeps its (Cout,1,1,1) shape
+    assert g.state_dict()["upsampling_nets.0.conv_first.weight_v"].shape == (192, 144, 1, 3)
+    assert g.state_dict()["upsampling_nets.0.conv_first.weight_g"].shape == (192, 1, 1, 1)
+    assert g.state_dict()["film_lft.1.conv.weight_g"].shape == (48, 1, 1)
+
+
+def test_harana_namespace_resolution():
+    """train_fastsvc.py:700-704 / utils.py:266-275: getattr(harana.models, "FastSVCGenerator")."""
+    import sys
+    saved = {k: v for k, v in sys.modules.items() if k == "harana" or k.startswith("harana.")}
+    try:
+        A.install_into_harana()
+        import harana.models
+        cls = getattr(harana.models, "FastSVCGenerator")
+        assert cls is A.FastSVCGenerator
+    finally:
+        for k in [m for m in sys.modules if m == "harana" or m.startswith("harana.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_product_path_fails_loudly_on_cpu():
+    g = A.FastSVCGenerator().eval()
+    x, s, l = torch.zeros(1, 144, 4), torch.zeros(1, 1, 640), torch.zeros(1, 1, 640)
+    with pytest.raises(A.FastSVCError):
+        g(x, s, l, torch.zeros(1, 512))
+    with pytest.raises(NotImplementedError):
+        g.train()(x, s, l, torch.zeros(1, 512))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "svcc23_fastsvc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
