@@ -65,13 +65,22 @@ struct ConvParams {
     int B;                       // batch per signal; gridDim.z = nsig * B
     int xs;                      // LDS row stride in floats (== 16 mod 32, >= NT + 2*halo)
     int vec;                     // 1: T % 4 == 0 and all row bases 16-byte aligned -> float4 epilogue
+    int tpw;                     // pipelined kernel: consecutive time tiles walked by one workgroup
+    int dbg;                     // ablation switches for profiling (FASTSVC_DBG env var); 0 in production
 };
 
+enum : int { DBG_NO_LOAD = 1, DBG_NO_MFMA = 2, DBG_NO_EPILOGUE = 4, DBG_NO_COMMIT = 8, DBG_NO_WEIGHTS = 16 };
+
 struct ConvLaunch {
-    int MW;      // 16-row co-tiles per wave (1, 2 or 3), fixed by the packed weight layout
+    int MW;      // 16-channel tiles per wave (1, 2 or 3), fixed by the packed weight layout
     int NW;      // 16-column time tiles per wave (1, 2 or 4)
+    int WM, WN;  // waves per workgroup along output channels / time (WM * WN == 4)
     int nsig;
+    int pipe;    // 1: pipelined float4 kernel, 0: generic scalar-staging kernel (WM=1, WN=4)
 };
+
+// the pipelined kernel needs T % 4 == 0, DIRECT (x_T % 4 == 0) or STRETCH (no affine) indexing
+bool conv_pipe_supported(const ConvParams& p);
 
 // generic k in {1,3} dilated conv, MFMA f32 16x16x4
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);

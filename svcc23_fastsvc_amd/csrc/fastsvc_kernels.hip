@@ -38,24 +38,288 @@ __device__ __forceinline__ int div_small(int t, int s) {
     }
 }
 
+// One packed weight fragment = MW consecutive floats per lane.  It is kept as a VECTOR value so
+// that it lives in consecutive VGPRs: a global_load_dwordx{2,3} can then land directly in the
+// ring slot and stay in flight (an array of scalars makes hipcc load into a temporary tuple and
+// v_mov it out, which costs an s_waitcnt vmcnt(0) per fragment).
+template <int MW> struct WFrag;
+template <> struct WFrag<1> { typedef float type; };
+template <> struct WFrag<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct WFrag<3> { typedef float type __attribute__((ext_vector_type(3))); };
+
+struct __attribute__((packed, aligned(4))) PackedF3 { float a, b, c; };
+
 template <int MW>
-__device__ __forceinline__ void load_wfrag(float (&w)[MW], const float* p) {
+__device__ __forceinline__ typename WFrag<MW>::type load_wfrag(const float* p) {
     if constexpr (MW == 1) {
-        w[0] = p[0];
+        return p[0];
     } else if constexpr (MW == 2) {
-        const float2 v = *reinterpret_cast<const float2*>(p);
-        w[0] = v.x; w[1] = v.y;
-    } else if constexpr (MW == 3) {
-        // 12-byte fragment (global_load_dwordx3); base is 4-byte aligned only
-        w[0] = p[0]; w[1] = p[1]; w[2] = p[2];
+        return *reinterpret_cast<const typename WFrag<2>::type*>(p);      // 8-byte aligned by layout
     } else {
+        const PackedF3 v = *reinterpret_cast<const PackedF3*>(p);         // 12-byte fragment
+        typename WFrag<3>::type r;
+        r.x = v.a; r.y = v.b; r.z = v.c;
+        return r;
+    }
+}
+
+template <int MW>
+__device__ __forceinline__ float wfrag_get(const typename WFrag<MW>::type& w, int m) {
+    if constexpr (MW == 1) return w;
+    else return w[m];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared pieces of the two convolution kernels
+// ---------------------------------------------------------------------------------------------
+
+// Weight fragments are streamed from L2 straight into VGPRs in packed fragment order.  A "group"
+// is the kg = KC/4 <= 6 k-steps of one tap of one chunk; the register ring `wr` always holds the
+// group being multiplied, and slot j is re-requested with fragment j of the NEXT group right after
+// its last MFMA, so every fragment is in flight for a whole group (kg * NW * MW MFMAs) before it is
+// needed.  Slots are indexed statically (no register shifting: moving an in-flight load would
+// force a wait).  The group sequence is cyclic over the layer, so the stream continues seamlessly
+// across chunks and across the consecutive time tiles a workgroup walks.
+constexpr int WG_MAX = 6;
+
+template <int MW>
+struct WeightStream {
+    typename WFrag<MW>::type wr[WG_MAX];
+    const float* next;     // fragment 0 of the group after the one held in wr
+    const float* base;     // first fragment of the layer (this wave's channel group, this lane)
+    const float* end;      // one past the last
+
+    __device__ __forceinline__ void init(const float* b, int q_total, int kg) {
+        base = b;
+        end = b + (long)q_total * 64 * MW;
         #pragma unroll
-        for (int m = 0; m < MW; ++m) w[m] = p[m];
+        for (int j = 0; j < WG_MAX; ++j) {
+            wr[j] = typename WFrag<MW>::type(0.f);
+            if (j < kg) wr[j] = load_wfrag<MW>(b + (long)j * 64 * MW);
+        }
+        next = b + (long)kg * 64 * MW;
+        if (next >= end) next = base;
+    }
+};
+
+// All k-steps of one staged chunk.  xa0: this lane's LDS address for tap 0, k-group 0.
+// KG > 0: compile-time group size (straight-line steps, so hipcc can emit counted vmcnt waits
+// and keep the other fragments in flight); KG == 0: run-time group size (generic kernel).
+template <int MW, int NW, int KG>
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NW][MW], const float* xa0, int XS,
+                                           WeightStream<MW>& ws, int ntaps, int kg, int dil) {
+    for (int tap = 0; tap < ntaps; ++tap) {
+        const float* xa = xa0 + tap * dil;
+        if constexpr (KG > 0) {
+            #pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                float av[NW];
+                #pragma unroll
+                for (int n = 0; n < NW; ++n) av[n] = xa[j * 4 * XS + n * 16];
+                #pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n], wfrag_get<MW>(ws.wr[j], m), acc[n][m], 0, 0, 0);
+                ws.wr[j] = load_wfrag<MW>(ws.next + (long)j * 64 * MW);
+                // pin the re-request right behind its step: hipcc otherwise sinks all six loads to
+                // the end of the tap and waits for them at the top of the next one
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            #pragma unroll
+            for (int j = 0; j < WG_MAX; ++j) {
+                if (j < kg) {
+                    float av[NW];
+                    #pragma unroll
+                    for (int n = 0; n < NW; ++n) av[n] = xa[n * 16];
+                    #pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        #pragma unroll
+                        for (int m = 0; m < MW; ++m)
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n], wfrag_get<MW>(ws.wr[j], m), acc[n][m], 0, 0, 0);
+                    ws.wr[j] = load_wfrag<MW>(ws.next + (long)j * 64 * MW);
+                    xa += 4 * XS;
+                }
+            }
+        }
+        ws.next += (long)kg * 64 * MW;
+        if (ws.next >= ws.end) ws.next = ws.base;
+    }
+}
+
+// Pipelined kernel: unit-deep weight stream.  One unit = one K chunk of one tile = 3 taps x 6
+// k-steps = 18 fragments, all slots static.  Slot s is re-requested with fragment s of the NEXT
+// unit right after its MFMAs, so every fragment flies for a whole unit, and because the staging
+// loads of the next unit are issued at the top of the unit (younger than every fragment consumed
+// in it) the counted waits never drain them: both streams overlap the matrix work completely.
+// For single-chunk layers (C_in = 24) the "next unit" is the same chunk: the layer's weights
+// simply stay in registers.
+constexpr int UNIT_STEPS = 18;
+
+template <int MW>
+struct UnitWeightStream {
+    typename WFrag<MW>::type wr[UNIT_STEPS];
+    const float* next;     // fragment 0 of the unit after the one held in wr
+    const float* base;
+    const float* end;
+
+    __device__ __forceinline__ void init(const float* b, int q_total) {
+        base = b;
+        end = b + (long)q_total * 64 * MW;
+        #pragma unroll
+        for (int s = 0; s < UNIT_STEPS; ++s) wr[s] = load_wfrag<MW>(b + (long)s * 64 * MW);
+        next = b + (long)UNIT_STEPS * 64 * MW;
+        if (next >= end) next = base;
+    }
+};
+
+template <int MW, int NW>
+__device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0, int XS,
+                                          UnitWeightStream<MW>& ws, int dil) {
+    #pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        #pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int s = tap * 6 + j;
+            float av[NW];
+            #pragma unroll
+            for (int n = 0; n < NW; ++n) av[n] = xa0[tap * dil + j * 4 * XS + n * 16];
+            #pragma unroll
+            for (int n = 0; n < NW; ++n)
+                #pragma unroll
+                for (int m = 0; m < MW; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n], wfrag_get<MW>(ws.wr[s], m), acc[n][m], 0, 0, 0);
+            ws.wr[s] = load_wfrag<MW>(ws.next + (long)s * 64 * MW);
+            // pin the re-request right behind its step (hipcc otherwise sinks the loads to the end
+            // of the unit and waits for all of them at the top of the next one)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    ws.next += (long)UNIT_STEPS * 64 * MW;
+    if (ws.next >= ws.end) ws.next = ws.base;
+}
+
+// Epilogue of one time tile.  D layout (16x16x4 f32): lane holds column j = lane & 15 (output
+// channel) and rows i = (lane >> 4) * 4 + r (time), r = 0..3 -> four consecutive time steps per
+// lane.  s1/s2 accumulate the InstanceNorm partial sums across the tiles a workgroup walks.
+template <int MW, int NW>
+__device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&acc)[NW][MW],
+                                                   float (&s1)[MW], float (&s2)[MW],
+                                                   int sig, int b, int mg, int tcol0, bool active, int lane) {
+    const int flags = p.flags;
+    if (p.dbg & DBG_NO_EPILOGUE) {
+        // keep the accumulators live (never true for finite data), then leave
+        float keep = 0.f;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n)
+            #pragma unroll
+            for (int m = 0; m < MW; ++m) keep += acc[n][m].x + acc[n][m].y + acc[n][m].z + acc[n][m].w;
+        if (keep == 1.2345678e33f) p.y[0] = keep;
+        return;
+    }
+    if (!active) return;
+    const float* biasp = p.bias + (long)sig * p.bias_sig;
+    float* ybase = p.y + (long)sig * p.y_sig + (long)b * p.y_b;
+    const float* resbase = p.res ? p.res + (long)sig * p.res_sig + (long)b * p.res_b : nullptr;
+    const float* r1x = p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nullptr;
+    const float* ssob = (flags & F_STATS) ? p.ss_out + (long)b * p.ss_out_b : nullptr;
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int co = (mg * MW + m) * 16 + (lane & 15);
+        if (co >= p.COUT) continue;
+        const float bias = biasp[co];
+        float r1w = 0.f, r1b = 0.f;
+        if (r1x) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
+        float* yrow = ybase + (long)co * p.T;
+        const float* rrow = resbase ? resbase + (long)co * p.T : nullptr;
+        const float* scrow = ssob ? ssob + (long)co * p.T : nullptr;
+        const float* shrow = ssob ? ssob + (long)(p.COUT + co) * p.T : nullptr;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int t = tcol0 + n * 16 + (lane >> 4) * 4;
+            if (t >= p.T) continue;
+            f32x4 v = acc[n][m];
+            v += bias;
+            if (flags & F_POST_LRELU) {
+                v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
+            }
+            if (p.vec) {
+                if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + t);
+                if (r1x) v += *reinterpret_cast<const f32x4*>(r1x + t) * r1w + r1b;
+                *reinterpret_cast<f32x4*>(yrow + t) = v;
+                if (scrow) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(scrow + t) * v
+                                  + *reinterpret_cast<const f32x4*>(shrow + t);
+                    s1[m] += (u.x + u.y) + (u.z + u.w);
+                    s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+                }
+            } else {
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (t + r >= p.T) break;
+                    float e = v[r];
+                    if (rrow) e += rrow[t + r];
+                    if (r1x) e += r1x[t + r] * r1w + r1b;
+                    yrow[t + r] = e;
+                    if (scrow) {
+                        const float u = scrow[t + r] * e + shrow[t + r];
+                        s1[m] += u; s2[m] += u * u;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Flush the InstanceNorm partial sums: 4 lane groups share a channel -> shuffle; the waves that
+// share a channel -> LDS f64 atomics; one f64 global atomic per channel per workgroup.
+template <int MW, int WM, int NTHREADS>
+__device__ __forceinline__ void stats_flush(const ConvParams& p, double (&d1a)[MW], double (&d2a)[MW],
+                                            double* sstat, int b, int wave_m, bool active, int tid, int lane) {
+    if (!(p.flags & F_STATS) || (p.dbg & DBG_NO_EPILOGUE)) return;
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        double d1 = d1a[m], d2 = d2a[m];
+        d1 += __shfl_xor(d1, 16); d2 += __shfl_xor(d2, 16);
+        d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
+        if (active && lane < 16) {
+            const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
+            atomicAdd(&sstat[slot + 0], d1);
+            atomicAdd(&sstat[slot + 1], d2);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * 16 * MW * WM; i += NTHREADS) {
+        const int co = blockIdx.y * (WM * MW * 16) + (i >> 1);
+        if (co < p.COUT) atomicAdd(&p.st_out[((long)b * p.COUT + co) * 2 + (i & 1)], sstat[i]);
+    }
+}
+
+// InstanceNorm constants of the input channels from the producer's f64 sums (fastsvc.py:138)
+template <int NTHREADS>
+__device__ __forceinline__ void norm_constants(const ConvParams& p, int b, int CINp, int tid,
+                                               float* nmean, float* nrstd, float* nspk) {
+    const double inv_len = 1.0 / (double)p.x_T;
+    for (int c = tid; c < CINp; c += NTHREADS) {
+        float m = 0.f, r = 0.f, s = 0.f;
+        if (c < p.CIN) {
+            const double s1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
+            const double s2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
+            const double mean = s1 * inv_len;
+            double var = s2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
+            var = var > 0.0 ? var : 0.0;
+            m = (float)mean;
+            r = (float)(1.0 / sqrt(var + IN_EPS));
+            s = p.spk[(long)b * p.CIN + c];
+        }
+        nmean[c] = m; nrstd[c] = r; nspk[c] = s;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Generic convolution.  gridDim = (ceil(T / NT), ceil(ngroups / WM), nsig * B)
+// Generic convolution (any length, any index mode; scalar staging).  Used for the decimating
+// layers and whenever T is not a multiple of 4.  gridDim = (ceil(T/NT), ceil(ngroups/WM), nsig*B)
 // ---------------------------------------------------------------------------------------------
 template <int MW, int NW, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN)
@@ -87,28 +351,11 @@ void conv_mfma_kernel(const ConvParams p) {
     float* nrstd = nmean + CINp;
     float* nspk = nrstd + CINp;
     float* Xs = nspk + CINp;                                                   // [KC][XS]
-    // (CINp is a multiple of 4, so Xs stays 16-byte aligned)
 
     if (p.flags & F_STATS) {
         for (int i = tid; i < 2 * 16 * MW * WM; i += NTHREADS) sstat[i] = 0.0;
     }
-    if (p.flags & F_PRE_NORM) {
-        const double inv_len = 1.0 / (double)p.x_T;
-        for (int c = tid; c < CINp; c += NTHREADS) {
-            float m = 0.f, r = 0.f, s = 0.f;
-            if (c < p.CIN) {
-                const double s1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
-                const double s2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
-                const double mean = s1 * inv_len;
-                double var = s2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
-                var = var > 0.0 ? var : 0.0;
-                m = (float)mean;
-                r = (float)(1.0 / sqrt(var + IN_EPS));
-                s = p.spk[(long)b * p.CIN + c];
-            }
-            nmean[c] = m; nrstd[c] = r; nspk[c] = s;
-        }
-    }
+    if (p.flags & F_PRE_NORM) norm_constants<NTHREADS>(p, b, CINp, tid, nmean, nrstd, nspk);
 
     f32x4 acc[NW][MW];
     #pragma unroll
@@ -119,14 +366,13 @@ void conv_mfma_kernel(const ConvParams p) {
     const float* xbase = p.x + (long)sig * p.x_sig + (long)b * p.x_b;
     const float* ssbase = (p.flags & F_PRE_AFFINE) ? p.ss_in + (long)b * p.ss_in_b : nullptr;
     const int kg = p.KC >> 2;
-    const int steps = p.ntaps * kg;
-    const float* wchunk = p.w + (long)sig * p.w_sig + ((long)mg * p.Q * 64 + lane) * MW;
+    WeightStream<MW> wst;
+    wst.init(p.w + (long)sig * p.w_sig + ((long)(active ? mg : 0) * p.Q * 64 + lane) * MW, p.Q, kg);
     const int flags = p.flags;
     const int mode = p.mode;
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         __syncthreads();   // previous chunk's LDS reads are done (first pass: norm constants visible)
-        // ---- stage KC input rows [t0 - halo, t0 + NT + halo) with the prologue applied ----
         for (int r = wave; r < p.KC; r += NWAVES) {
             const int ci = ch * p.KC + r;
             float* row = Xs + r * XS;
@@ -160,120 +406,235 @@ void conv_mfma_kernel(const ConvParams p) {
             }
         }
         __syncthreads();
-        // ---- implicit GEMM over this chunk: steps = ntaps * KC/4 MFMA k-steps ----
         if (active) {
-            const float* wp = wchunk + (long)ch * steps * 64 * MW;
             const float* xa0 = Xs + (lane >> 4) * XS + (lane & 15) + wave_n * (NW * 16);
-            float wcur[MW];
-            load_wfrag<MW>(wcur, wp);
-            int g = 0, tap = 0;
-            const float* xa = xa0;
-            for (int st = 0; st < steps; ++st) {
-                float wnext[MW];
-                #pragma unroll
-                for (int m = 0; m < MW; ++m) wnext[m] = 0.f;
-                if (st + 1 < steps) load_wfrag<MW>(wnext, wp + (long)(st + 1) * 64 * MW);
-                float av[NW];
-                #pragma unroll
-                for (int n = 0; n < NW; ++n) av[n] = xa[n * 16];
-                #pragma unroll
-                for (int n = 0; n < NW; ++n)
-                    #pragma unroll
-                    for (int m = 0; m < MW; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n], wcur[m], acc[n][m], 0, 0, 0);
-                #pragma unroll
-                for (int m = 0; m < MW; ++m) wcur[m] = wnext[m];
-                ++g;
-                xa += 4 * XS;
-                if (g == kg) { g = 0; ++tap; xa = xa0 + tap * p.dil; }
-            }
+            mfma_chunk<MW, NW, 0>(acc, xa0, XS, wst, p.ntaps, kg, p.dil);
         }
     }
-
-    // ---- epilogue ----
-    // D layout (16x16x4 f32): lane holds column j = lane & 15 (output channel) and rows
-    // i = (lane >> 4) * 4 + r (time), r = 0..3  ->  four consecutive time steps per lane.
     float s1[MW], s2[MW];
+    double d1[MW], d2[MW];
     #pragma unroll
     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
+    conv_epilogue_tile<MW, NW>(p, acc, s1, s2, sig, b, mg, t0 + wave_n * (NW * 16), active, lane);
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) { d1[m] = (double)s1[m]; d2[m] = (double)s2[m]; }
+    stats_flush<MW, WM, NTHREADS>(p, d1, d2, sstat, b, wave_m, active, tid, lane);
+}
 
-    if (active) {
-        const float* biasp = p.bias + (long)sig * p.bias_sig;
-        float* ybase = p.y + (long)sig * p.y_sig + (long)b * p.y_b;
-        const float* resbase = p.res ? p.res + (long)sig * p.res_sig + (long)b * p.res_b : nullptr;
-        const float* r1x = p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nullptr;
-        const float* ssob = (flags & F_STATS) ? p.ss_out + (long)b * p.ss_out_b : nullptr;
-        #pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            const int co = (mg * MW + m) * 16 + (lane & 15);
-            if (co >= p.COUT) continue;
-            const float bias = biasp[co];
-            float r1w = 0.f, r1b = 0.f;
-            if (r1x) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
-            float* yrow = ybase + (long)co * p.T;
-            const float* rrow = resbase ? resbase + (long)co * p.T : nullptr;
-            const float* scrow = ssob ? ssob + (long)co * p.T : nullptr;
-            const float* shrow = ssob ? ssob + (long)(p.COUT + co) * p.T : nullptr;
-            #pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                const int t = t0 + wave_n * (NW * 16) + n * 16 + (lane >> 4) * 4;
-                if (t >= p.T) continue;
-                f32x4 v = acc[n][m];
-                v += bias;
-                if (flags & F_POST_LRELU) {
-                    v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
-                }
-                if (p.vec) {
-                    if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + t);
-                    if (r1x) v += *reinterpret_cast<const f32x4*>(r1x + t) * r1w + r1b;
-                    *reinterpret_cast<f32x4*>(yrow + t) = v;
-                    if (scrow) {
-                        const f32x4 u = *reinterpret_cast<const f32x4*>(scrow + t) * v
-                                      + *reinterpret_cast<const f32x4*>(shrow + t);
-                        s1[m] += (u.x + u.y) + (u.z + u.w);
-                        s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
-                    }
-                } else {
-                    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (t + r >= p.T) break;
-                        float e = v[r];
-                        if (rrow) e += rrow[t + r];
-                        if (r1x) e += r1x[t + r] * r1w + r1b;
-                        yrow[t + r] = e;
-                        if (scrow) {
-                            const float u = scrow[t + r] * e + shrow[t + r];
-                            s1[m] += u; s2[m] += u * u;
-                        }
-                    }
-                }
-            }
-        }
-    }
+// ---------------------------------------------------------------------------------------------
+// Pipelined convolution: the hot kernel.  Requires T % 4 == 0 (float4 everywhere), index mode
+// DIRECT or STRETCH, KC <= 24.
+//   * a workgroup walks p.tpw CONSECUTIVE time tiles of one (signal, batch item, channel block):
+//     the per-thread staging slots, the InstanceNorm constants and the packed-weight stream are
+//     set up once, the InstanceNorm partial sums are flushed once;
+//   * the input window of a tile starts at a multiple of 4 columns (halo rounded up to 4), so
+//     every staged item is one aligned float4; each thread owns ITEMS fixed (row, float4) slots;
+//   * software pipeline over units = (tile, K chunk) (async-stage split): the global loads of
+//     unit u+1 are issued into registers BEFORE the MFMA loop of unit u and written to the other
+//     LDS buffer AFTER it; one barrier per unit; the tile epilogue (residual loads, float4 stores)
+//     runs after that barrier so it overlaps the other waves' next MFMA loop;
+//   * waves split output channels (WM) on wide layers so that no two waves of a workgroup fetch
+//     the same packed weights, and split time (WN) on narrow ones.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int NTHREADS>
+struct StageGeom {
+    static constexpr int MAXW4 = (NT + 56) / 4;                       // halo <= 28 columns per side
+    static constexpr int ITEMS = (24 * MAXW4 + NTHREADS - 1) / NTHREADS;
+};
 
-    if (flags & F_STATS) {
-        // reduce over the 4 lane groups that share a channel, then over the WN waves via LDS f64
-        #pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            double d1 = (double)s1[m], d2 = (double)s2[m];
-            d1 += __shfl_xor(d1, 16); d2 += __shfl_xor(d2, 16);
-            d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
-            if (active && lane < 16) {
-                const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
-                atomicAdd(&sstat[slot + 0], d1);
-                atomicAdd(&sstat[slot + 1], d2);
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < 2 * 16 * MW * WM; i += NTHREADS) {
-            const int co = blockIdx.y * (WM * MW * 16) + (i >> 1);
-            if (co < p.COUT) atomicAdd(&p.st_out[((long)b * p.COUT + co) * 2 + (i & 1)], sstat[i]);
-        }
+__device__ __forceinline__ unsigned udiv_small(unsigned t, int s) {
+    switch (s) {
+        case 1: return t;
+        case 2: return t >> 1;
+        case 4: return t >> 2;
+        case 5: return __umulhi(t, 0xCCCCCCCDu) >> 2;
+        default: return t / (unsigned)s;
     }
 }
 
+template <int MW, int NW, int WM, int WN, int MODE, bool AFF>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_mfma_pipe_kernel(const ConvParams p) {
+    constexpr int NWAVES = WM * WN;
+    constexpr int NTHREADS = 64 * NWAVES;
+    constexpr int NT = 16 * NW * WN;
+    constexpr int ITEMS = StageGeom<NT, NTHREADS>::ITEMS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WN;
+    const int wave_n = wave - wave_m * WN;
+    const int z = blockIdx.z;
+    const int sig = z / p.B;
+    const int b = z - sig * p.B;
+    const int mg = blockIdx.y * WM + wave_m;
+    const bool active = mg < p.ngroups;
+    const int halo = p.dil;                      // k = 3 only
+    const int halo_al = (halo + 3) & ~3;
+    const int W4 = (NT + 2 * halo_al) >> 2;
+    const int XS = p.xs;
+    const int CINp = p.nchunks * p.KC;
+    const int flags = p.flags;
+    const int ntx = (p.T + NT - 1) / NT;
+    const int tile0 = blockIdx.x * p.tpw;
+    const int ntiles = min(p.tpw, ntx - tile0);
+    const int nunits = ntiles * p.nchunks;
+
+    double* sstat = reinterpret_cast<double*>(smem_raw);                       // [WM*MW*16][2]
+    float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);  // [CINp]
+    float* Xs0 = reinterpret_cast<float*>(ncoef + CINp);                       // [2][KC][XS]
+    const int bufsz = p.KC * XS;
+
+    if (flags & F_STATS) {
+        for (int i = tid; i < 2 * 16 * MW * WM; i += NTHREADS) sstat[i] = 0.0;
+    }
+    if (AFF && (flags & F_PRE_NORM)) {
+        // (u - mean) * rstd + p  ==  u * A + Bc  with A = rstd, Bc = p - mean * rstd
+        const double inv_len = 1.0 / (double)p.x_T;
+        for (int c = tid; c < CINp; c += NTHREADS) {
+            float2 ab = make_float2(0.f, 0.f);
+            if (c < p.CIN) {
+                const double q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
+                const double q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
+                const double mean = q1 * inv_len;
+                double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
+                var = var > 0.0 ? var : 0.0;
+                const double rstd = 1.0 / sqrt(var + IN_EPS);
+                ab.x = (float)rstd;
+                ab.y = (float)((double)p.spk[(long)b * p.CIN + c] - mean * rstd);
+            }
+            ncoef[c] = ab;
+        }
+    }
+
+    // ---- fixed per-thread staging slots: item i -> (row r, float4 q) of a chunk window ----
+    int loff[ITEMS];      // LDS float offset inside a buffer, -1: slot outside the window
+    int rr[ITEMS];        // row inside the chunk
+    int q4[ITEMS];        // first column of the slot relative to the window start
+    const float inv_w4 = 1.0f / (float)W4;
+    #pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = i * NTHREADS + tid;
+        const int r = (int)(((float)idx + 0.5f) * inv_w4);
+        const int q = idx - r * W4;
+        loff[i] = (r < p.KC) ? r * XS + 4 * q : -1;
+        rr[i] = r;
+        q4[i] = 4 * q;
+    }
+
+    f32x4 px[ITEMS];
+    f32x4 psc[AFF ? ITEMS : 1];
+    f32x4 psh[AFF ? ITEMS : 1];
+    unsigned okmask = 0;                   // bit i: slot i of the unit in flight holds real data
+    const float* xbase = p.x + (long)sig * p.x_sig + (long)b * p.x_b;
+    const float* scbase = AFF ? p.ss_in + (long)b * p.ss_in_b : nullptr;
+    const float* shbase = AFF ? scbase + (long)p.CIN * p.x_T : nullptr;
+
+    // All loads are UNCONDITIONAL (addresses clamped into the tensor, validity kept in okmask):
+    // straight-line loads let hipcc count them exactly, so the weight-stream waits inside the MFMA
+    // loop become counted vmcnt(N) instead of vmcnt(0) and these loads stay in flight.
+    auto prefetch = [&](int tl, int ch) {
+        const int t_start = (tile0 + tl) * NT - halo_al;
+        const long cbase = (long)ch * p.KC * p.x_T;
+        const int rows_left = p.CIN - ch * p.KC;          // rows >= this are channel padding
+        okmask = 0;
+        #pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int t = t_start + q4[i];
+            const bool ok = loff[i] >= 0 && (unsigned)t < (unsigned)p.T && rr[i] < rows_left;
+            okmask |= (ok ? 1u : 0u) << i;
+            const int tc = min(max(t, 0), p.T - 4);                    // T % 4 == 0, T >= 4
+            const int rc = min(rr[i], rows_left - 1);
+            if (MODE == MODE_STRETCH) {
+                const unsigned src0 = udiv_small((unsigned)tc, p.s);
+                const int ph = tc - (int)src0 * p.s;
+                const float* src = xbase + cbase + (long)rc * p.x_T + src0;
+                px[i].x = src[0];
+                px[i].y = src[udiv_small(ph + 1, p.s)];
+                px[i].z = src[udiv_small(ph + 2, p.s)];
+                px[i].w = src[udiv_small(ph + 3, p.s)];
+            } else {
+                const long off = cbase + (long)rc * p.x_T + tc;
+                px[i] = *reinterpret_cast<const f32x4*>(xbase + off);
+                if (AFF) {
+                    psc[i] = *reinterpret_cast<const f32x4*>(scbase + off);
+                    psh[i] = *reinterpret_cast<const f32x4*>(shbase + off);
+                }
+            }
+        }
+        if (p.dbg & DBG_NO_LOAD) okmask = 0;
+    };
+    auto commit = [&](int ch, float* Xs) {
+        if (p.dbg & DBG_NO_COMMIT) return;
+        #pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (loff[i] < 0) continue;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};          // zero "same" padding / channel padding
+            if (okmask & (1u << i)) {
+                v = px[i];
+                if (AFF) {
+                    v = psc[i] * v + psh[i];
+                    if (flags & F_PRE_NORM) {
+                        const float2 ab = ncoef[ch * p.KC + rr[i]];
+                        v = v * ab.x + ab.y;
+                    }
+                }
+                if (flags & F_PRE_LRELU) {
+                    v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
+                }
+            }
+            *reinterpret_cast<f32x4*>(Xs + loff[i]) = v;
+        }
+    };
+
+    f32x4 acc[NW][MW];
+    float s1[MW], s2[MW];
+    double d1[MW], d2[MW];
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; d1[m] = 0.0; d2[m] = 0.0; }
+
+    UnitWeightStream<MW> wst;
+    wst.init(p.w + (long)sig * p.w_sig + ((long)(active ? mg : 0) * p.Q * 64 + lane) * MW,
+             (p.dbg & DBG_NO_WEIGHTS) ? UNIT_STEPS : p.Q);
+    const int colbase = (lane >> 4) * XS + (lane & 15) + wave_n * (NW * 16) + (halo_al - halo);
+
+    prefetch(0, 0);
+    __syncthreads();                       // norm coefficients visible
+    commit(0, Xs0);
+    __syncthreads();
+    int u = 0;
+    for (int tl = 0; tl < ntiles; ++tl) {
+        #pragma unroll
+        for (int n = 0; n < NW; ++n)
+            #pragma unroll
+            for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
+            const bool more = u + 1 < nunits;
+            const int nch = (ch + 1 < p.nchunks) ? ch + 1 : 0;
+            const int ntl = (ch + 1 < p.nchunks) ? tl : tl + 1;
+            if (more) prefetch(ntl, nch);                              // loads in flight ...
+            if (active && !(p.dbg & DBG_NO_MFMA))
+                mfma_unit<MW, NW>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
+            if (more) {
+                commit(nch, Xs0 + ((u + 1) & 1) * bufsz);              // ... land after the MFMAs
+                __syncthreads();
+            }
+        }
+        conv_epilogue_tile<MW, NW>(p, acc, s1, s2, sig, b, mg, (tile0 + tl) * NT + wave_n * (NW * 16),
+                                   active, lane);
+        #pragma unroll
+        for (int m = 0; m < MW; ++m) {     // fp32 partials stay short (<= 4*NW elements), rest in f64
+            d1[m] += (double)s1[m]; d2[m] += (double)s2[m];
+            s1[m] = 0.f; s2[m] = 0.f;
+        }
+    }
+    stats_flush<MW, WM, NTHREADS>(p, d1, d2, sstat, b, wave_m, active, tid, lane);
+}
+
 template <int MW, int NW>
-static hipError_t launch_conv_t(const ConvParams& p, int nsig, hipStream_t stream) {
+static hipError_t launch_conv_generic(const ConvParams& p, int nsig, hipStream_t stream) {
     constexpr int WM = 1, WN = 4;
     constexpr int NT = 16 * NW * WN;
     dim3 grid((p.T + NT - 1) / NT, (p.ngroups + WM - 1) / WM, nsig * p.B);
@@ -284,10 +645,47 @@ static hipError_t launch_conv_t(const ConvParams& p, int nsig, hipStream_t strea
     return hipGetLastError();
 }
 
-int conv_tile_columns(int NW) { return 16 * NW * 4; }
+template <int MW, int NW, int WM, int WN>
+static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t stream) {
+    constexpr int NT = 16 * NW * WN;
+    const int ntx = (p.T + NT - 1) / NT;
+    const int tpw = p.tpw > 0 ? p.tpw : 1;
+    dim3 grid((ntx + tpw - 1) / tpw, (p.ngroups + WM - 1) / WM, nsig * p.B);
+    dim3 block(64 * WM * WN);
+    const int CINp = p.nchunks * p.KC;
+    const int nbuf = (p.nchunks > 1 || tpw > 1) ? 2 : 1;
+    const size_t smem = sizeof(double) * 2 * 16 * MW * WM
+                      + sizeof(float) * (2 * (size_t)CINp + (size_t)nbuf * p.KC * p.xs);
+    const bool aff = (p.flags & F_PRE_AFFINE) != 0;
+    if (p.mode == MODE_STRETCH) {
+        hipLaunchKernelGGL((conv_mfma_pipe_kernel<MW, NW, WM, WN, MODE_STRETCH, false>), grid, block, smem, stream, p);
+    } else if (aff) {
+        hipLaunchKernelGGL((conv_mfma_pipe_kernel<MW, NW, WM, WN, MODE_DIRECT, true>), grid, block, smem, stream, p);
+    } else {
+        hipLaunchKernelGGL((conv_mfma_pipe_kernel<MW, NW, WM, WN, MODE_DIRECT, false>), grid, block, smem, stream, p);
+    }
+    return hipGetLastError();
+}
+
+bool conv_pipe_supported(const ConvParams& p) {
+    if (!p.vec || p.KC != 24 || p.ntaps != 3) return false;   // 3 taps x 6 k-steps per unit, compiled in
+    if (p.mode == MODE_DIRECT) return (p.x_T % 4) == 0;
+    if (p.mode == MODE_STRETCH) return (p.flags & F_PRE_AFFINE) == 0;
+    return false;
+}
 
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream) {
-#define FASTSVC_CASE(mw, nw) if (cfg.MW == mw && cfg.NW == nw) return launch_conv_t<mw, nw>(p, cfg.nsig, stream);
+    if (cfg.pipe) {
+#define FASTSVC_PIPE(mw, nw, wm, wn) \
+        if (cfg.MW == mw && cfg.NW == nw && cfg.WM == wm && cfg.WN == wn) return launch_conv_pipe<mw, nw, wm, wn>(p, cfg.nsig, stream);
+        FASTSVC_PIPE(2, 4, 1, 4) FASTSVC_PIPE(2, 2, 1, 4) FASTSVC_PIPE(2, 1, 1, 4)
+        FASTSVC_PIPE(3, 4, 1, 4) FASTSVC_PIPE(3, 2, 1, 4) FASTSVC_PIPE(3, 1, 1, 4)
+        FASTSVC_PIPE(3, 4, 2, 2) FASTSVC_PIPE(3, 2, 2, 2) FASTSVC_PIPE(3, 1, 2, 2)
+        FASTSVC_PIPE(3, 4, 4, 1) FASTSVC_PIPE(3, 2, 4, 1)
+#undef FASTSVC_PIPE
+        return hipErrorInvalidValue;
+    }
+#define FASTSVC_CASE(mw, nw) if (cfg.MW == mw && cfg.NW == nw) return launch_conv_generic<mw, nw>(p, cfg.nsig, stream);
     FASTSVC_CASE(1, 1) FASTSVC_CASE(1, 2) FASTSVC_CASE(1, 4)
     FASTSVC_CASE(2, 1) FASTSVC_CASE(2, 2) FASTSVC_CASE(2, 4)
     FASTSVC_CASE(3, 1) FASTSVC_CASE(3, 2) FASTSVC_CASE(3, 4)
@@ -381,6 +779,8 @@ hipError_t launch_pointwise_out(const float* x, const float* w, const float* bia
 // ---------------------------------------------------------------------------------------------
 struct SpkArgs {
     SpkBlock blk[8];
+    int cstart[9];      // prefix sums of the blocks' channel counts
+    int nblocks;
 };
 
 __global__ __launch_bounds__(256)
@@ -388,7 +788,6 @@ void spk_proj_kernel(const float* __restrict__ emb, const SpkArgs args, int E) {
     extern __shared__ __attribute__((aligned(16))) float e_s[];   // [E] normalised embedding
     __shared__ float red[4];
     const int b = blockIdx.x;
-    const SpkBlock blk = args.blk[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* e = emb + (long)b * E;
     float ss = 0.f;
@@ -400,23 +799,32 @@ void spk_proj_kernel(const float* __restrict__ emb, const SpkArgs args, int E) {
     const float nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
     for (int i = tid; i < E; i += 256) e_s[i] = e[i] / nrm;
     __syncthreads();
-    for (int c = wave; c < blk.C; c += 4) {
-        const float* wr = blk.w + (long)c * E;
-        float a = 0.f;
-        for (int i = lane; i < E; i += 64) a += wr[i] * e_s[i];
-        #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0) blk.out[(long)b * blk.C + c] = a + blk.bias[c];
-    }
+    const int cglob = blockIdx.y * 4 + wave;            // one wave per output channel
+    if (cglob >= args.cstart[args.nblocks]) return;
+    int k = 0;
+    while (cglob >= args.cstart[k + 1]) ++k;
+    const SpkBlock blk = args.blk[k];
+    const int c = cglob - args.cstart[k];
+    const float* wr = blk.w + (long)c * E;
+    float a = 0.f;
+    for (int i = lane; i < E; i += 64) a += wr[i] * e_s[i];
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) blk.out[(long)b * blk.C + c] = a + blk.bias[c];
 }
 
 hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks, int B, int E,
                            hipStream_t stream) {
-    if (nblocks > 8) return hipErrorInvalidValue;
+    if (nblocks > 8 || nblocks < 1) return hipErrorInvalidValue;
     SpkArgs args;
-    for (int i = 0; i < nblocks; ++i) args.blk[i] = blocks[i];
-    for (int i = nblocks; i < 8; ++i) args.blk[i] = blocks[0];
-    hipLaunchKernelGGL(spk_proj_kernel, dim3(B, nblocks), dim3(256), sizeof(float) * E, stream,
+    args.nblocks = nblocks;
+    args.cstart[0] = 0;
+    for (int i = 0; i < 8; ++i) {
+        args.blk[i] = blocks[i < nblocks ? i : 0];
+        args.cstart[i + 1] = args.cstart[i] + (i < nblocks ? blocks[i].C : 0);
+    }
+    const int ctot = args.cstart[nblocks];
+    hipLaunchKernelGGL(spk_proj_kernel, dim3(B, (ctot + 3) / 4), dim3(256), sizeof(float) * E, stream,
                        emb, args, E);
     return hipGetLastError();
 }

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -455,16 +456,44 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
     p.bias = blob + c.b_off; p.bias_sig = pair_b_stride;
     p.Q = c.Q; p.ngroups = c.ngroups; p.COUT = c.cout;
     p.ntaps = c.ntaps; p.dil = c.dil;
-    // tile choice: biggest time tile that still gives the 256 CUs a few workgroups each
-    const long zb = (long)nsig * p.B * c.ngroups;
-    int NW = 4;
-    while (NW > 1 && ((p.T + 64 * NW - 1) / (64 * NW)) * zb < 768) NW >>= 1;
-    const int NT = 64 * NW;
-    const int halo = c.ntaps == 3 ? c.dil : 0;
-    const int W = NT + 2 * halo;
-    p.xs = (W + 15) / 32 * 32 + 16;
     p.vec = (p.T % 4 == 0) ? 1 : 0;
-    ConvLaunch L{c.MW, NW, nsig};
+    {
+        static const int dbg = std::getenv("FASTSVC_DBG") ? std::atoi(std::getenv("FASTSVC_DBG")) : 0;
+        p.dbg = dbg;
+    }
+    const int halo = c.ntaps == 3 ? c.dil : 0;
+    const long zb = (long)nsig * p.B;
+    ConvLaunch L{c.MW, 4, 1, 4, nsig, 0};
+    p.tpw = 1;
+    if (conv_pipe_supported(p)) {
+        // candidates in order of preference (big tiles, waves split over output channels on wide
+        // layers); take the first that keeps (nearly) all 256 CUs busy, else the most parallel
+        struct Cand { int NW, WM, WN; };
+        std::vector<Cand> cands;
+        if (c.MW == 3 && c.ngroups % 4 == 0) cands = {{4, 4, 1}, {4, 2, 2}, {2, 4, 1}, {2, 2, 2}, {1, 2, 2}, {1, 1, 4}};
+        else if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{4, 2, 2}, {2, 2, 2}, {4, 1, 4}, {1, 2, 2}, {2, 1, 4}, {1, 1, 4}};
+        else cands = {{4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
+        long best = -1;
+        for (const Cand& cd : cands) {
+            const int NT = 16 * cd.NW * cd.WN;
+            const long wgs = (long)((p.T + NT - 1) / NT) * ((c.ngroups + cd.WM - 1) / cd.WM) * zb;
+            if (wgs >= 224) { L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; best = wgs; break; }
+            if (wgs > best) { L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; best = wgs; }
+        }
+        L.pipe = 1;
+        // tiles per workgroup: amortise the per-workgroup set-up while keeping >= ~3 workgroups per CU
+        p.tpw = 1;
+        while (p.tpw < 8 && best / (2 * p.tpw) >= 768) p.tpw *= 2;
+        const int NT = 16 * L.NW * L.WN;
+        const int W = NT + 2 * ((halo + 3) & ~3);
+        p.xs = (W + 15) / 32 * 32 + 16;
+    } else {
+        int NW = 4;
+        while (NW > 1 && ((p.T + 64 * NW - 1) / (64 * NW)) * zb * c.ngroups < 768) NW >>= 1;
+        L.NW = NW;
+        const int W = 64 * NW + 2 * halo;
+        p.xs = (W + 15) / 32 * 32 + 16;
+    }
     if (prof) {
         const double cols = (double)p.T * p.B * nsig;
         const double flops = 2.0 * c.ntaps * c.cin * c.cout * cols;
@@ -477,7 +506,11 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if ((p.flags & F_STATS) && !((p.flags & F_PRE_AFFINE) && p.ss_in == p.ss_out)) el += 2.0 * c.cout * p.T;
         const double bytes = 4.0 * (el * p.B * nsig + (double)(c.w_floats + c.b_floats) * nsig);
         char kname[40];
-        std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d>", c.MW, NW);
+        if (L.pipe)
+            std::snprintf(kname, sizeof(kname), "conv_mfma_pipe<%d,%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN,
+                          p.mode, (p.flags & F_PRE_AFFINE) ? 1 : 0);
+        else
+            std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d,1,4>", L.MW, L.NW);
         hipError_t e = prof->begin(layer, kname, flops, bytes);
         if (e != hipSuccess) return e;
         e = launch_conv(p, L, stream);
