@@ -244,6 +244,10 @@ def forward_dedup(weights: Dict[str, np.ndarray], scales, x, s, l, spk_emb=None,
         taps[f"up.{i}.xmid"] = x_
         taps[f"up.{i}.t2"] = t2
         taps[f"up.{i}.out"] = x
+        # FiLM-affined tensors (before InstanceNorm) - what the HIP path materialises
+        taps[f"up.{i}.u1"] = sc * t0 + sh
+        taps[f"up.{i}.u2"] = sc * x_ + sh
+        taps[f"up.{i}.u3"] = sc * t2 + sh
         if p is not None:
             taps[f"up.{i}.spk"] = p.squeeze(-1)
     y = _conv(x, w, "conv_last")

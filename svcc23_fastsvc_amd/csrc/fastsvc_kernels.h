@@ -16,9 +16,10 @@ enum : int {
 enum : int {
     F_PRE_LRELU = 1,    // LeakyReLU(0.2) on the (transformed) input before the conv
     F_PRE_AFFINE = 2,   // u = scale * x + shift             (fastsvc.py:131-132)
-    F_PRE_NORM = 4,     // u = (u - mean) * rstd + p         (fastsvc.py:134-139), needs F_PRE_AFFINE
+    F_PRE_NORM = 4,     // u = (u - mean) * rstd + p         (fastsvc.py:134-139)
     F_POST_LRELU = 8,   // LeakyReLU(0.2) on conv + bias
-    F_STATS = 16        // accumulate sum / sum-of-squares of (scale_out * y + shift_out) per (b, co)
+    F_STATS = 16,       // accumulate sum / sum-of-squares of (scale_out * y + shift_out) per (b, co)
+    F_AFF_OUT = 32      // also write u = scale_out * y + shift_out to y2 (the next conv's input)
 };
 
 constexpr float LRELU_SLOPE = 0.2f;
@@ -39,10 +40,12 @@ struct ConvParams {
     long bias_sig;
     int Q;                       // k-steps per 16*MW-row group = ntaps * nchunks * KC / 4
     int ngroups;                 // number of 16*MW-row groups
-    // destination (nsig, B, COUT, T)
+    // destination (nsig, B, COUT, T); y may be null when only the FiLM-affine output y2 is needed
     float* y;
     long y_sig, y_b;
     int T, COUT;
+    float* y2;                   // (B, COUT, T): scale_out * y + shift_out  (F_AFF_OUT)
+    long y2_b;
     // optional residual, same geometry as y
     const float* res;
     long res_sig, res_b;

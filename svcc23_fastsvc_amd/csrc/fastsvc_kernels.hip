@@ -157,47 +157,71 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NW][MW], const float* xa
 // simply stay in registers.
 constexpr int UNIT_STEPS = 18;
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+
+// Fragment load through a buffer descriptor: address = SRD base (SGPRs, wave-uniform: this wave's
+// channel group) + voffset (VGPR: lane * MW * 4, constant) + soffset (SGPR: unit and step offset).
+// No per-step VGPR address arithmetic, no 64-bit address registers.
+template <int MW>
+__device__ __forceinline__ typename WFrag<MW>::type load_wfrag_buf(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    if constexpr (MW == 1) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    } else if constexpr (MW == 2) {
+        return __builtin_bit_cast(typename WFrag<2>::type, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+    } else {
+        return __builtin_bit_cast(typename WFrag<3>::type, __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff, 0));
+    }
+}
+
 template <int MW>
 struct UnitWeightStream {
+    static constexpr int STEP_BYTES = 64 * MW * 4;
+    static constexpr int UNIT_BYTES = UNIT_STEPS * STEP_BYTES;
     typename WFrag<MW>::type wr[UNIT_STEPS];
-    const float* next;     // fragment 0 of the unit after the one held in wr
-    const float* base;
-    const float* end;
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;              // lane * MW * 4
+    int next;              // byte offset of the unit after the one held in wr
+    int total;             // bytes of this channel group's packed weights
 
-    __device__ __forceinline__ void init(const float* b, int q_total) {
-        base = b;
-        end = b + (long)q_total * 64 * MW;
+    __device__ __forceinline__ void init(const float* group_base, int q_total, int lane) {
+        total = q_total * STEP_BYTES;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(group_base), 0, total, 0x00020000);
+        voff = lane * MW * 4;
         #pragma unroll
-        for (int s = 0; s < UNIT_STEPS; ++s) wr[s] = load_wfrag<MW>(b + (long)s * 64 * MW);
-        next = b + (long)UNIT_STEPS * 64 * MW;
-        if (next >= end) next = base;
+        for (int s = 0; s < UNIT_STEPS; ++s) wr[s] = load_wfrag_buf<MW>(rsrc, voff, s * STEP_BYTES);
+        next = UNIT_BYTES;
+        if (next >= total) next = 0;
     }
 };
 
 template <int MW, int NW>
 __device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0, int XS,
                                           UnitWeightStream<MW>& ws, int dil) {
+    // The LDS reads of step s+1 are issued BEFORE the MFMAs of step s (register double-buffer by
+    // full unrolling), so their latency hides under the matrix work even with one wave per SIMD.
+    float av[2][NW];
     #pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
-        #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int s = tap * 6 + j;
-            float av[NW];
+    for (int n = 0; n < NW; ++n) av[0][n] = xa0[n * 16];
+    #pragma unroll
+    for (int s = 0; s < UNIT_STEPS; ++s) {
+        if (s + 1 < UNIT_STEPS) {
+            const int tap = (s + 1) / 6, j = (s + 1) % 6;
             #pragma unroll
-            for (int n = 0; n < NW; ++n) av[n] = xa0[tap * dil + j * 4 * XS + n * 16];
-            #pragma unroll
-            for (int n = 0; n < NW; ++n)
-                #pragma unroll
-                for (int m = 0; m < MW; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n], wfrag_get<MW>(ws.wr[s], m), acc[n][m], 0, 0, 0);
-            ws.wr[s] = load_wfrag<MW>(ws.next + (long)s * 64 * MW);
-            // pin the re-request right behind its step (hipcc otherwise sinks the loads to the end
-            // of the unit and waits for all of them at the top of the next one)
-            __builtin_amdgcn_sched_barrier(0);
+            for (int n = 0; n < NW; ++n) av[(s + 1) & 1][n] = xa0[tap * dil + j * 4 * XS + n * 16];
         }
+        #pragma unroll
+        for (int n = 0; n < NW; ++n)
+            #pragma unroll
+            for (int m = 0; m < MW; ++m)
+                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][n], wfrag_get<MW>(ws.wr[s], m), acc[n][m], 0, 0, 0);
+        ws.wr[s] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + s * UnitWeightStream<MW>::STEP_BYTES);
+        // pin the re-request right behind its step (hipcc otherwise sinks the loads to the end
+        // of the unit and waits for all of them at the top of the next one)
+        __builtin_amdgcn_sched_barrier(0);
     }
-    ws.next += (long)UNIT_STEPS * 64 * MW;
-    if (ws.next >= ws.end) ws.next = ws.base;
+    ws.next += UnitWeightStream<MW>::UNIT_BYTES;
+    if (ws.next >= ws.total) ws.next = 0;
 }
 
 // Epilogue of one time tile.  D layout (16x16x4 f32): lane holds column j = lane & 15 (output
@@ -215,15 +239,16 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
         for (int n = 0; n < NW; ++n)
             #pragma unroll
             for (int m = 0; m < MW; ++m) keep += acc[n][m].x + acc[n][m].y + acc[n][m].z + acc[n][m].w;
-        if (keep == 1.2345678e33f) p.y[0] = keep;
+        if (keep == 1.2345678e33f) (p.y ? p.y : p.y2)[0] = keep;
         return;
     }
     if (!active) return;
     const float* biasp = p.bias + (long)sig * p.bias_sig;
-    float* ybase = p.y + (long)sig * p.y_sig + (long)b * p.y_b;
+    float* ybase = p.y ? p.y + (long)sig * p.y_sig + (long)b * p.y_b : nullptr;
+    float* y2base = (flags & F_AFF_OUT) ? p.y2 + (long)b * p.y2_b : nullptr;
     const float* resbase = p.res ? p.res + (long)sig * p.res_sig + (long)b * p.res_b : nullptr;
     const float* r1x = p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nullptr;
-    const float* ssob = (flags & F_STATS) ? p.ss_out + (long)b * p.ss_out_b : nullptr;
+    const float* ssob = (flags & (F_STATS | F_AFF_OUT)) ? p.ss_out + (long)b * p.ss_out_b : nullptr;
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int co = (mg * MW + m) * 16 + (lane & 15);
@@ -231,7 +256,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
         const float bias = biasp[co];
         float r1w = 0.f, r1b = 0.f;
         if (r1x) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
-        float* yrow = ybase + (long)co * p.T;
+        float* yrow = ybase ? ybase + (long)co * p.T : nullptr;
+        float* y2row = y2base ? y2base + (long)co * p.T : nullptr;
         const float* rrow = resbase ? resbase + (long)co * p.T : nullptr;
         const float* scrow = ssob ? ssob + (long)co * p.T : nullptr;
         const float* shrow = ssob ? ssob + (long)(p.COUT + co) * p.T : nullptr;
@@ -247,10 +273,11 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
             if (p.vec) {
                 if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + t);
                 if (r1x) v += *reinterpret_cast<const f32x4*>(r1x + t) * r1w + r1b;
-                *reinterpret_cast<f32x4*>(yrow + t) = v;
+                if (yrow) *reinterpret_cast<f32x4*>(yrow + t) = v;
                 if (scrow) {
                     const f32x4 u = *reinterpret_cast<const f32x4*>(scrow + t) * v
                                   + *reinterpret_cast<const f32x4*>(shrow + t);
+                    if (y2row) *reinterpret_cast<f32x4*>(y2row + t) = u;
                     s1[m] += (u.x + u.y) + (u.z + u.w);
                     s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
                 }
@@ -261,9 +288,10 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
                     float e = v[r];
                     if (rrow) e += rrow[t + r];
                     if (r1x) e += r1x[t + r] * r1w + r1b;
-                    yrow[t + r] = e;
+                    if (yrow) yrow[t + r] = e;
                     if (scrow) {
                         const float u = scrow[t + r] * e + shrow[t + r];
+                        if (y2row) y2row[t + r] = u;
                         s1[m] += u; s2[m] += u * u;
                     }
                 }
@@ -283,7 +311,7 @@ __device__ __forceinline__ void stats_flush(const ConvParams& p, double (&d1a)[M
         double d1 = d1a[m], d2 = d2a[m];
         d1 += __shfl_xor(d1, 16); d2 += __shfl_xor(d2, 16);
         d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
-        if (active && lane < 16) {
+        if (active && lane < 16) {      // waves that hold no sums (producer waves) pass active = false
             const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
             atomicAdd(&sstat[slot + 0], d1);
             atomicAdd(&sstat[slot + 1], d2);
@@ -387,8 +415,8 @@ void conv_mfma_kernel(const ConvParams p) {
             if (flags & F_PRE_AFFINE) {
                 scrow = ssbase + (long)ci * p.x_T;
                 shrow = ssbase + (long)(p.CIN + ci) * p.x_T;
-                if (flags & F_PRE_NORM) { mean = nmean[ci]; rstd = nrstd[ci]; pb = nspk[ci]; }
             }
+            if (flags & F_PRE_NORM) { mean = nmean[ci]; rstd = nrstd[ci]; pb = nspk[ci]; }
             for (int j = lane; j < W; j += 64) {
                 const int t = t0 - halo + j;
                 float v = 0.f;
@@ -396,10 +424,8 @@ void conv_mfma_kernel(const ConvParams p) {
                     const int src = (mode == MODE_DIRECT) ? t
                                   : (mode == MODE_DECIMATE) ? t * p.s : div_small(t, p.s);
                     v = xrow[src];
-                    if (flags & F_PRE_AFFINE) {
-                        v = scrow[src] * v + shrow[src];
-                        if (flags & F_PRE_NORM) v = (v - mean) * rstd + pb;
-                    }
+                    if (flags & F_PRE_AFFINE) v = scrow[src] * v + shrow[src];
+                    if (flags & F_PRE_NORM) v = (v - mean) * rstd + pb;
                     if (flags & F_PRE_LRELU) v = lrelu(v);
                 }
                 row[j] = v;
@@ -422,19 +448,21 @@ void conv_mfma_kernel(const ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pipelined convolution: the hot kernel.  Requires T % 4 == 0 (float4 everywhere), index mode
-// DIRECT or STRETCH, KC <= 24.
-//   * a workgroup walks p.tpw CONSECUTIVE time tiles of one (signal, batch item, channel block):
-//     the per-thread staging slots, the InstanceNorm constants and the packed-weight stream are
-//     set up once, the InstanceNorm partial sums are flushed once;
-//   * the input window of a tile starts at a multiple of 4 columns (halo rounded up to 4), so
-//     every staged item is one aligned float4; each thread owns ITEMS fixed (row, float4) slots;
-//   * software pipeline over units = (tile, K chunk) (async-stage split): the global loads of
-//     unit u+1 are issued into registers BEFORE the MFMA loop of unit u and written to the other
-//     LDS buffer AFTER it; one barrier per unit; the tile epilogue (residual loads, float4 stores)
-//     runs after that barrier so it overlaps the other waves' next MFMA loop;
-//   * waves split output channels (WM) on wide layers so that no two waves of a workgroup fetch
-//     the same packed weights, and split time (WN) on narrow ones.
+// Wave-specialised pipelined convolution: the hot kernel.  Requires T % 4 == 0 (float4
+// everywhere), k = 3, KC = 24, index mode DIRECT or STRETCH.
+//
+//   workgroup = 8 waves = 4 CONSUMER waves + 4 PRODUCER waves (one of each per SIMD):
+//   * consumer waves issue nothing but LDS reads, MFMAs and the packed-weight stream (unit-deep
+//     register ring, counted waits), and write the tile epilogue;
+//   * producer waves own all global staging: float4 loads of the input window (aligned window:
+//     halo rounded up to 4 columns, fixed per-thread slots, clamped unconditional addresses),
+//     two register sets deep (the loads of unit u+2 are in flight while unit u+1 is transformed:
+//     InstanceNorm-apply + speaker bias as one FMA, LeakyReLU, zero padding) and written to the
+//     LDS buffer the consumers will read next.  Each wave has its own vmcnt, so staging latency
+//     never stalls the matrix pipe, and the two roles need max(), not sum(), of their registers;
+//   * one s_barrier per unit = (time tile, K chunk); a workgroup walks p.tpw consecutive tiles of
+//     one (signal, batch item, channel block): set-up, InstanceNorm coefficients and the weight
+//     stream are paid once, the InstanceNorm partial sums are flushed once.
 // ---------------------------------------------------------------------------------------------
 template <int NT, int NTHREADS>
 struct StageGeom {
@@ -452,26 +480,98 @@ __device__ __forceinline__ unsigned udiv_small(unsigned t, int s) {
     }
 }
 
-template <int MW, int NW, int WM, int WN, int MODE, bool AFF>
-__global__ __launch_bounds__(64 * WM * WN)
-void conv_mfma_pipe_kernel(const ConvParams p) {
-    constexpr int NWAVES = WM * WN;
-    constexpr int NTHREADS = 64 * NWAVES;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long nfloats) {
+    // raw buffer over [base, base + nfloats): out-of-range loads return 0, stores are dropped
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(nfloats * 4), 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+
+// Tile epilogue of the wave-specialised kernel (T % 4 == 0).  Every tensor is addressed through a
+// buffer descriptor (wave-uniform base in SGPRs) plus ONE 32-bit byte offset per (channel, time)
+// position shared by y / y2 / residual / scale / shift: no 64-bit pointer arithmetic, few VGPRs.
+struct EpiRsrc {
+    __amdgpu_buffer_rsrc_t y, y2, res, ss, r1x;
+};
+
+template <int MW, int NW>
+__device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[NW][MW],
+                                                 float (&s1)[MW], float (&s2)[MW],
+                                                 int sig, int mg, int tcol0, bool active, int lane) {
+    const int flags = p.flags;
+    if (p.dbg & DBG_NO_EPILOGUE) {
+        float keep = 0.f;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n)
+            #pragma unroll
+            for (int m = 0; m < MW; ++m) keep += acc[n][m].x + acc[n][m].y + acc[n][m].z + acc[n][m].w;
+        if (keep == 1.2345678e33f) (p.y ? p.y : p.y2)[0] = keep;
+        return;
+    }
+    if (!active) return;
+    const float* biasp = p.bias + (long)sig * p.bias_sig;
+    const int shift_soff = p.COUT * p.T * 4;              // shift rows follow the scale rows
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int co = (mg * MW + m) * 16 + (lane & 15);
+        if (co >= p.COUT) continue;
+        const float bias = biasp[co];
+        float r1w = 0.f, r1b = 0.f;
+        if (p.r1x) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
+        const int rowoff = co * p.T;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int t = tcol0 + n * 16 + (lane >> 4) * 4;
+            if (t >= p.T) continue;
+            const int off = (rowoff + t) * 4;
+            f32x4 v = acc[n][m];
+            v += bias;
+            if (flags & F_POST_LRELU) {
+                v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
+            }
+            if (p.res) v += buf_load4(R.res, off, 0);
+            if (p.r1x) v += buf_load4(R.r1x, t * 4, 0) * r1w + r1b;
+            if (p.y) buf_store4(R.y, off, v);
+            if (flags & (F_STATS | F_AFF_OUT)) {
+                const f32x4 u = buf_load4(R.ss, off, 0) * v + buf_load4(R.ss, off, shift_soff);
+                if (flags & F_AFF_OUT) buf_store4(R.y2, off, u);
+                s1[m] += (u.x + u.y) + (u.z + u.w);
+                s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+            }
+        }
+    }
+}
+
+template <int MW, int NW, int WM, int WN, int MODE>
+__global__ __launch_bounds__(512, (MW * NW <= 8) ? 4 : 2)     // <= 128 VGPRs where two workgroups per CU fit
+void conv_mfma_ws_kernel(const ConvParams p) {
     constexpr int NT = 16 * NW * WN;
-    constexpr int ITEMS = StageGeom<NT, NTHREADS>::ITEMS;
+    constexpr int NPROD = 256;                                         // producer threads
+    constexpr int ITEMS = StageGeom<NT, NPROD>::ITEMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave / WN;
-    const int wave_n = wave - wave_m * WN;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // 0..3 consumers, 4..7 producers
+    const bool producer = wave >= 4;
+    const int cw = wave & 3;
+    const int wave_m = cw / WN;
+    const int wave_n = cw - wave_m * WN;
     const int z = blockIdx.z;
     const int sig = z / p.B;
     const int b = z - sig * p.B;
     const int mg = blockIdx.y * WM + wave_m;
-    const bool active = mg < p.ngroups;
-    const int halo = p.dil;                      // k = 3 only
+    const bool active = !producer && mg < p.ngroups;
+    const int halo = p.dil;                                            // k = 3 only
     const int halo_al = (halo + 3) & ~3;
     const int W4 = (NT + 2 * halo_al) >> 2;
     const int XS = p.xs;
@@ -488,12 +588,12 @@ void conv_mfma_pipe_kernel(const ConvParams p) {
     const int bufsz = p.KC * XS;
 
     if (flags & F_STATS) {
-        for (int i = tid; i < 2 * 16 * MW * WM; i += NTHREADS) sstat[i] = 0.0;
+        for (int i = tid; i < 2 * 16 * MW * WM; i += 512) sstat[i] = 0.0;
     }
-    if (AFF && (flags & F_PRE_NORM)) {
+    if (flags & F_PRE_NORM) {
         // (u - mean) * rstd + p  ==  u * A + Bc  with A = rstd, Bc = p - mean * rstd
         const double inv_len = 1.0 / (double)p.x_T;
-        for (int c = tid; c < CINp; c += NTHREADS) {
+        for (int c = tid; c < CINp; c += 512) {
             float2 ab = make_float2(0.f, 0.f);
             if (c < p.CIN) {
                 const double q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
@@ -508,129 +608,154 @@ void conv_mfma_pipe_kernel(const ConvParams p) {
             ncoef[c] = ab;
         }
     }
+    __syncthreads();                                   // coefficients / zeroed sums visible
 
-    // ---- fixed per-thread staging slots: item i -> (row r, float4 q) of a chunk window ----
-    int loff[ITEMS];      // LDS float offset inside a buffer, -1: slot outside the window
-    int rr[ITEMS];        // row inside the chunk
-    int q4[ITEMS];        // first column of the slot relative to the window start
-    const float inv_w4 = 1.0f / (float)W4;
-    #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const int idx = i * NTHREADS + tid;
-        const int r = (int)(((float)idx + 0.5f) * inv_w4);
-        const int q = idx - r * W4;
-        loff[i] = (r < p.KC) ? r * XS + 4 * q : -1;
-        rr[i] = r;
-        q4[i] = 4 * q;
-    }
-
-    f32x4 px[ITEMS];
-    f32x4 psc[AFF ? ITEMS : 1];
-    f32x4 psh[AFF ? ITEMS : 1];
-    unsigned okmask = 0;                   // bit i: slot i of the unit in flight holds real data
-    const float* xbase = p.x + (long)sig * p.x_sig + (long)b * p.x_b;
-    const float* scbase = AFF ? p.ss_in + (long)b * p.ss_in_b : nullptr;
-    const float* shbase = AFF ? scbase + (long)p.CIN * p.x_T : nullptr;
-
-    // All loads are UNCONDITIONAL (addresses clamped into the tensor, validity kept in okmask):
-    // straight-line loads let hipcc count them exactly, so the weight-stream waits inside the MFMA
-    // loop become counted vmcnt(N) instead of vmcnt(0) and these loads stay in flight.
-    auto prefetch = [&](int tl, int ch) {
-        const int t_start = (tile0 + tl) * NT - halo_al;
-        const long cbase = (long)ch * p.KC * p.x_T;
-        const int rows_left = p.CIN - ch * p.KC;          // rows >= this are channel padding
-        okmask = 0;
+    if (producer) {
+        // ================================ PRODUCER WAVES ================================
+        const int ptid = tid - 256;
+        int loff[ITEMS];      // LDS float offset inside a buffer, -1: slot outside the window
+        int rr[ITEMS];        // row inside the chunk
+        int q4[ITEMS];        // first column of the slot relative to the window start
+        const float inv_w4 = 1.0f / (float)W4;
         #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const int t = t_start + q4[i];
-            const bool ok = loff[i] >= 0 && (unsigned)t < (unsigned)p.T && rr[i] < rows_left;
-            okmask |= (ok ? 1u : 0u) << i;
-            const int tc = min(max(t, 0), p.T - 4);                    // T % 4 == 0, T >= 4
-            const int rc = min(rr[i], rows_left - 1);
-            if (MODE == MODE_STRETCH) {
-                const unsigned src0 = udiv_small((unsigned)tc, p.s);
-                const int ph = tc - (int)src0 * p.s;
-                const float* src = xbase + cbase + (long)rc * p.x_T + src0;
-                px[i].x = src[0];
-                px[i].y = src[udiv_small(ph + 1, p.s)];
-                px[i].z = src[udiv_small(ph + 2, p.s)];
-                px[i].w = src[udiv_small(ph + 3, p.s)];
-            } else {
-                const long off = cbase + (long)rc * p.x_T + tc;
-                px[i] = *reinterpret_cast<const f32x4*>(xbase + off);
-                if (AFF) {
-                    psc[i] = *reinterpret_cast<const f32x4*>(scbase + off);
-                    psh[i] = *reinterpret_cast<const f32x4*>(shbase + off);
+            const int idx = i * NPROD + ptid;
+            const int r = (int)(((float)idx + 0.5f) * inv_w4);
+            const int q = idx - r * W4;
+            loff[i] = (r < p.KC) ? r * XS + 4 * q : -1;
+            rr[i] = r;
+            q4[i] = 4 * q;
+        }
+        // source rows of this (signal, batch item) through a buffer descriptor: offsets outside the
+        // tensor (columns before the first / after the last row, channel padding) read as 0 in
+        // hardware, everything else is real memory and is masked by `okmask` where it is padding.
+        const __amdgpu_buffer_rsrc_t xr =
+            make_rsrc(p.x + (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.x_T);
+        int ro[ITEMS];        // rr * x_T (+ q4 for DIRECT)
+        #pragma unroll
+        for (int i = 0; i < ITEMS; ++i) ro[i] = rr[i] * p.x_T + (MODE == MODE_STRETCH ? 0 : q4[i]);
+
+        // unconditional loads of unit `un` into a register set; validity in the mask
+        auto pload = [&](int un, f32x4 (&px)[ITEMS], unsigned& okmask) {
+            const int tl = un / p.nchunks;
+            const int ch = un - tl * p.nchunks;
+            const int t_start = (tile0 + tl) * NT - halo_al;
+            const int soff = ch * p.KC * p.x_T * 4;
+            const int rows_left = p.CIN - ch * p.KC;          // rows >= this are channel padding
+            okmask = 0;
+            #pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = t_start + q4[i];
+                const bool ok = loff[i] >= 0 && (unsigned)t < (unsigned)p.T && rr[i] < rows_left;
+                okmask |= (ok ? 1u : 0u) << i;
+                if (MODE == MODE_STRETCH) {
+                    const int tc = max(t, 0);
+                    const unsigned src0 = udiv_small((unsigned)tc, p.s);
+                    const int ph = tc - (int)src0 * p.s;
+                    const int o = (ro[i] + (int)src0) * 4;
+                    px[i].x = buf_load1(xr, o, soff);
+                    px[i].y = buf_load1(xr, o + 4 * (int)udiv_small(ph + 1, p.s), soff);
+                    px[i].z = buf_load1(xr, o + 4 * (int)udiv_small(ph + 2, p.s), soff);
+                    px[i].w = buf_load1(xr, o + 4 * (int)udiv_small(ph + 3, p.s), soff);
+                } else {
+                    px[i] = buf_load4(xr, (ro[i] + t_start) * 4, soff);
                 }
             }
-        }
-        if (p.dbg & DBG_NO_LOAD) okmask = 0;
-    };
-    auto commit = [&](int ch, float* Xs) {
-        if (p.dbg & DBG_NO_COMMIT) return;
-        #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            if (loff[i] < 0) continue;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};          // zero "same" padding / channel padding
-            if (okmask & (1u << i)) {
-                v = px[i];
-                if (AFF) {
-                    v = psc[i] * v + psh[i];
+            if (p.dbg & DBG_NO_LOAD) okmask = 0;
+        };
+        // prologue transform + LDS write of a register set
+        auto pcommit = [&](int un, const f32x4 (&px)[ITEMS], unsigned okmask, float* Xs) {
+            if (p.dbg & DBG_NO_COMMIT) return;
+            const int ch = un % p.nchunks;
+            #pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                if (loff[i] < 0) continue;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};          // zero "same" padding / channel padding
+                if (okmask & (1u << i)) {
+                    v = px[i];
                     if (flags & F_PRE_NORM) {
                         const float2 ab = ncoef[ch * p.KC + rr[i]];
                         v = v * ab.x + ab.y;
                     }
+                    if (flags & F_PRE_LRELU) {
+                        v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
+                    }
                 }
-                if (flags & F_PRE_LRELU) {
-                    v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
-                }
+                *reinterpret_cast<f32x4*>(Xs + loff[i]) = v;
             }
-            *reinterpret_cast<f32x4*>(Xs + loff[i]) = v;
+        };
+
+        f32x4 pa[ITEMS], pb[ITEMS];
+        unsigned oka = 0, okb = 0;
+        pload(0, pa, oka);
+        if (nunits > 1) pload(1, pb, okb);
+        pcommit(0, pa, oka, Xs0);
+        __syncthreads();                               // unit 0 staged
+        for (int u = 0; u < nunits; u += 2) {
+            // consumers multiply unit u (buffer 0): stage unit u+1 into buffer 1, fetch unit u+2
+            if (u + 1 < nunits) {
+                if (u + 2 < nunits) pload(u + 2, pa, oka);
+                pcommit(u + 1, pb, okb, Xs0 + bufsz);
+            }
+            __syncthreads();                           // end of unit u
+            if (u + 1 >= nunits) break;
+            // consumers multiply unit u+1 (buffer 1): stage unit u+2 into buffer 0, fetch unit u+3
+            if (u + 2 < nunits) {
+                if (u + 3 < nunits) pload(u + 3, pb, okb);
+                pcommit(u + 2, pa, oka, Xs0);
+            }
+            __syncthreads();                           // end of unit u+1
         }
-    };
-
-    f32x4 acc[NW][MW];
-    float s1[MW], s2[MW];
-    double d1[MW], d2[MW];
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; d1[m] = 0.0; d2[m] = 0.0; }
-
-    UnitWeightStream<MW> wst;
-    wst.init(p.w + (long)sig * p.w_sig + ((long)(active ? mg : 0) * p.Q * 64 + lane) * MW,
-             (p.dbg & DBG_NO_WEIGHTS) ? UNIT_STEPS : p.Q);
-    const int colbase = (lane >> 4) * XS + (lane & 15) + wave_n * (NW * 16) + (halo_al - halo);
-
-    prefetch(0, 0);
-    __syncthreads();                       // norm coefficients visible
-    commit(0, Xs0);
-    __syncthreads();
-    int u = 0;
-    for (int tl = 0; tl < ntiles; ++tl) {
+        double z1[MW], z2[MW];
         #pragma unroll
-        for (int n = 0; n < NW; ++n)
+        for (int m = 0; m < MW; ++m) { z1[m] = 0.0; z2[m] = 0.0; }
+        stats_flush<MW, WM, 512>(p, z1, z2, sstat, b, 0, false, tid, lane);
+    } else {
+        // ================================ CONSUMER WAVES ================================
+        f32x4 acc[NW][MW];
+        float s1[MW], s2[MW];
+        double d1[MW], d2[MW];
+        #pragma unroll
+        for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; d1[m] = 0.0; d2[m] = 0.0; }
+        UnitWeightStream<MW> wst;
+        wst.init(p.w + (long)sig * p.w_sig + (long)(active ? mg : 0) * p.Q * 64 * MW,
+                 (p.dbg & DBG_NO_WEIGHTS) ? UNIT_STEPS : p.Q, lane);
+        const int colbase = (lane >> 4) * XS + (lane & 15) + wave_n * (NW * 16) + (halo_al - halo);
+        EpiRsrc R;
+        {
+            const long ct = (long)p.COUT * p.T;
+            const float* nul = p.bias;                  // any valid address for unused descriptors
+            R.y = make_rsrc(p.y ? p.y + (long)sig * p.y_sig + (long)b * p.y_b : nul, p.y ? ct : 0);
+            R.y2 = make_rsrc((flags & F_AFF_OUT) ? p.y2 + (long)b * p.y2_b : nul, (flags & F_AFF_OUT) ? ct : 0);
+            R.res = make_rsrc(p.res ? p.res + (long)sig * p.res_sig + (long)b * p.res_b : nul, p.res ? ct : 0);
+            R.ss = make_rsrc((flags & (F_STATS | F_AFF_OUT)) ? p.ss_out + (long)b * p.ss_out_b : nul,
+                             (flags & (F_STATS | F_AFF_OUT)) ? 2 * ct : 0);
+            R.r1x = make_rsrc(p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nul, p.r1x ? p.T : 0);
+        }
+        __syncthreads();                               // unit 0 staged
+        int u = 0;
+        for (int tl = 0; tl < ntiles; ++tl) {
             #pragma unroll
-            for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
-            const bool more = u + 1 < nunits;
-            const int nch = (ch + 1 < p.nchunks) ? ch + 1 : 0;
-            const int ntl = (ch + 1 < p.nchunks) ? tl : tl + 1;
-            if (more) prefetch(ntl, nch);                              // loads in flight ...
-            if (active && !(p.dbg & DBG_NO_MFMA))
-                mfma_unit<MW, NW>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
-            if (more) {
-                commit(nch, Xs0 + ((u + 1) & 1) * bufsz);              // ... land after the MFMAs
-                __syncthreads();
+            for (int n = 0; n < NW; ++n)
+                #pragma unroll
+                for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
+                if (active && !(p.dbg & DBG_NO_MFMA))
+                    mfma_unit<MW, NW>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
+                if (ch + 1 == p.nchunks) {
+                    ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg,
+                                             (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m) {     // fp32 partials stay short, the rest in f64
+                        d1[m] += (double)s1[m]; d2[m] += (double)s2[m];
+                        s1[m] = 0.f; s2[m] = 0.f;
+                    }
+                }
+                __syncthreads();                       // end of unit u
             }
         }
-        conv_epilogue_tile<MW, NW>(p, acc, s1, s2, sig, b, mg, (tile0 + tl) * NT + wave_n * (NW * 16),
-                                   active, lane);
-        #pragma unroll
-        for (int m = 0; m < MW; ++m) {     // fp32 partials stay short (<= 4*NW elements), rest in f64
-            d1[m] += (double)s1[m]; d2[m] += (double)s2[m];
-            s1[m] = 0.f; s2[m] = 0.f;
-        }
+        stats_flush<MW, WM, 512>(p, d1, d2, sstat, b, wave_m, active, tid, lane);
     }
-    stats_flush<MW, WM, NTHREADS>(p, d1, d2, sstat, b, wave_m, active, tid, lane);
 }
 
 template <int MW, int NW>
@@ -656,22 +781,20 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     const int nbuf = (p.nchunks > 1 || tpw > 1) ? 2 : 1;
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM
                       + sizeof(float) * (2 * (size_t)CINp + (size_t)nbuf * p.KC * p.xs);
-    const bool aff = (p.flags & F_PRE_AFFINE) != 0;
+    block = dim3(512);                                  // 4 consumer + 4 producer waves
     if (p.mode == MODE_STRETCH) {
-        hipLaunchKernelGGL((conv_mfma_pipe_kernel<MW, NW, WM, WN, MODE_STRETCH, false>), grid, block, smem, stream, p);
-    } else if (aff) {
-        hipLaunchKernelGGL((conv_mfma_pipe_kernel<MW, NW, WM, WN, MODE_DIRECT, true>), grid, block, smem, stream, p);
+        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_STRETCH>), grid, block, smem, stream, p);
     } else {
-        hipLaunchKernelGGL((conv_mfma_pipe_kernel<MW, NW, WM, WN, MODE_DIRECT, false>), grid, block, smem, stream, p);
+        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DIRECT>), grid, block, smem, stream, p);
     }
     return hipGetLastError();
 }
 
 bool conv_pipe_supported(const ConvParams& p) {
     if (!p.vec || p.KC != 24 || p.ntaps != 3) return false;   // 3 taps x 6 k-steps per unit, compiled in
+    if (p.flags & F_PRE_AFFINE) return false;                  // only the generic kernel fuses the affine
     if (p.mode == MODE_DIRECT) return (p.x_T % 4) == 0;
-    if (p.mode == MODE_STRETCH) return (p.flags & F_PRE_AFFINE) == 0;
-    return false;
+    return p.mode == MODE_STRETCH;
 }
 
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream) {

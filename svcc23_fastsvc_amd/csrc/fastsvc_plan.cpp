@@ -403,9 +403,10 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
         const std::string s = std::to_string(i);
         ws.add("up." + s + ".a", B, u.C, Tin);
         ws.add("up." + s + ".xr", B, u.C, Tout);
-        ws.add("up." + s + ".t0", B, u.C, Tout);
+        ws.add("up." + s + ".u1", B, u.C, Tout);      // scale * t0 + shift      (fastsvc.py:131-132)
         ws.add("up." + s + ".xmid", B, u.C, Tout);
-        ws.add("up." + s + ".t2", B, u.C, Tout);
+        ws.add("up." + s + ".u2", B, u.C, Tout);      // scale * xmid + shift
+        ws.add("up." + s + ".u3", B, u.C, Tout);      // scale * t2 + shift
         ws.add("up." + s + ".out", B, u.C, Tout);
         ws.add("up." + s + ".spk", B, u.C, 1);
         ws.add("up." + s + ".stats", 3 * B, u.C, 2, sizeof(double));
@@ -499,16 +500,17 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         const double flops = 2.0 * c.ntaps * c.cin * c.cout * cols;
         double in_cols = (double)p.T;                       // source columns actually needed
         if (p.mode == MODE_STRETCH) in_cols = (double)p.x_T;
-        double el = (double)c.cin * in_cols + (double)c.cout * p.T;
+        double el = (double)c.cin * in_cols;
+        if (p.y) el += (double)c.cout * p.T;
+        if (p.flags & F_AFF_OUT) el += (double)c.cout * p.T;
         if (p.flags & F_PRE_AFFINE) el += 2.0 * c.cin * p.T;
         if (p.res) el += (double)c.cout * p.T;
         if (p.r1x) el += (double)p.T;
-        if ((p.flags & F_STATS) && !((p.flags & F_PRE_AFFINE) && p.ss_in == p.ss_out)) el += 2.0 * c.cout * p.T;
+        if (p.flags & (F_STATS | F_AFF_OUT)) el += 2.0 * c.cout * p.T;
         const double bytes = 4.0 * (el * p.B * nsig + (double)(c.w_floats + c.b_floats) * nsig);
         char kname[40];
         if (L.pipe)
-            std::snprintf(kname, sizeof(kname), "conv_mfma_pipe<%d,%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN,
-                          p.mode, (p.flags & F_PRE_AFFINE) ? 1 : 0);
+            std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN, p.mode);
         else
             std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d,1,4>", L.MW, L.NW);
         hipError_t e = prof->begin(layer, kname, flops, bytes);
@@ -691,9 +693,10 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         const std::string s = std::to_string(i);
         float* a = buf("up." + s + ".a");
         float* xr = buf("up." + s + ".xr");
-        float* t0 = buf("up." + s + ".t0");
+        float* u1 = buf("up." + s + ".u1");
         float* xm = buf("up." + s + ".xmid");
-        float* t2 = buf("up." + s + ".t2");
+        float* u2 = buf("up." + s + ".u2");
+        float* u3 = buf("up." + s + ".u3");
         float* xo = buf("up." + s + ".out");
         float* pb = buf("up." + s + ".spk");
         double* st = reinterpret_cast<double*>(buf("up." + s + ".stats"));
@@ -703,6 +706,11 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         ConvParams base;
         std::memset(&base, 0, sizeof(base));
         base.B = B; base.s = 1; base.mode = MODE_DIRECT;
+        // Every tensor that feeds a FiLM-affine is stored already affined (u = scale*t + shift,
+        // written by the producing epilogue, which also accumulates its InstanceNorm sums), so the
+        // consuming conv stages ONE tensor and applies (u - mean) * rstd + p, LeakyReLU on the fly.
+        const int aff_out = F_AFF_OUT | (spk ? F_STATS : 0);
+        const int pre = F_PRE_LRELU | (spk ? F_PRE_NORM : 0);
 
         ConvParams p = base;                                       // a = conv_first(x)
         p.x = x; p.x_b = (long)Cx * Tin; p.x_T = (int)Tin;
@@ -715,29 +723,28 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.y = xr; p.y_b = cb; p.T = (int)Tout;
         HIP_TRY(run_conv(u.res, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".res_stretch").c_str()));
 
-        p.flags = F_PRE_LRELU | F_POST_LRELU;                      // t0 = lrelu(conv_up(stretch(lrelu(a))))
-        p.y = t0;
-        if (spk) { p.flags |= F_STATS; p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st; }
+        p.flags = F_PRE_LRELU | F_POST_LRELU | aff_out;            // u1 = aff(lrelu(conv_up(stretch(lrelu(a)))))
+        p.y = nullptr; p.y2 = u1; p.y2_b = cb;
+        p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st;
         HIP_TRY(run_conv(u.up, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".up_stretch").c_str()));
 
-        const int aff = F_PRE_AFFINE | F_PRE_LRELU | (spk ? F_PRE_NORM : 0);
-        p = base;                                                  // xmid = conv_d3(lrelu(aff(t0))) + xr
-        p.x = t0; p.x_b = cb; p.x_T = (int)Tout; p.T = (int)Tout;
-        p.flags = aff; p.ss_in = ss; p.ss_in_b = 2 * cb; p.st_in = st; p.spk = pb;
+        p = base;                                                  // xmid = conv_d3(lrelu(norm(u1))) + xr
+        p.x = u1; p.x_b = cb; p.x_T = (int)Tout; p.T = (int)Tout;
+        p.flags = pre | aff_out; p.st_in = st; p.spk = pb;
         p.res = xr; p.res_b = cb;
-        p.y = xm; p.y_b = cb;
-        if (spk) { p.flags |= F_STATS; p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn; }
+        p.y = xm; p.y_b = cb; p.y2 = u2; p.y2_b = cb;              // and u2 = aff(xmid)
+        p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn;
         HIP_TRY(run_conv(u.d3, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d3").c_str()));
 
-        p.x = xm; p.st_in = st + stn; p.res = nullptr;             // t2 = conv_d9(lrelu(aff(xmid)))
-        p.y = t2;
-        if (spk) p.st_out = st + 2 * stn;
+        p.x = u2; p.st_in = st + stn; p.res = nullptr;             // u3 = aff(conv_d9(lrelu(norm(u2))))
+        p.y = nullptr; p.y2 = u3;
+        p.st_out = st + 2 * stn;
         HIP_TRY(run_conv(u.d9, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d9").c_str()));
 
-        p.x = t2; p.st_in = st + 2 * stn;                          // out = conv_d27(lrelu(aff(t2))) + xmid
-        p.flags = aff; p.ss_out = nullptr; p.st_out = nullptr;
+        p.x = u3; p.st_in = st + 2 * stn;                          // out = conv_d27(lrelu(norm(u3))) + xmid
+        p.flags = pre; p.ss_out = nullptr; p.st_out = nullptr; p.y2 = nullptr;
         p.res = xm; p.res_b = cb;
-        p.y = xo;
+        p.y = xo; p.y_b = cb;
         HIP_TRY(run_conv(u.d27, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d27").c_str()));
 
         x = xo; Cx = u.C; Tin = Tout;

@@ -36,7 +36,7 @@ def check(cfg, B, F, seed_w, seed_x, with_spk=True, verbose=True):
         cmp(f"scale.{k}", ss[:, :C], taps[f"scale.{k}"])
         cmp(f"shift.{k}", ss[:, C:], taps[f"shift.{k}"])
     for i in range(n):
-        for t in ("a", "xr", "t0", "xmid", "t2", "out"):
+        for t in ("a", "xr", "u1", "xmid", "u2", "u3", "out"):
             cmp(f"up.{i}.{t}", plan.tap(f"up.{i}.{t}", B, F, ws), taps[f"up.{i}.{t}"])
         if with_spk:
             cmp(f"up.{i}.spk", plan.tap(f"up.{i}.spk", B, F, ws)[:, :, 0], taps[f"up.{i}.spk"])
