@@ -48,27 +48,56 @@ def parse():
     return ap.parse_args()
 
 
+def _usable_cores() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(budget_s: float):
-    """Oracle `forward_as_executed` (the reference's op sequence incl. its redundant chains) on
-    the host cores: one cfg2-shaped utterance (B=1, F=600 -> 96 000 samples) per iteration."""
+    """Oracle `forward_as_executed` (the reference's op sequence incl. its redundant chains, fp32
+    CPU PyTorch) on the host cores: one cfg1-shaped utterance (B=1, F=300 -> 48 000 samples) per
+    iteration.  PyTorch's intra-op pool does not scale to a whole 2-socket box on convolutions
+    this small (an all-cores run is slower than 16 threads), so a few thread counts are tried
+    within the time budget and the BEST is reported, with the thread count it used."""
     from oracle import fastsvc_oracle as O      # checker / reported baseline only
     cfg = S.FULL_CONFIG
     w = S.fold_weight_norm(S.synth_state_dict(cfg, WEIGHT_SEED))
-    b = S.synth_batch(cfg, 1, 600, 4242)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    t_end = time.time() + budget_s
-    O.forward_as_executed(w, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)   # warm-up
-    times = []
-    while len(times) < 3 or (time.time() < t_end and len(times) < 50):
-        t = time.time()
-        O.forward_as_executed(w, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)
-        times.append(time.time() - t)
-    med = float(np.median(times))
-    return {"value": 96000.0 / med, "unit": "samples/s", "cores": int(torch.get_num_threads()),
-            "kind": "port",
+    b = S.synth_batch(cfg, 1, 300, 4242)
+    usable = _usable_cores()
+    cands = sorted({1, min(8, usable), min(16, usable), min(32, usable), min(64, usable)})
+    per = max(2.0, budget_s / len(cands))
+    best = None
+    tried = {}
+    for nt in cands:
+        torch.set_num_threads(nt)
+        O.forward_as_executed(w, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)   # warm-up
+        times = []
+        t_end = time.time() + per
+        while len(times) < 3 or (time.time() < t_end and len(times) < 40):
+            t = time.time()
+            O.forward_as_executed(w, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)
+            times.append(time.time() - t)
+            if times[-1] > per:          # hopelessly oversubscribed: one sample is enough
+                break
+        med = float(np.median(times))
+        tried[str(nt)] = 48000.0 / med
+        if best is None or 48000.0 / med > best[0]:
+            best = (48000.0 / med, nt, len(times))
+    return {"value": best[0], "unit": "samples/s", "cores": int(best[1]), "kind": "port",
+            "host_cores_usable": usable, "samples_per_s_by_threads": tried,
             "sample": f"oracle forward_as_executed (reference op sequence, fp32 CPU PyTorch), "
-                      f"1 x 4 s utterance (96000 samples), median of {len(times)} runs"}
+                      f"1 x 2 s utterance (48000 samples) per run, median of {best[2]} runs at the "
+                      f"best of {cands} threads"}
 
 
 def roofline(plan, blob, args_dev, n_prof=3):

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Summarise gpurun_out/prof_<tag>/ into profiles/<tag>_* (tracked):
+   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py`
+   <tag>_hbm_traffic.csv    per-kernel-symbol FETCH_SIZE / WRITE_SIZE per launch (separate PMC passes)
+   pmc_traffic.json         kernel symbol (bench.py naming) -> HBM bytes per launch (corrected)
+FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64
+bytes for wide coalesced reads (MI355X_MICROARCH.md, HBM section), so fetch bytes are doubled."""
+import collections, csv, json, os, re, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = agg[r["Kernel_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+    return agg
+
+
+fetch = per_kernel(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
+write = per_kernel(os.path.join(src, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE")
+rows, js = [], {}
+for k in sorted(fetch, key=lambda k: -fetch[k][0]):
+    if "fastsvc" not in k:
+        continue
+    f_kib = fetch[k][0] / fetch[k][1]
+    w_kib = write[k][0] / write[k][1] if k in write else 0.0
+    hbm = (2.0 * f_kib + w_kib) * 1024.0
+    rows.append((k, fetch[k][1], f_kib, w_kib, hbm))
+    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", k)
+    if m:
+        js["conv_mfma_ws<%s,%s,%s,%s,%s>" % m.groups()] = hbm
+    m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
+    if m:
+        js["conv_mfma<%s,%s,%s,%s>" % m.groups()] = hbm
+    for short in ("in1_conv", "pointwise_out", "spk_proj"):
+        if short + "_kernel" in k:
+            js[short] = hbm
+with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as f:
+    f.write("kernel,launches_profiled,FETCH_SIZE_KiB_per_launch_raw,WRITE_SIZE_KiB_per_launch,hbm_bytes_per_launch_corrected\n")
+    for r in rows:
+        f.write('"%s",%d,%.1f,%.1f,%.0f\n' % r)
+json.dump(js, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:3000])
+for r in rows[:8]:
+    print("%-70s n=%3d fetch %9.0f KiB write %9.0f KiB -> %7.1f MB/launch" % (r[0][:70], r[1], r[2], r[3], r[4] / 1e6))
