@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -417,10 +418,12 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
 
 // Optional per-launch instrumentation (fastsvc_forward_profile): hipEvents on the launch stream.
 struct Profiler {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the caller's stream (synchronised in finish)
+    hipStream_t cur = nullptr;             // stream of the launch being bracketed
     std::vector<fastsvc_launch_record> recs;
     std::vector<hipEvent_t> ev;
-    hipError_t begin(const std::string& layer, const std::string& kernel, double flops, double bytes) {
+    hipError_t begin(hipStream_t on, const std::string& layer, const std::string& kernel, double flops, double bytes) {
+        cur = on;
         fastsvc_launch_record r;
         std::memset(&r, 0, sizeof(r));
         std::snprintf(r.layer, sizeof(r.layer), "%s", layer.c_str());
@@ -431,9 +434,9 @@ struct Profiler {
         hipError_t e = hipEventCreate(&e0); if (e != hipSuccess) return e;
         e = hipEventCreate(&e1); if (e != hipSuccess) return e;
         ev.push_back(e0); ev.push_back(e1);
-        return hipEventRecord(e0, stream);
+        return hipEventRecord(e0, cur);
     }
-    hipError_t end() { return hipEventRecord(ev.back(), stream); }
+    hipError_t end() { return hipEventRecord(ev.back(), cur); }
     hipError_t finish() {
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
@@ -448,6 +451,34 @@ struct Profiler {
         return hipSuccess;
     }
 };
+
+// Helper streams for the parts of the forward that are off the critical path (FiLM nets of the
+// stages whose scale/shift are only needed by later up blocks, the 1x1 / stretch residual convs).
+// They are forked from and joined back into the caller's stream with events, so the call stays
+// asynchronous with respect to the host and ordered with respect to the caller's stream.
+struct ExecCtx {
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev[48];
+    int nev = 0;
+};
+
+ExecCtx* exec_ctx_for_current_device() {
+    static std::mutex mu;
+    static std::map<int, ExecCtx*> ctxs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = ctxs.find(dev);
+    if (it != ctxs.end()) return it->second;
+    ExecCtx* c = new ExecCtx();
+    for (int i = 0; i < 2; ++i)
+        if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    for (int i = 0; i < 48; ++i)
+        if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+    c->nev = 48;
+    ctxs[dev] = c;
+    return c;
+}
 
 hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int nsig, long pair_w_stride,
                     long pair_b_stride, hipStream_t stream, Profiler* prof = nullptr,
@@ -513,7 +544,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN, p.mode);
         else
             std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d,1,4>", L.MW, L.NW);
-        hipError_t e = prof->begin(layer, kname, flops, bytes);
+        hipError_t e = prof->begin(stream, layer, kname, flops, bytes);
         if (e != hipSuccess) return e;
         e = launch_conv(p, L, stream);
         if (e != hipSuccess) return e;
@@ -572,6 +603,20 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     const Workspace ws = layout_workspace(P, B, F);
     if (workspace_bytes < ws.bytes) return fail(FASTSVC_E_WORKSPACE, "workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    static const bool serial = std::getenv("FASTSVC_SERIAL") != nullptr;   // debugging: one stream
+    ExecCtx* ctx = serial ? nullptr : exec_ctx_for_current_device();
+    hipStream_t s_film = ctx ? ctx->aux[0] : stream;      // FiLM nets of stages 0..n-2
+    hipStream_t s_side = ctx ? ctx->aux[1] : stream;      // 1x1 / stretch residual convs
+    int evi = 0;
+    // `to` waits for everything enqueued on `from` so far
+    auto order_after = [&](hipStream_t from, hipStream_t to) -> hipError_t {
+        if (from == to || !ctx) return hipSuccess;
+        hipEvent_t e = ctx->ev[evi++ % ctx->nev];
+        hipError_t r = hipEventRecord(e, from);
+        if (r != hipSuccess) return r;
+        return hipStreamWaitEvent(to, e, 0);
+    };
+    std::vector<hipEvent_t> ss_ready(P.n, nullptr);       // FiLM output of stage k is complete
     const float* blob = static_cast<const float*>(dev_blob);
     unsigned char* wsb = static_cast<unsigned char*>(workspace);
     auto buf = [&](const std::string& name) -> float* {
@@ -608,7 +653,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             blocks[i].C = P.up[i].C;
         }
         double spk_c = 0; for (int i = 0; i < n; ++i) spk_c += P.up[i].C;
-        if (prof) HIP_TRY(prof->begin("spk_proj", "spk_proj", 2.0 * spk_c * P.cfg.spk_emb_size * B,
+        if (prof) HIP_TRY(prof->begin(stream, "spk_proj", "spk_proj", 2.0 * spk_c * P.cfg.spk_emb_size * B,
                                       4.0 * (spk_c * P.cfg.spk_emb_size + (double)B * P.cfg.spk_emb_size + spk_c * B)));
         HIP_TRY(launch_spk_proj(spk_emb, blocks, n, B, P.cfg.spk_emb_size, stream));
         if (prof) HIP_TRY(prof->end());
@@ -632,7 +677,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         std::memset(&base, 0, sizeof(base));
         base.B = B; base.T = (int)Tk; base.s = 1; base.mode = MODE_DIRECT;
         if (k == 0) {
-            if (prof) HIP_TRY(prof->begin("down.0.c1", "in1_conv", 2.0 * 3 * d.C * (double)Tk * B * 2,
+            if (prof) HIP_TRY(prof->begin(stream, "down.0.c1", "in1_conv", 2.0 * 3 * d.C * (double)Tk * B * 2,
                                           4.0 * (1.0 + d.C) * (double)Tk * B * 2));
             HIP_TRY(launch_in1_conv(sigbuf, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
                                     (long)(d.c1_raw[1].w_off - d.c1_raw[0].w_off),
@@ -644,7 +689,8 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             p.x = hprev; p.x_sig = (long)B * Cprev * Tprev; p.x_b = (long)Cprev * Tprev; p.x_T = (int)Tprev;
             p.mode = MODE_DECIMATE; p.s = d.scale;
             p.y = r; p.y_sig = tsig; p.y_b = tb;
-            HIP_TRY(run_conv(d.r[0], blob, p, 2, (long)(d.r[1].w_off - d.r[0].w_off), (long)(d.r[1].b_off - d.r[0].b_off), stream, prof, ("down." + s + ".res1x1").c_str()));
+            HIP_TRY(order_after(stream, s_side));                  // h_{k-1} is ready
+            HIP_TRY(run_conv(d.r[0], blob, p, 2, (long)(d.r[1].w_off - d.r[0].w_off), (long)(d.r[1].b_off - d.r[0].b_off), s_side, prof, ("down." + s + ".res1x1").c_str()));
             p.flags = F_PRE_LRELU;                                 // c1 = conv3_d1(lrelu(h_{k-1}[::s]))
             p.y = c1;
             HIP_TRY(run_conv(d.c1[0], blob, p, 2, (long)(d.c1[1].w_off - d.c1[0].w_off), (long)(d.c1[1].b_off - d.c1[0].b_off), stream, prof, ("down." + s + ".c1").c_str()));
@@ -664,20 +710,29 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                     return fail(FASTSVC_E_INVALID, "internal: rank-1 pair strides");
             } else {
                 p.res = buf("down_r." + s); p.res_sig = tsig; p.res_b = tb;
+                HIP_TRY(order_after(s_side, stream));              // r is ready
             }
             HIP_TRY(run_conv(d.c3[0], blob, p, 2, (long)(d.c3[1].w_off - d.c3[0].w_off), (long)(d.c3[1].b_off - d.c3[0].b_off), stream, prof, ("down." + s + ".c3_d4").c_str()));
         }
         {
+            // the FiLM net of the LAST stage feeds the first up block: critical path, caller's stream;
+            // the others are only needed by later up blocks: helper stream
+            hipStream_t sf = (k == n - 1) ? stream : s_film;
+            HIP_TRY(order_after(stream, sf));                      // h_k is ready
             float* u = buf("film_u." + s);                         // (B, 2C, Tk): [lft ; sine] channels
             ConvParams p = base;
             p.x = h; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
             p.flags = F_POST_LRELU;
             p.y = u; p.y_sig = tb; p.y_b = 2 * tb;
-            HIP_TRY(run_conv(d.film[0], blob, p, 2, (long)(d.film[1].w_off - d.film[0].w_off), (long)(d.film[1].b_off - d.film[0].b_off), stream, prof, ("film." + s + ".conv").c_str()));
+            HIP_TRY(run_conv(d.film[0], blob, p, 2, (long)(d.film[1].w_off - d.film[0].w_off), (long)(d.film[1].b_off - d.film[0].b_off), sf, prof, ("film." + s + ".conv").c_str()));
             ConvParams q = base;                                   // [scale ; shift] summed over both signals
             q.x = u; q.x_sig = 0; q.x_b = 2 * tb; q.x_T = (int)Tk;
             q.y = buf("ss." + s); q.y_sig = 0; q.y_b = 2 * tb;
-            HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, stream, prof, ("film." + s + ".heads").c_str()));
+            HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, sf, prof, ("film." + s + ".heads").c_str()));
+            if (sf != stream && ctx) {
+                ss_ready[k] = ctx->ev[evi++ % ctx->nev];
+                HIP_TRY(hipEventRecord(ss_ready[k], sf));
+            }
         }
         hprev = h; Cprev = d.C; Tprev = Tk;
     }
@@ -712,6 +767,8 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         const int aff_out = F_AFF_OUT | (spk ? F_STATS : 0);
         const int pre = F_PRE_LRELU | (spk ? F_PRE_NORM : 0);
 
+        if (ss_ready[k]) HIP_TRY(hipStreamWaitEvent(stream, ss_ready[k], 0));   // scale/shift of stage k
+
         ConvParams p = base;                                       // a = conv_first(x)
         p.x = x; p.x_b = (long)Cx * Tin; p.x_T = (int)Tin;
         p.y = a; p.y_b = (long)u.C * Tin; p.T = (int)Tin;
@@ -721,7 +778,8 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.x = a; p.x_b = (long)u.C * Tin; p.x_T = (int)Tin;
         p.mode = MODE_STRETCH; p.s = u.scale;
         p.y = xr; p.y_b = cb; p.T = (int)Tout;
-        HIP_TRY(run_conv(u.res, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".res_stretch").c_str()));
+        HIP_TRY(order_after(stream, s_side));                      // a is ready
+        HIP_TRY(run_conv(u.res, blob, p, 1, 0, 0, s_side, prof, ("up." + s + ".res_stretch").c_str()));
 
         p.flags = F_PRE_LRELU | F_POST_LRELU | aff_out;            // u1 = aff(lrelu(conv_up(stretch(lrelu(a)))))
         p.y = nullptr; p.y2 = u1; p.y2_b = cb;
@@ -732,6 +790,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.x = u1; p.x_b = cb; p.x_T = (int)Tout; p.T = (int)Tout;
         p.flags = pre | aff_out; p.st_in = st; p.spk = pb;
         p.res = xr; p.res_b = cb;
+        HIP_TRY(order_after(s_side, stream));                      // xr is ready
         p.y = xm; p.y_b = cb; p.y2 = u2; p.y2_b = cb;              // and u2 = aff(xmid)
         p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn;
         HIP_TRY(run_conv(u.d3, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d3").c_str()));
@@ -751,7 +810,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     }
 
     // ---- conv_last ----
-    if (prof) HIP_TRY(prof->begin("conv_last", "pointwise_out", 2.0 * Cx * P.cfg.out_channels * (double)T * B,
+    if (prof) HIP_TRY(prof->begin(stream, "conv_last", "pointwise_out", 2.0 * Cx * P.cfg.out_channels * (double)T * B,
                                   4.0 * (Cx + P.cfg.out_channels) * (double)T * B));
     HIP_TRY(launch_pointwise_out(x, blob + P.last.w_off, blob + P.last.b_off, out, B, Cx,
                                  P.cfg.out_channels, (int)T, stream));
