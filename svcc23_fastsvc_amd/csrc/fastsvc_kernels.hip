@@ -155,7 +155,7 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NW][MW], const float* xa
 // in it) the counted waits never drain them: both streams overlap the matrix work completely.
 // For single-chunk layers (C_in = 24) the "next unit" is the same chunk: the layer's weights
 // simply stay in registers.
-constexpr int UNIT_STEPS = 18;
+constexpr int UNIT_STEPS = 18;      // k = 3: 3 taps x 6 k-steps; the 1x1 variant uses 6
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
@@ -174,11 +174,11 @@ __device__ __forceinline__ typename WFrag<MW>::type load_wfrag_buf(__amdgpu_buff
     }
 }
 
-template <int MW>
+template <int MW, int NSTEPS = UNIT_STEPS>
 struct UnitWeightStream {
     static constexpr int STEP_BYTES = 64 * MW * 4;
-    static constexpr int UNIT_BYTES = UNIT_STEPS * STEP_BYTES;
-    typename WFrag<MW>::type wr[UNIT_STEPS];
+    static constexpr int UNIT_BYTES = NSTEPS * STEP_BYTES;
+    typename WFrag<MW>::type wr[NSTEPS];
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;              // lane * MW * 4
     int next;              // byte offset of the unit after the one held in wr
@@ -189,23 +189,23 @@ struct UnitWeightStream {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(group_base), 0, total, 0x00020000);
         voff = lane * MW * 4;
         #pragma unroll
-        for (int s = 0; s < UNIT_STEPS; ++s) wr[s] = load_wfrag_buf<MW>(rsrc, voff, s * STEP_BYTES);
+        for (int s = 0; s < NSTEPS; ++s) wr[s] = load_wfrag_buf<MW>(rsrc, voff, s * STEP_BYTES);
         next = UNIT_BYTES;
         if (next >= total) next = 0;
     }
 };
 
-template <int MW, int NW>
+template <int MW, int NW, int NSTEPS>
 __device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0, int XS,
-                                          UnitWeightStream<MW>& ws, int dil) {
+                                          UnitWeightStream<MW, NSTEPS>& ws, int dil) {
     // The LDS reads of step s+1 are issued BEFORE the MFMAs of step s (register double-buffer by
     // full unrolling), so their latency hides under the matrix work even with one wave per SIMD.
     float av[2][NW];
     #pragma unroll
     for (int n = 0; n < NW; ++n) av[0][n] = xa0[n * 16];
     #pragma unroll
-    for (int s = 0; s < UNIT_STEPS; ++s) {
-        if (s + 1 < UNIT_STEPS) {
+    for (int s = 0; s < NSTEPS; ++s) {
+        if (s + 1 < NSTEPS) {
             const int tap = (s + 1) / 6, j = (s + 1) % 6;
             #pragma unroll
             for (int n = 0; n < NW; ++n) av[(s + 1) & 1][n] = xa0[tap * dil + j * 4 * XS + n * 16];
@@ -215,12 +215,12 @@ __device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0
             #pragma unroll
             for (int m = 0; m < MW; ++m)
                 acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][n], wfrag_get<MW>(ws.wr[s], m), acc[n][m], 0, 0, 0);
-        ws.wr[s] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + s * UnitWeightStream<MW>::STEP_BYTES);
+        ws.wr[s] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + s * UnitWeightStream<MW, NSTEPS>::STEP_BYTES);
         // pin the re-request right behind its step (hipcc otherwise sinks the loads to the end
         // of the unit and waits for all of them at the top of the next one)
         __builtin_amdgcn_sched_barrier(0);
     }
-    ws.next += UnitWeightStream<MW>::UNIT_BYTES;
+    ws.next += UnitWeightStream<MW, NSTEPS>::UNIT_BYTES;
     if (ws.next >= ws.total) ws.next = 0;
 }
 
@@ -470,6 +470,7 @@ struct StageGeom {
     static constexpr int ITEMS = (24 * MAXW4 + NTHREADS - 1) / NTHREADS;
 };
 
+
 __device__ __forceinline__ unsigned udiv_small(unsigned t, int s) {
     switch (s) {
         case 1: return t;
@@ -551,9 +552,10 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
     }
 }
 
-template <int MW, int NW, int WM, int WN, int MODE>
-__global__ __launch_bounds__(512, (MW * NW <= 8) ? 4 : 2)     // <= 128 VGPRs where two workgroups per CU fit
+template <int MW, int NW, int WM, int WN, int MODE, int NTAPS>
+__global__ __launch_bounds__(512, (MW <= 2 || NW == 1) ? 4 : 2)  // <= 128 VGPRs where two workgroups per CU fit without spills
 void conv_mfma_ws_kernel(const ConvParams p) {
+    constexpr int NSTEPS = 6 * NTAPS;
     constexpr int NT = 16 * NW * WN;
     constexpr int NPROD = 256;                                         // producer threads
     constexpr int ITEMS = StageGeom<NT, NPROD>::ITEMS;
@@ -571,7 +573,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
     const int b = z - sig * p.B;
     const int mg = blockIdx.y * WM + wave_m;
     const bool active = !producer && mg < p.ngroups;
-    const int halo = p.dil;                                            // k = 3 only
+    const int halo = (NTAPS == 3) ? p.dil : 0;
     const int halo_al = (halo + 3) & ~3;
     const int W4 = (NT + 2 * halo_al) >> 2;
     const int XS = p.xs;
@@ -614,8 +616,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         // ================================ PRODUCER WAVES ================================
         const int ptid = tid - 256;
         int loff[ITEMS];      // LDS float offset inside a buffer, -1: slot outside the window
-        int rr[ITEMS];        // row inside the chunk
-        int q4[ITEMS];        // first column of the slot relative to the window start
+        int rq[ITEMS];        // (row inside the chunk) << 16 | first column relative to the window start
         const float inv_w4 = 1.0f / (float)W4;
         #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -623,17 +624,13 @@ void conv_mfma_ws_kernel(const ConvParams p) {
             const int r = (int)(((float)idx + 0.5f) * inv_w4);
             const int q = idx - r * W4;
             loff[i] = (r < p.KC) ? r * XS + 4 * q : -1;
-            rr[i] = r;
-            q4[i] = 4 * q;
+            rq[i] = (r << 16) | (4 * q);
         }
         // source rows of this (signal, batch item) through a buffer descriptor: offsets outside the
         // tensor (columns before the first / after the last row, channel padding) read as 0 in
         // hardware, everything else is real memory and is masked by `okmask` where it is padding.
         const __amdgpu_buffer_rsrc_t xr =
             make_rsrc(p.x + (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.x_T);
-        int ro[ITEMS];        // rr * x_T (+ q4 for DIRECT)
-        #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) ro[i] = rr[i] * p.x_T + (MODE == MODE_STRETCH ? 0 : q4[i]);
 
         // unconditional loads of unit `un` into a register set; validity in the mask
         auto pload = [&](int un, f32x4 (&px)[ITEMS], unsigned& okmask) {
@@ -645,20 +642,28 @@ void conv_mfma_ws_kernel(const ConvParams p) {
             okmask = 0;
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
-                const int t = t_start + q4[i];
-                const bool ok = loff[i] >= 0 && (unsigned)t < (unsigned)p.T && rr[i] < rows_left;
+                const int r = rq[i] >> 16;
+                const int t = t_start + (rq[i] & 0xffff);
+                const int ro = r * p.x_T;
+                const bool ok = loff[i] >= 0 && (unsigned)t < (unsigned)p.T && r < rows_left;
                 okmask |= (ok ? 1u : 0u) << i;
                 if (MODE == MODE_STRETCH) {
                     const int tc = max(t, 0);
                     const unsigned src0 = udiv_small((unsigned)tc, p.s);
                     const int ph = tc - (int)src0 * p.s;
-                    const int o = (ro[i] + (int)src0) * 4;
+                    const int o = (ro + (int)src0) * 4;
                     px[i].x = buf_load1(xr, o, soff);
                     px[i].y = buf_load1(xr, o + 4 * (int)udiv_small(ph + 1, p.s), soff);
                     px[i].z = buf_load1(xr, o + 4 * (int)udiv_small(ph + 2, p.s), soff);
                     px[i].w = buf_load1(xr, o + 4 * (int)udiv_small(ph + 3, p.s), soff);
+                } else if (MODE == MODE_DECIMATE) {
+                    const int o = (ro + t * p.s) * 4;           // x[..., ::s]; negative t -> out of range -> 0
+                    px[i].x = buf_load1(xr, o, soff);
+                    px[i].y = buf_load1(xr, o + 4 * p.s, soff);
+                    px[i].z = buf_load1(xr, o + 8 * p.s, soff);
+                    px[i].w = buf_load1(xr, o + 12 * p.s, soff);
                 } else {
-                    px[i] = buf_load4(xr, (ro[i] + t_start) * 4, soff);
+                    px[i] = buf_load4(xr, (ro + t) * 4, soff);
                 }
             }
             if (p.dbg & DBG_NO_LOAD) okmask = 0;
@@ -674,7 +679,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
                 if (okmask & (1u << i)) {
                     v = px[i];
                     if (flags & F_PRE_NORM) {
-                        const float2 ab = ncoef[ch * p.KC + rr[i]];
+                        const float2 ab = ncoef[ch * p.KC + (rq[i] >> 16)];
                         v = v * ab.x + ab.y;
                     }
                     if (flags & F_PRE_LRELU) {
@@ -706,20 +711,13 @@ void conv_mfma_ws_kernel(const ConvParams p) {
             }
             __syncthreads();                           // end of unit u+1
         }
-        double z1[MW], z2[MW];
-        #pragma unroll
-        for (int m = 0; m < MW; ++m) { z1[m] = 0.0; z2[m] = 0.0; }
-        stats_flush<MW, WM, 512>(p, z1, z2, sstat, b, 0, false, tid, lane);
     } else {
         // ================================ CONSUMER WAVES ================================
         f32x4 acc[NW][MW];
         float s1[MW], s2[MW];
-        double d1[MW], d2[MW];
-        #pragma unroll
-        for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; d1[m] = 0.0; d2[m] = 0.0; }
-        UnitWeightStream<MW> wst;
+        UnitWeightStream<MW, NSTEPS> wst;
         wst.init(p.w + (long)sig * p.w_sig + (long)(active ? mg : 0) * p.Q * 64 * MW,
-                 (p.dbg & DBG_NO_WEIGHTS) ? UNIT_STEPS : p.Q, lane);
+                 (p.dbg & DBG_NO_WEIGHTS) ? NSTEPS : p.Q, lane);
         const int colbase = (lane >> 4) * XS + (lane & 15) + wave_n * (NW * 16) + (halo_al - halo);
         EpiRsrc R;
         {
@@ -741,20 +739,38 @@ void conv_mfma_ws_kernel(const ConvParams p) {
                 for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
                 if (active && !(p.dbg & DBG_NO_MFMA))
-                    mfma_unit<MW, NW>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
+                    mfma_unit<MW, NW, NSTEPS>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
                 if (ch + 1 == p.nchunks) {
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
                     ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg,
                                              (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
-                    #pragma unroll
-                    for (int m = 0; m < MW; ++m) {     // fp32 partials stay short, the rest in f64
-                        d1[m] += (double)s1[m]; d2[m] += (double)s2[m];
-                        s1[m] = 0.f; s2[m] = 0.f;
+                    if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
+                        // fp32 partials stay short (this tile only); the running sums are f64 in LDS
+                        #pragma unroll
+                        for (int m = 0; m < MW; ++m) {
+                            float a1 = s1[m], a2 = s2[m];
+                            a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+                            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                            if (active && lane < 16) {
+                                const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
+                                atomicAdd(&sstat[slot + 0], (double)a1);
+                                atomicAdd(&sstat[slot + 1], (double)a2);
+                            }
+                        }
                     }
                 }
                 __syncthreads();                       // end of unit u
             }
         }
-        stats_flush<MW, WM, 512>(p, d1, d2, sstat, b, wave_m, active, tid, lane);
+    }
+    // one f64 global atomic per channel per workgroup
+    if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
+        __syncthreads();
+        for (int i = tid; i < 2 * 16 * MW * WM; i += 512) {
+            const int co = blockIdx.y * (WM * MW * 16) + (i >> 1);
+            if (co < p.COUT) atomicAdd(&p.st_out[((long)b * p.COUT + co) * 2 + (i & 1)], sstat[i]);
+        }
     }
 }
 
@@ -782,19 +798,25 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM
                       + sizeof(float) * (2 * (size_t)CINp + (size_t)nbuf * p.KC * p.xs);
     block = dim3(512);                                  // 4 consumer + 4 producer waves
-    if (p.mode == MODE_STRETCH) {
-        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_STRETCH>), grid, block, smem, stream, p);
+    if (p.ntaps == 1) {
+        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DECIMATE, 1>), grid, block, smem, stream, p);
+    } else if (p.mode == MODE_STRETCH) {
+        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_STRETCH, 3>), grid, block, smem, stream, p);
+    } else if (p.mode == MODE_DECIMATE) {
+        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DECIMATE, 3>), grid, block, smem, stream, p);
     } else {
-        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DIRECT>), grid, block, smem, stream, p);
+        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DIRECT, 3>), grid, block, smem, stream, p);
     }
     return hipGetLastError();
 }
 
 bool conv_pipe_supported(const ConvParams& p) {
-    if (!p.vec || p.KC != 24 || p.ntaps != 3) return false;   // 3 taps x 6 k-steps per unit, compiled in
+    if (!p.vec || p.KC != 24) return false;                    // 6 k-steps per tap per chunk, compiled in
     if (p.flags & F_PRE_AFFINE) return false;                  // only the generic kernel fuses the affine
+    if (p.ntaps == 1) return p.mode == MODE_DECIMATE;          // the 1x1 residual convs of the down nets
+    if (p.ntaps != 3) return false;
     if (p.mode == MODE_DIRECT) return (p.x_T % 4) == 0;
-    return p.mode == MODE_STRETCH;
+    return p.mode == MODE_STRETCH || p.mode == MODE_DECIMATE;
 }
 
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream) {

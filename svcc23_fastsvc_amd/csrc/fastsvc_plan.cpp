@@ -471,8 +471,12 @@ ExecCtx* exec_ctx_for_current_device() {
     auto it = ctxs.find(dev);
     if (it != ctxs.end()) return it->second;
     ExecCtx* c = new ExecCtx();
-    for (int i = 0; i < 2; ++i)
-        if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    // the FiLM helper stream runs at the LOWEST priority: its kernels only fill the CUs the
+    // critical-path kernels leave idle; the residual-conv stream keeps the default priority
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = numerically largest
+    if (hipStreamCreateWithPriority(&c->aux[0], hipStreamNonBlocking, prio_lo) != hipSuccess) { delete c; return nullptr; }
+    if (hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
     for (int i = 0; i < 48; ++i)
         if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
     c->nev = 48;
@@ -541,7 +545,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         const double bytes = 4.0 * (el * p.B * nsig + (double)(c.w_floats + c.b_floats) * nsig);
         char kname[40];
         if (L.pipe)
-            std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN, p.mode);
+            std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN, p.mode, c.ntaps);
         else
             std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d,1,4>", L.MW, L.NW);
         hipError_t e = prof->begin(stream, layer, kname, flops, bytes);

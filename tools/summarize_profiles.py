@@ -35,9 +35,9 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     w_kib = write[k][0] / write[k][1] if k in write else 0.0
     hbm = (2.0 * f_kib + w_kib) * 1024.0
     rows.append((k, fetch[k][1], f_kib, w_kib, hbm))
-    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", k)
+    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", k)
     if m:
-        js["conv_mfma_ws<%s,%s,%s,%s,%s>" % m.groups()] = hbm
+        js["conv_mfma_ws<%s,%s,%s,%s,%s,%s>" % m.groups()] = hbm
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
     if m:
         js["conv_mfma<%s,%s,%s,%s>" % m.groups()] = hbm
