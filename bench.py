@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--autotune", action="store_true",
+                    help="run the untimed device-side autotune pass (cf. cudnn.benchmark) instead of "
+                         "the static launch cost model")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -196,6 +199,10 @@ def main():
                     h.wait()
         torch.cuda.synchronize()
 
+    # one-off, untimed: pick the launch shape of every layer for this (B, F) on this device
+    # (the reference's recipes run with torch.backends.cudnn.benchmark = True, train_fastsvc.py:617)
+    if args.autotune:
+        plan.forward(blob, *args_dev, out=outs[0], workspace=ws, autotune=True)
     for i in range(args.warmup):
         step(i)
     drain()
@@ -235,6 +242,8 @@ def main():
             "rtf_24k": 24000.0 / value,
             "alg_gflop_per_step": plan.flops_per_sample * B * T / 1e9,
             "e2e_alg_tflops_per_gpu": plan.flops_per_sample * B * T / (elapsed / args.steps) / 1e12,
+            "launch_shapes": "static cost model" if not args.autotune else
+                             f"autotuned on device ({getattr(plan, 'last_autotune_trials', 0)} timed trials, untimed)",
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -109,6 +109,18 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
 int fastsvc_workspace_tap(const fastsvc_plan* plan, int32_t B, int32_t F, const char* tap_name,
                           size_t* byte_offset, int64_t* numel, int64_t shape3[3]);
 
+/* Optional device-side autotuning for one problem size (the analogue of the reference's
+ * `torch.backends.cudnn.benchmark = True`, train_fastsvc.py:617): runs one forward in which every
+ * convolution times its candidate launch shapes (time tile x channel split x tiles per workgroup)
+ * on `stream`, keeps the fastest per layer in the plan (thread-safe cache keyed by layer, B, T) and
+ * synchronises the stream.  `out` holds a valid forward result afterwards.  Without this call the
+ * launch shapes come from a static cost model.  n_trials (nullable) returns the number of timed
+ * trial configurations. */
+int fastsvc_autotune(const fastsvc_plan* plan, const void* dev_blob,
+                     const float* ppg, const float* sine, const float* lft, const float* spk_emb,
+                     float* out, int32_t B, int32_t F,
+                     void* workspace, size_t workspace_bytes, void* stream, int32_t* n_trials);
+
 /* Per-launch timing of one forward (bench.py roofline accounting).  Same arguments as
  * fastsvc_forward; brackets every kernel launch with hipEvents on `stream`, synchronises the
  * stream at the end and fills one record per launch: the layer it computes, the kernel symbol

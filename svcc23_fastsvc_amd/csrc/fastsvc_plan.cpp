@@ -94,6 +94,10 @@ struct fastsvc_plan {
     std::vector<std::pair<PackedConv*, PackSource>> pack_jobs;
     std::vector<RawParam*> raw_jobs;
     double flops_per_sample = 0.0;
+    // autotuned launch choices (fastsvc_autotune), keyed by "layer|B|T"; guarded by tune_mu
+    struct Choice { int NW, WM, WN, tpw; };
+    mutable std::mutex tune_mu;
+    mutable std::map<std::string, Choice> tuned;
 
     size_t alloc(size_t nfloats) {
         size_t off = blob_floats;
@@ -484,6 +488,15 @@ ExecCtx* exec_ctx_for_current_device() {
     return c;
 }
 
+// Autotuning state of one forward call (fastsvc_autotune): when `tuning` every pipelined conv
+// times all its candidate launch shapes on the device before the real launch.
+struct TuneCtx {
+    const fastsvc_plan* plan = nullptr;
+    bool tuning = false;
+    int trials = 0;
+};
+thread_local TuneCtx g_tune;
+
 hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int nsig, long pair_w_stride,
                     long pair_b_stride, hipStream_t stream, Profiler* prof = nullptr,
                     const char* layer = "") {
@@ -502,24 +515,98 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
     ConvLaunch L{c.MW, 4, 1, 4, nsig, 0};
     p.tpw = 1;
     if (conv_pipe_supported(p)) {
-        // candidates in order of preference (big tiles, waves split over output channels on wide
-        // layers); take the first that keeps (nearly) all 256 CUs busy, else the most parallel
+        // Tile shape and tiles-per-workgroup from a small cost model: a workgroup costs a fixed
+        // start-up (launch, slot set-up, first window in flight) plus tpw * nchunks units, a unit
+        // being bounded by the consumer wave's MFMA stream or by the producers' window traffic;
+        // the grid runs in ceil(workgroups / resident slots) rounds.
         struct Cand { int NW, WM, WN; };
         std::vector<Cand> cands;
-        if (c.MW == 3 && c.ngroups % 4 == 0) cands = {{4, 4, 1}, {4, 2, 2}, {2, 4, 1}, {2, 2, 2}, {1, 2, 2}, {1, 1, 4}};
-        else if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{4, 2, 2}, {2, 2, 2}, {4, 1, 4}, {1, 2, 2}, {2, 1, 4}, {1, 1, 4}};
+        if (c.MW == 3 && c.ngroups % 4 == 0) cands = {{4, 4, 1}, {2, 4, 1}, {4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
+        else if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         else cands = {{4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
-        long best = -1;
+        auto xs_for = [&](int NW, int WN) {
+            const int W = 16 * NW * WN + 2 * ((halo + 3) & ~3);
+            return (W + 15) / 32 * 32 + 16;
+        };
+        char key[96];
+        std::snprintf(key, sizeof(key), "%s|%d|%d", layer, p.B, p.T);
+        bool have = false;
+        if (g_tune.plan) {
+            std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
+            auto it = g_tune.plan->tuned.find(key);
+            if (it != g_tune.plan->tuned.end()) {
+                L.NW = it->second.NW; L.WM = it->second.WM; L.WN = it->second.WN; p.tpw = it->second.tpw;
+                have = true;
+            }
+        }
+        if (!have && g_tune.tuning && g_tune.plan) {
+            // time every (shape, tiles-per-workgroup) on the device; InstanceNorm sums are not
+            // accumulated by the trial launches (the real launch below does that once)
+            static const int tpws[] = {1, 2, 3, 4, 6, 8, 12, 16};
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return hipErrorUnknown;
+            float best_ms = 1e30f;
+            ConvParams q = p;
+            q.flags &= ~F_STATS;
+            for (const Cand& cd : cands) {
+                const int NT = 16 * cd.NW * cd.WN;
+                const long ntx = (p.T + NT - 1) / NT;
+                for (int tpw : tpws) {
+                    q.tpw = tpw; q.xs = xs_for(cd.NW, cd.WN);
+                    ConvLaunch Lq{c.MW, cd.NW, cd.WM, cd.WN, nsig, 1};
+                    hipError_t e = launch_conv(q, Lq, stream);            // warm
+                    if (e != hipSuccess) return e;
+                    hipEventRecord(e0, stream);
+                    for (int r = 0; r < 3; ++r) { e = launch_conv(q, Lq, stream); if (e != hipSuccess) return e; }
+                    hipEventRecord(e1, stream);
+                    if (hipEventSynchronize(e1) != hipSuccess) return hipErrorUnknown;
+                    float ms = 0.f;
+                    hipEventElapsedTime(&ms, e0, e1);
+                    ++g_tune.trials;
+                    if (ms < best_ms) { best_ms = ms; L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; p.tpw = tpw; }
+                    if (tpw >= ntx) break;                                // larger tpw changes nothing
+                }
+            }
+            hipEventDestroy(e0); hipEventDestroy(e1);
+            std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
+            g_tune.plan->tuned[key] = fastsvc_plan::Choice{L.NW, L.WM, L.WN, p.tpw};
+            have = true;
+        }
+        if (!have) {
+        // Tile shape and tiles-per-workgroup from a small cost model: a workgroup costs a fixed
+        // start-up (launch, slot set-up, first window in flight) plus tpw * nchunks units, a unit
+        // being bounded by the consumer wave's MFMA stream or by the producers' window traffic;
+        // the grid runs in ceil(workgroups / resident slots) rounds.
+        const double startup_us = 4.0;
+        double best_t = 1e30;
         for (const Cand& cd : cands) {
             const int NT = 16 * cd.NW * cd.WN;
-            const long wgs = (long)((p.T + NT - 1) / NT) * ((c.ngroups + cd.WM - 1) / cd.WM) * zb;
-            if (wgs >= 224) { L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; best = wgs; break; }
-            if (wgs > best) { L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; best = wgs; }
+            const long ntx = (p.T + NT - 1) / NT;
+            const long gy = (c.ngroups + cd.WM - 1) / cd.WM;
+            const int resident = (c.MW <= 2 || cd.NW == 1) ? 2 : 1;          // VGPR budget, see the kernel
+            const long slots = 256L * resident;
+            // unit time: MFMA stream of one consumer wave vs bytes the 256 producer threads move
+            const double mfma_us = 6.0 * c.ntaps * cd.NW * c.MW * 32.0 / 2.2e3;
+            const double win = NT + 2.0 * ((halo + 3) & ~3);
+            const double bytes_unit = c.KC * win * 4.0 + (double)16 * c.MW * cd.WM * NT * 4.0 *
+                                      ((p.y ? 1 : 0) + ((p.flags & F_AFF_OUT) ? 3 : 0) + (p.res ? 1 : 0)) / c.nchunks;
+            const double mem_us = bytes_unit / (5.0e6 / 256.0 / resident);    // ~5 TB/s shared by all slots
+            // packed weights streamed from L2 by the four consumer waves (per unit, per workgroup):
+            // ~16 TB/s of L2 shared by all resident workgroups; this is what punishes small NW
+            const double wbytes_unit = 4.0 * 6.0 * c.ntaps * 64.0 * c.MW * 4.0;
+            const double l2_us = wbytes_unit / (16.0e6 / 256.0 / resident);
+            double unit_us = mfma_us > mem_us ? mfma_us : mem_us;
+            if (l2_us > unit_us) unit_us = l2_us;
+            unit_us /= (resident == 2 ? 1.6 : 1.0);
+            for (int tpw = 1; tpw <= 16; ++tpw) {
+                const long wgs = ((ntx + tpw - 1) / tpw) * gy * zb;
+                const long rounds = (wgs + slots - 1) / slots;
+                const double t = rounds * (startup_us + tpw * c.nchunks * unit_us);
+                if (t < best_t * 0.999) { best_t = t; L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; p.tpw = tpw; }
+            }
+        }
         }
         L.pipe = 1;
-        // tiles per workgroup: amortise the per-workgroup set-up while keeping >= ~3 workgroups per CU
-        p.tpw = 1;
-        while (p.tpw < 8 && best / (2 * p.tpw) >= 768) p.tpw *= 2;
         const int NT = 16 * L.NW * L.WN;
         const int W = NT + 2 * ((halo + 3) & ~3);
         p.xs = (W + 15) / 32 * 32 + 16;
@@ -608,7 +695,8 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     if (workspace_bytes < ws.bytes) return fail(FASTSVC_E_WORKSPACE, "workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static const bool serial = std::getenv("FASTSVC_SERIAL") != nullptr;   // debugging: one stream
-    ExecCtx* ctx = serial ? nullptr : exec_ctx_for_current_device();
+    g_tune.plan = plan;
+    ExecCtx* ctx = (serial || g_tune.tuning) ? nullptr : exec_ctx_for_current_device();
     hipStream_t s_film = ctx ? ctx->aux[0] : stream;      // FiLM nets of stages 0..n-2
     hipStream_t s_side = ctx ? ctx->aux[1] : stream;      // 1x1 / stretch residual convs
     int evi = 0;
@@ -828,6 +916,21 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
                     void* workspace, size_t workspace_bytes, void* stream) {
     return forward_impl(plan, dev_blob, ppg, sine, lft, spk_emb, out, B, F, lengths, workspace,
                         workspace_bytes, stream, nullptr);
+}
+
+int fastsvc_autotune(const fastsvc_plan* plan, const void* dev_blob,
+                     const float* ppg, const float* sine, const float* lft, const float* spk_emb,
+                     float* out, int32_t B, int32_t F,
+                     void* workspace, size_t workspace_bytes, void* stream, int32_t* n_trials) {
+    g_tune.tuning = true;
+    g_tune.trials = 0;
+    const int rc = forward_impl(plan, dev_blob, ppg, sine, lft, spk_emb, out, B, F, nullptr, workspace,
+                                workspace_bytes, stream, nullptr);
+    g_tune.tuning = false;
+    if (n_trials) *n_trials = g_tune.trials;
+    if (rc != FASTSVC_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return FASTSVC_OK;
 }
 
 int fastsvc_forward_profile(const fastsvc_plan* plan, const void* dev_blob,

@@ -23,7 +23,7 @@ MAX_STAGES = 8
 ABI_SYMBOLS = (
     "fastsvc_abi_version", "fastsvc_last_error", "fastsvc_plan_create", "fastsvc_plan_destroy",
     "fastsvc_weight_blob_bytes", "fastsvc_pack_weights", "fastsvc_workspace_bytes",
-    "fastsvc_forward", "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
+    "fastsvc_forward", "fastsvc_autotune", "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
     "fastsvc_flops_per_sample",
 )
 
@@ -82,6 +82,8 @@ def load_library():
     lib.fastsvc_workspace_bytes.restype = sz
     lib.fastsvc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.fastsvc_forward.restype = ctypes.c_int
+    lib.fastsvc_autotune.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, ctypes.POINTER(i32)]
+    lib.fastsvc_autotune.restype = ctypes.c_int
     lib.fastsvc_forward_profile.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp,
                                             ctypes.POINTER(_LaunchRecord), i32, ctypes.POINTER(i32)]
     lib.fastsvc_forward_profile.restype = ctypes.c_int
@@ -187,11 +189,14 @@ class Plan:
 
     def forward(self, blob: torch.Tensor, ppg: torch.Tensor, sine: torch.Tensor, lft: torch.Tensor,
                 spk_emb: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
-                workspace: Optional[torch.Tensor] = None, profile: Optional[list] = None) -> torch.Tensor:
+                workspace: Optional[torch.Tensor] = None, profile: Optional[list] = None,
+                autotune: bool = False) -> torch.Tensor:
         """Enqueue one forward on the current HIP stream of ``ppg.device``; returns (B, O, T).
 
         With ``profile`` (a list) the launches are bracketed by hipEvents on that stream, the
-        stream is synchronised and one dict per kernel launch is appended to the list."""
+        stream is synchronised and one dict per kernel launch is appended to the list.
+        With ``autotune`` every convolution first times its candidate launch shapes for this
+        (B, F) and the plan remembers the fastest (cf. ``cudnn.benchmark``); synchronises."""
         cfg = self.cfg
         if not ppg.is_cuda:
             raise FastSVCError("FastSVC HIP path needs GPU tensors (no CPU fallback); got " + str(ppg.device))
@@ -225,7 +230,11 @@ class Plan:
                 ctypes.c_void_p(spk_emb.data_ptr()) if spk_emb is not None else None,
                 ctypes.c_void_p(out.data_ptr()), B, F, None,
                 ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), ctypes.c_void_p(stream))
-            if profile is None:
+            if autotune:
+                ntr = ctypes.c_int32(0)
+                rc = self.lib.fastsvc_autotune(*common[:9], common[10], common[11], common[12], ctypes.byref(ntr))
+                self.last_autotune_trials = int(ntr.value)
+            elif profile is None:
                 rc = self.lib.fastsvc_forward(*common)
             else:
                 recs = (_LaunchRecord * 256)()

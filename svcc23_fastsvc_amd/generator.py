@@ -99,6 +99,10 @@ class FastSVCGenerator(nn.Module):
 
     # sub-batch so that one launch sequence never needs more scratch than this (bytes)
     max_workspace_bytes = 48 << 30
+    # True: the first forward of every new (batch, frames) shape times the candidate launch shapes
+    # of each layer on the device and keeps the fastest (the role cudnn.benchmark plays for the
+    # reference, train_fastsvc.py:617).  False: static cost model.
+    autotune = False
 
     def __init__(self, in_channels: int = 144, mid_channels: Sequence[int] = (192, 96, 48, 24),
                  upsampling_scales: Sequence[int] = (2, 4, 4, 5), out_channels: int = 1,
@@ -132,6 +136,7 @@ class FastSVCGenerator(nn.Module):
         self.conv_last = _conv1x1(cfg.mid_channels[-1], out_channels)
         self.apply_weight_norm()
 
+        self._tuned_shapes = set()
         self._plan: Optional[Plan] = None
         self._blob: Optional[torch.Tensor] = None
         self._blob_key = None
@@ -208,7 +213,10 @@ class FastSVCGenerator(nn.Module):
         while step > 1 and plan.workspace_bytes(step, F) > self.max_workspace_bytes:
             step = (step + 1) // 2
         if step == B:
-            y = plan.forward(blob, x, s, l, spk_emb)
+            tune = bool(self.autotune) and (B, F, str(x.device)) not in self._tuned_shapes
+            y = plan.forward(blob, x, s, l, spk_emb, autotune=tune)
+            if tune:
+                self._tuned_shapes.add((B, F, str(x.device)))
         else:
             y = torch.empty((B, self.out_channels, F * hop), dtype=torch.float32, device=x.device)
             ws = torch.empty(plan.workspace_bytes(step, F), dtype=torch.uint8, device=x.device)

@@ -218,3 +218,23 @@ def test_profile_records_cover_every_launch(dev):
     assert abs(total / (2 * 20 * 160) / plan.flops_per_sample - 1) < 0.02
     y2 = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb))
     assert float((y - y2).abs().max()) <= 1e-5
+
+
+def test_autotuned_launch_shapes_keep_parity(dev):
+    """fastsvc_autotune picks different tile shapes / tiles-per-workgroup per layer; the result must
+    not depend on them (same oracle tolerance, and equal to the cost-model run to fp32 noise)."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 17)
+    b = S.synth_batch(cfg, 2, 150, 18)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    plan = A.Plan(cfg)
+    blob = plan.pack(sd).to(dev)
+    y0 = plan.forward(blob, *ins).cpu()
+    y1 = plan.forward(blob, *ins, autotune=True).cpu()
+    assert plan.last_autotune_trials > 100
+    y2 = plan.forward(blob, *ins).cpu()                  # now uses the tuned shapes
+    ref = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)
+    for y in (y0, y1, y2):
+        assert float((y - ref).abs().max()) <= TIGHT
+    assert float((y0 - y2).abs().max()) <= 2e-5
