@@ -145,6 +145,18 @@ int fastsvc_forward_profile(const fastsvc_plan* plan, const void* dev_blob,
 int fastsvc_forward_launch_count(const fastsvc_plan* plan, int32_t with_spk_emb);
 double fastsvc_flops_per_sample(const fastsvc_plan* plan);
 
+/* ---- the step right before the forward inside `inference()` ----
+ * Replaces SignalGenerator.__call__ (harana/utils/features.py:144-213; called at fastsvc.py:381):
+ *   f0   (B, 1, F) device, Hz, 0 = unvoiced
+ *   out  (B, ntypes, F*hop) device; channel k is signal type types[k]: 0 = "noise", 1 = "sine"
+ *        (NSF sine + voiced/unvoiced noise, features.py:177-197), 2 = "uv"
+ *   scratch  fastsvc_signal_scratch_bytes(B, F) device bytes (per-frame phase prefix, f64)
+ * Deterministic for a given seed (the reference draws torch.randn). Asynchronous on `stream`. */
+size_t fastsvc_signal_scratch_bytes(int32_t B, int32_t F);
+int fastsvc_signal_generate(const float* f0, float* out, void* scratch, int32_t B, int32_t F, int32_t hop,
+                            float sample_rate, float sine_amp, float noise_amp,
+                            const int32_t* types, int32_t ntypes, uint64_t seed, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

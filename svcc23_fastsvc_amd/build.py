@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip.so")
-SOURCES = ["fastsvc_kernels.hip", "fastsvc_plan.cpp"]
+SOURCES = ["fastsvc_kernels.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip"]
 HEADERS = [os.path.join(CSRC, "fastsvc_kernels.h"), os.path.join(ROOT, "include", "fastsvc_hip.h")]
 ARCH = "gfx950"
 

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "fastsvc_abi_version", "fastsvc_last_error", "fastsvc_plan_create", "fastsvc_plan_destroy",
     "fastsvc_weight_blob_bytes", "fastsvc_pack_weights", "fastsvc_workspace_bytes",
     "fastsvc_forward", "fastsvc_autotune", "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
-    "fastsvc_flops_per_sample",
+    "fastsvc_flops_per_sample", "fastsvc_signal_scratch_bytes", "fastsvc_signal_generate",
 )
 
 
@@ -94,6 +94,11 @@ def load_library():
     lib.fastsvc_forward_launch_count.restype = ctypes.c_int
     lib.fastsvc_flops_per_sample.argtypes = [vp]
     lib.fastsvc_flops_per_sample.restype = ctypes.c_double
+    lib.fastsvc_signal_scratch_bytes.argtypes = [i32, i32]
+    lib.fastsvc_signal_scratch_bytes.restype = sz
+    lib.fastsvc_signal_generate.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, ctypes.c_float,
+                                            ctypes.c_float, ctypes.POINTER(i32), i32, ctypes.c_uint64, vp]
+    lib.fastsvc_signal_generate.restype = ctypes.c_int
     if lib.fastsvc_abi_version() != 1:
         raise FastSVCError("libfastsvc_hip.so ABI version mismatch")
     _LIB = lib
