@@ -198,23 +198,31 @@ struct UnitWeightStream {
 template <int MW, int NW, int NSTEPS>
 __device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0, int XS,
                                           UnitWeightStream<MW, NSTEPS>& ws, int dil) {
-    // The LDS reads of step s+1 are issued BEFORE the MFMAs of step s (register double-buffer by
-    // full unrolling), so their latency hides under the matrix work even with one wave per SIMD.
-    float av[2][NW];
+    // The LDS reads of step s+LA are issued BEFORE the MFMAs of step s (register ring by full
+    // unrolling), so their latency hides under the matrix work even with one wave per SIMD.
+    // Look-ahead LA = 2 steps when a step is short (few MFMAs), else 1.
+    constexpr int LA = (NW * MW <= 4) ? 2 : 1;
+    float av[LA + 1][NW];
     #pragma unroll
-    for (int n = 0; n < NW; ++n) av[0][n] = xa0[n * 16];
+    for (int q = 0; q < LA; ++q) {
+        if (q < NSTEPS) {
+            const int tap = q / 6, j = q % 6;
+            #pragma unroll
+            for (int n = 0; n < NW; ++n) av[q][n] = xa0[tap * dil + j * 4 * XS + n * 16];
+        }
+    }
     #pragma unroll
     for (int s = 0; s < NSTEPS; ++s) {
-        if (s + 1 < NSTEPS) {
-            const int tap = (s + 1) / 6, j = (s + 1) % 6;
+        if (s + LA < NSTEPS) {
+            const int tap = (s + LA) / 6, j = (s + LA) % 6;
             #pragma unroll
-            for (int n = 0; n < NW; ++n) av[(s + 1) & 1][n] = xa0[tap * dil + j * 4 * XS + n * 16];
+            for (int n = 0; n < NW; ++n) av[(s + LA) % (LA + 1)][n] = xa0[tap * dil + j * 4 * XS + n * 16];
         }
         #pragma unroll
         for (int n = 0; n < NW; ++n)
             #pragma unroll
             for (int m = 0; m < MW; ++m)
-                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][n], wfrag_get<MW>(ws.wr[s], m), acc[n][m], 0, 0, 0);
+                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s % (LA + 1)][n], wfrag_get<MW>(ws.wr[s], m), acc[n][m], 0, 0, 0);
         ws.wr[s] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + s * UnitWeightStream<MW, NSTEPS>::STEP_BYTES);
         // pin the re-request right behind its step (hipcc otherwise sinks the loads to the end
         // of the unit and waits for all of them at the top of the next one)
@@ -589,28 +597,33 @@ void conv_mfma_ws_kernel(const ConvParams p) {
     float* Xs0 = reinterpret_cast<float*>(ncoef + CINp);                       // [2][KC][XS]
     const int bufsz = p.KC * XS;
 
-    if (flags & F_STATS) {
-        for (int i = tid; i < 2 * 16 * MW * WM; i += 512) sstat[i] = 0.0;
-    }
-    if (flags & F_PRE_NORM) {
-        // (u - mean) * rstd + p  ==  u * A + Bc  with A = rstd, Bc = p - mean * rstd
-        const double inv_len = 1.0 / (double)p.x_T;
-        for (int c = tid; c < CINp; c += 512) {
-            float2 ab = make_float2(0.f, 0.f);
-            if (c < p.CIN) {
-                const double q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
-                const double q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
-                const double mean = q1 * inv_len;
-                double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
-                var = var > 0.0 ? var : 0.0;
-                const double rstd = 1.0 / sqrt(var + IN_EPS);
-                ab.x = (float)rstd;
-                ab.y = (float)((double)p.spk[(long)b * p.CIN + c] - mean * rstd);
-            }
-            ncoef[c] = ab;
+    // InstanceNorm coefficients and zeroed sums: run by ALL threads, but only after the producers
+    // have their first two window loads and the consumers their weight stream in flight, so the
+    // st_in round trip overlaps them instead of preceding them.
+    auto setup_shared = [&]() {
+        if (flags & F_STATS) {
+            for (int i = tid; i < 2 * 16 * MW * WM; i += 512) sstat[i] = 0.0;
         }
-    }
-    __syncthreads();                                   // coefficients / zeroed sums visible
+        if (flags & F_PRE_NORM) {
+            // (u - mean) * rstd + p  ==  u * A + Bc  with A = rstd, Bc = p - mean * rstd
+            const double inv_len = 1.0 / (double)p.x_T;
+            for (int c = tid; c < CINp; c += 512) {
+                float2 ab = make_float2(0.f, 0.f);
+                if (c < p.CIN) {
+                    const double q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
+                    const double q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
+                    const double mean = q1 * inv_len;
+                    double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
+                    var = var > 0.0 ? var : 0.0;
+                    const double rstd = 1.0 / sqrt(var + IN_EPS);
+                    ab.x = (float)rstd;
+                    ab.y = (float)((double)p.spk[(long)b * p.CIN + c] - mean * rstd);
+                }
+                ncoef[c] = ab;
+            }
+        }
+        __syncthreads();                                   // coefficients / zeroed sums visible
+    };
 
     if (producer) {
         // ================================ PRODUCER WAVES ================================
@@ -694,6 +707,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         unsigned oka = 0, okb = 0;
         pload(0, pa, oka);
         if (nunits > 1) pload(1, pb, okb);
+        setup_shared();
         pcommit(0, pa, oka, Xs0);
         __syncthreads();                               // unit 0 staged
         for (int u = 0; u < nunits; u += 2) {
@@ -730,6 +744,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
                              (flags & (F_STATS | F_AFF_OUT)) ? 2 * ct : 0);
             R.r1x = make_rsrc(p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nul, p.r1x ? p.T : 0);
         }
+        setup_shared();
         __syncthreads();                               // unit 0 staged
         int u = 0;
         for (int tl = 0; tl < ntiles; ++tl) {
