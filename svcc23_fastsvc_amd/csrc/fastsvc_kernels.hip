@@ -560,7 +560,71 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
     }
 }
 
-template <int MW, int NW, int WM, int WN, int MODE, int NTAPS>
+// Compile-time specialised epilogues for the NARROW (HBM-bound) layers.  The generic epilogue
+// above keeps every optional tensor behind a uniform branch, which makes hipcc wait vmcnt(0)
+// after each load: ~3 serialised memory latencies per item, 8 items per tile.  Here the kind is a
+// template parameter, the code is straight-line, out-of-range lanes use an offset beyond every
+// descriptor (loads return 0, stores are dropped) and the loads of G items are issued together.
+enum : int { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RES = 2, EPI_RANK1 = 3, EPI_AFF = 4 };
+constexpr int OOB_OFF = 0x7ffffff0;
+
+template <int MW, int NW, int EPI>
+__device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[NW][MW],
+                                                 float (&s1)[MW], float (&s2)[MW],
+                                                 int sig, int mg, int tcol0, bool active, int lane) {
+    if (p.dbg & DBG_NO_EPILOGUE) { ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg, tcol0, active, lane); return; }
+    if (!active) return;                                   // whole wave (uniform)
+    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;     // max(v, slope*v): identity for 1
+    const float* biasp = p.bias + (long)sig * p.bias_sig;                  // padded to the channel tiles
+    const int shift_soff = p.COUT * p.T * 4;
+    constexpr int G = (EPI == EPI_AFF) ? (NW >= 2 ? 2 : 1) : NW;           // items whose loads fly together
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const bool cok = cot < p.COUT;
+        const int co = cok ? cot : 0;
+        const float bias = biasp[cot];                     // padded array: always in bounds
+        float r1w = 0.f, r1b = 0.f;
+        if (EPI == EPI_RANK1) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
+        const int rowoff = co * p.T;
+        #pragma unroll
+        for (int n0 = 0; n0 < NW; n0 += G) {
+            int off[G];
+            f32x4 l0[G], l1[G], l2[G];
+            #pragma unroll
+            for (int g = 0; g < G; ++g) {                  // every load of the group first
+                const int t = tcol0 + (n0 + g) * 16 + (lane >> 4) * 4;
+                const bool ok = cok && t < p.T;
+                off[g] = ok ? (rowoff + t) * 4 : OOB_OFF;
+                if (EPI == EPI_RES) l0[g] = buf_load4(R.res, off[g], 0);
+                if (EPI == EPI_RANK1) l0[g] = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
+                if (EPI == EPI_AFF) {
+                    l0[g] = buf_load4(R.res, off[g], 0);              // zero-length descriptor when absent
+                    l1[g] = buf_load4(R.ss, off[g], 0);
+                    l2[g] = buf_load4(R.ss, off[g], shift_soff);
+                }
+            }
+            #pragma unroll
+            for (int g = 0; g < G; ++g) {
+                f32x4 v = acc[n0 + g][m];
+                v += bias;
+                v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+                v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                if (EPI == EPI_RES || EPI == EPI_AFF) v += l0[g];
+                if (EPI == EPI_RANK1) v += l0[g] * r1w + r1b;
+                buf_store4(R.y, off[g], v);                           // dropped when y is absent
+                if (EPI == EPI_AFF) {
+                    const f32x4 u = l1[g] * v + l2[g];
+                    buf_store4(R.y2, off[g], u);
+                    s1[m] += (u.x + u.y) + (u.z + u.w);
+                    s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+                }
+            }
+        }
+    }
+}
+
+template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(512, (MW <= 2 || NW == 1) ? 4 : 2)  // <= 128 VGPRs where two workgroups per CU fit without spills
 void conv_mfma_ws_kernel(const ConvParams p) {
     constexpr int NSTEPS = 6 * NTAPS;
@@ -758,8 +822,12 @@ void conv_mfma_ws_kernel(const ConvParams p) {
                 if (ch + 1 == p.nchunks) {
                     #pragma unroll
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
-                    ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg,
-                                             (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
+                    if constexpr (EPI == EPI_GENERIC)
+                        ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg,
+                                                 (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
+                    else
+                        ws_epilogue_kind<MW, NW, EPI>(p, R, acc, s1, s2, sig, mg,
+                                                      (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
                     if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
                         // fp32 partials stay short (this tile only); the running sums are f64 in LDS
                         #pragma unroll
@@ -815,6 +883,22 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     block = dim3(512);                                  // 4 consumer + 4 producer waves
     if (p.ntaps == 1) {
         hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DECIMATE, 1>), grid, block, smem, stream, p);
+    } else if (MW == 2 && p.ntaps == 3 && (p.mode == MODE_STRETCH || p.mode == MODE_DIRECT)) {
+        // narrow layers: compile-time specialised epilogue
+        const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+        const int kind = aff ? EPI_AFF : p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
+        if constexpr (MW == 2) {
+#define FASTSVC_EPI(mode, k) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), grid, block, smem, stream, p)
+            if (p.mode == MODE_STRETCH) {
+                if (kind == EPI_AFF) FASTSVC_EPI(MODE_STRETCH, EPI_AFF); else FASTSVC_EPI(MODE_STRETCH, EPI_PLAIN);
+            } else {
+                if (kind == EPI_AFF) FASTSVC_EPI(MODE_DIRECT, EPI_AFF);
+                else if (kind == EPI_RANK1) FASTSVC_EPI(MODE_DIRECT, EPI_RANK1);
+                else if (kind == EPI_RES) FASTSVC_EPI(MODE_DIRECT, EPI_RES);
+                else FASTSVC_EPI(MODE_DIRECT, EPI_PLAIN);
+            }
+#undef FASTSVC_EPI
+        }
     } else if (p.mode == MODE_STRETCH) {
         hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_STRETCH, 3>), grid, block, smem, stream, p);
     } else if (p.mode == MODE_DECIMATE) {
