@@ -104,7 +104,10 @@ def cpu_baseline(budget_s: float):
 
 
 def roofline(plan, blob, args_dev, n_prof=3):
-    """Per-kernel-symbol aggregation of hipEvent-timed launches; dominant symbol by time."""
+    """Per-kernel-symbol aggregation of hipEvent-timed launches; dominant symbol by time.
+    fastsvc_forward_profile runs the forward on ONE stream (no helper streams) so that each
+    kernel is timed running alone; `profiles/*_kernel_stats_serial.csv` is rocprofv3's view of the
+    same thing (FASTSVC_SERIAL=1), `*_kernel_stats.csv` the default multi-stream schedule."""
     agg = {}
     total_ms = 0.0
     for _ in range(n_prof):

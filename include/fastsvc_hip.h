@@ -125,7 +125,8 @@ int fastsvc_autotune(const fastsvc_plan* plan, const void* dev_blob,
  * fastsvc_forward; brackets every kernel launch with hipEvents on `stream`, synchronises the
  * stream at the end and fills one record per launch: the layer it computes, the kernel symbol
  * (template instance) it ran, its algorithmic FLOPs (2*MAC, padding excluded) and algorithmic HBM
- * bytes (each operand tensor once + packed weights once), and the measured duration. */
+ * bytes (each operand tensor once + packed weights once), and the measured duration.  The profiled
+ * forward runs on `stream` ONLY (no helper streams), so every kernel is timed running alone. */
 typedef struct fastsvc_launch_record {
     char layer[64];
     char kernel[40];

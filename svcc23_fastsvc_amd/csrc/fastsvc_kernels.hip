@@ -577,7 +577,7 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
     const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;     // max(v, slope*v): identity for 1
     const float* biasp = p.bias + (long)sig * p.bias_sig;                  // padded to the channel tiles
     const int shift_soff = p.COUT * p.T * 4;
-    constexpr int G = (EPI == EPI_AFF) ? (NW >= 2 ? 2 : 1) : NW;           // items whose loads fly together
+    constexpr int G = (EPI == EPI_AFF) ? 1 : NW;                           // items whose loads fly together
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int cot = (mg * MW + m) * 16 + (lane & 15);
@@ -883,11 +883,11 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     block = dim3(512);                                  // 4 consumer + 4 producer waves
     if (p.ntaps == 1) {
         hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DECIMATE, 1>), grid, block, smem, stream, p);
-    } else if (MW == 2 && p.ntaps == 3 && (p.mode == MODE_STRETCH || p.mode == MODE_DIRECT)) {
-        // narrow layers: compile-time specialised epilogue
+    } else if (p.ntaps == 3 && (p.mode == MODE_STRETCH || p.mode == MODE_DIRECT)) {
+        // compile-time specialised epilogue
         const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
         const int kind = aff ? EPI_AFF : p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
-        if constexpr (MW == 2) {
+        {
 #define FASTSVC_EPI(mode, k) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), grid, block, smem, stream, p)
             if (p.mode == MODE_STRETCH) {
                 if (kind == EPI_AFF) FASTSVC_EPI(MODE_STRETCH, EPI_AFF); else FASTSVC_EPI(MODE_STRETCH, EPI_PLAIN);

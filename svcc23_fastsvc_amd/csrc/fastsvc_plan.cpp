@@ -632,7 +632,16 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         const double bytes = 4.0 * (el * p.B * nsig + (double)(c.w_floats + c.b_floats) * nsig);
         char kname[40];
         if (L.pipe)
-            std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN, p.mode, c.ntaps);
+        {
+            // same rule as launch_conv_pipe: compile-time epilogue kind of the 3-tap DIRECT / STRETCH launches
+            int kind = 0;
+            if (c.ntaps == 3 && (p.mode == MODE_DIRECT || p.mode == MODE_STRETCH)) {
+                const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+                kind = aff ? 4 : (p.mode == MODE_STRETCH ? 1 : p.r1x ? 3 : p.res ? 2 : 1);
+            }
+            std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN,
+                          p.mode, c.ntaps, kind);
+        }
         else
             std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d,1,4>", L.MW, L.NW);
         hipError_t e = prof->begin(stream, layer, kname, flops, bytes);
@@ -696,7 +705,8 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static const bool serial = std::getenv("FASTSVC_SERIAL") != nullptr;   // debugging: one stream
     g_tune.plan = plan;
-    ExecCtx* ctx = (serial || g_tune.tuning) ? nullptr : exec_ctx_for_current_device();
+    // per-launch profiling and autotuning run on ONE stream so that every kernel is timed alone
+    ExecCtx* ctx = (serial || g_tune.tuning || prof) ? nullptr : exec_ctx_for_current_device();
     hipStream_t s_film = ctx ? ctx->aux[0] : stream;      // FiLM nets of stages 0..n-2
     hipStream_t s_side = ctx ? ctx->aux[1] : stream;      // 1x1 / stretch residual convs
     int evi = 0;

@@ -13,6 +13,9 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "stats_serial", "stats_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "stats_serial", "stats_kernel_stats.csv"),
+                os.path.join(dst, f"{tag}_kernel_stats_serial.csv"))
 
 
 def per_kernel(path, counter):
@@ -35,9 +38,9 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     w_kib = write[k][0] / write[k][1] if k in write else 0.0
     hbm = (2.0 * f_kib + w_kib) * 1024.0
     rows.append((k, fetch[k][1], f_kib, w_kib, hbm))
-    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", k)
+    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", k)
     if m:
-        js["conv_mfma_ws<%s,%s,%s,%s,%s,%s>" % m.groups()] = hbm
+        js["conv_mfma_ws<%s,%s,%s,%s,%s,%s,%s>" % m.groups()] = hbm
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
     if m:
         js["conv_mfma<%s,%s,%s,%s>" % m.groups()] = hbm
