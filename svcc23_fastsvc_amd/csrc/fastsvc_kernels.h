@@ -10,7 +10,15 @@ namespace fastsvc {
 enum : int {
     MODE_DIRECT = 0,    // src = t
     MODE_DECIMATE = 1,  // src = t * s        Squeeze2d == x[..., ::s]        (upsample.py:53-74)
-    MODE_STRETCH = 2    // src = t / s        Stretch2d == repeat_interleave  (upsample.py:21-50)
+    MODE_STRETCH = 2,   // src = t / s        Stretch2d == repeat_interleave  (upsample.py:21-50)
+    // Stretch2d + k=3 d=1 conv computed at the INPUT rate (SURVEY note P).  With j = t / s,
+    // phase = t % s and the stretched signal xs[t] = x[j]:
+    //     out[s*j + phase] = z[j] + (phase == 0 ? a[j] : 0) + (phase == s-1 ? c[j] : 0)
+    //     z = (W0+W1+W2) x[j],  a = W0 (x[j-1] - x[j]),  c = W2 (x[j+1] - x[j])
+    // i.e. three input-rate 1-tap products instead of three output-rate ones: s times fewer MACs.
+    // Geometry: T (tiles, x_T) is the INPUT length, the output tensors have T * s columns; the
+    // packed weights hold W0 | W0+W1+W2 | W2 in the three tap slots (fastsvc_plan.cpp packer).
+    MODE_POLY = 3
 };
 
 enum : int {
@@ -84,6 +92,8 @@ struct ConvLaunch {
 
 // the pipelined kernel needs T % 4 == 0, DIRECT (x_T % 4 == 0) or STRETCH (no affine) indexing
 bool conv_pipe_supported(const ConvParams& p);
+// tile shapes the polyphase (MODE_POLY) variant of the pipelined kernel is compiled for
+bool conv_poly_shape(int MW, int NW, int WM, int WN);
 
 // generic k in {1,3} dilated conv, MFMA f32 16x16x4
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);

@@ -232,6 +232,43 @@ __device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0
     if (ws.next >= ws.total) ws.next = 0;
 }
 
+// Polyphase unit (MODE_POLY): per 4-channel k-group read x[j-1], x[j], x[j+1] from the window
+// (the same three LDS reads a 3-tap conv makes), form the two differences on the VALU and feed three
+// accumulator sets: acc[0] += (x[j-1]-x[j]) W0,  acc[1] += x[j] (W0+W1+W2),  acc[2] += (x[j+1]-x[j]) W2.
+// Weight slots: tap-major like every unit (slot = tap * 6 + k-group), so the stream is unchanged.
+template <int MW, int NW>
+__device__ __forceinline__ void mfma_unit_poly(f32x4 (&acc)[3][NW][MW], const float* xa0, int XS,
+                                               UnitWeightStream<MW, UNIT_STEPS>& ws) {
+    float av[2][3][NW];                                     // k-group ring, one group of look-ahead
+    #pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) av[0][tap][n] = xa0[tap + n * 16];
+    #pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        if (j + 1 < 6) {
+            #pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+                #pragma unroll
+                for (int n = 0; n < NW; ++n) av[(j + 1) & 1][tap][n] = xa0[tap + (j + 1) * 4 * XS + n * 16];
+        }
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            #pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const float a = (tap == 1) ? av[j & 1][1][n] : av[j & 1][tap][n] - av[j & 1][1][n];
+                #pragma unroll
+                for (int m = 0; m < MW; ++m)
+                    acc[tap][n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wfrag_get<MW>(ws.wr[tap * 6 + j], m), acc[tap][n][m], 0, 0, 0);
+            }
+            ws.wr[tap * 6 + j] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + (tap * 6 + j) * UnitWeightStream<MW, UNIT_STEPS>::STEP_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    ws.next += UnitWeightStream<MW, UNIT_STEPS>::UNIT_BYTES;
+    if (ws.next >= ws.total) ws.next = 0;
+}
+
 // Epilogue of one time tile.  D layout (16x16x4 f32): lane holds column j = lane & 15 (output
 // channel) and rows i = (lane >> 4) * 4 + r (time), r = 0..3 -> four consecutive time steps per
 // lane.  s1/s2 accumulate the InstanceNorm partial sums across the tiles a workgroup walks.
@@ -624,8 +661,78 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
     }
 }
 
-template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC>
-__global__ __launch_bounds__(512, (MW <= 2 || NW == 1) ? 4 : 2)  // <= 128 VGPRs where two workgroups per CU fit without spills
+// Polyphase epilogue (MODE_POLY): a lane holds z, a, c for FOUR consecutive input columns of one
+// output channel, i.e. 4*S consecutive output samples = S float4 stores.  EPI_PLAIN: y = o + bias
+// (the stretched residual conv, fastsvc.py:72-75,94); EPI_AFF: t = lrelu(o + bias),
+// u = scale * t + shift -> y2, InstanceNorm partial sums (fastsvc.py:57-62,97 + 115-140).
+template <int MW, int NW, int EPI, int S>
+__device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[3][NW][MW],
+                                                 float (&s1)[MW], float (&s2)[MW],
+                                                 int mg, int tcol0, bool active, int lane) {
+    if (!active) return;                                   // whole wave (uniform)
+    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
+    const int T_out = p.T * S;
+    const int shift_soff = p.COUT * T_out * 4;
+    constexpr int G = (MW <= 2 && NW == 1) ? (S < 4 ? S : 4) : S;  // output float4s whose loads fly together (register budget)
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const bool cok = cot < p.COUT;
+        const int co = cok ? cot : 0;
+        const float bias = p.bias[cot];                    // padded array: always in bounds
+        const int rowoff = co * T_out;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int t = tcol0 + n * 16 + (lane >> 4) * 4;            // input-rate column
+            const bool ok = cok && t < p.T;
+            const int off0 = ok ? (rowoff + t * S) * 4 : OOB_OFF;
+            // first / last phase of each input column (bias folded in); the middle phases are z + bias
+            const f32x4 zz = acc[1][n][m] + bias;
+            const f32x4 zf = zz + acc[0][n][m];
+            const f32x4 zl = zz + acc[2][n][m];
+            auto phase_value = [&](int k) -> float {               // k: compile-time after unrolling
+                const int jj = k / S, ph = k % S;
+                return ph == 0 ? zf[jj] : ph == S - 1 ? zl[jj] : zz[jj];
+            };
+            #pragma unroll
+            for (int q0 = 0; q0 < S; q0 += G) {
+                f32x4 l1[G], l2[G];
+                if (EPI == EPI_AFF) {
+                    #pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (q0 + g < S) {
+                            l1[g] = buf_load4(R.ss, off0 + (q0 + g) * 16, 0);
+                            l2[g] = buf_load4(R.ss, off0 + (q0 + g) * 16, shift_soff);
+                        }
+                }
+                #pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (q0 + g < S) {
+                        const int q = q0 + g;
+                        f32x4 v = f32x4{phase_value(4 * q), phase_value(4 * q + 1), phase_value(4 * q + 2), phase_value(4 * q + 3)};
+                        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+                        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                        buf_store4(R.y, off0 + q * 16, v);             // dropped when y is absent
+                        if (EPI == EPI_AFF) {
+                            const f32x4 u = l1[g] * v + l2[g];
+                            buf_store4(R.y2, off0 + q * 16, u);
+                            s1[m] += (u.x + u.y) + (u.z + u.w);
+                            s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+                        }
+                    }
+            }
+        }
+    }
+}
+
+// Register budget: 128 VGPRs (two workgroups per CU) where that fits without spills, else 256.
+// Polyphase with MW == 3 carries three accumulator sets next to the 54-register weight ring and
+// a 2*S-load epilogue: 256 (those layers launch about one workgroup per CU anyway).
+template <int MW, int NW, int MODE>
+constexpr int ws_min_waves() { return (MODE == MODE_POLY) ? (MW <= 2 && NW == 1 ? 4 : 2) : ((MW <= 2 || NW == 1) ? 4 : 2); }
+
+template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC, int S = 1>
+__global__ __launch_bounds__(512, (ws_min_waves<MW, NW, MODE>()))
 void conv_mfma_ws_kernel(const ConvParams p) {
     constexpr int NSTEPS = 6 * NTAPS;
     constexpr int NT = 16 * NW * WN;
@@ -791,7 +898,9 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         }
     } else {
         // ================================ CONSUMER WAVES ================================
-        f32x4 acc[NW][MW];
+        constexpr bool POLY = (MODE == MODE_POLY);
+        f32x4 acc[POLY ? 1 : NW][MW];
+        f32x4 acc3[3][POLY ? NW : 1][MW];              // polyphase: a / z / c accumulator sets
         float s1[MW], s2[MW];
         UnitWeightStream<MW, NSTEPS> wst;
         wst.init(p.w + (long)sig * p.w_sig + (long)(active ? mg : 0) * p.Q * 64 * MW,
@@ -799,7 +908,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         const int colbase = (lane >> 4) * XS + (lane & 15) + wave_n * (NW * 16) + (halo_al - halo);
         EpiRsrc R;
         {
-            const long ct = (long)p.COUT * p.T;
+            const long ct = (long)p.COUT * p.T * (POLY ? S : 1);     // polyphase: outputs have T * S columns
             const float* nul = p.bias;                  // any valid address for unused descriptors
             R.y = make_rsrc(p.y ? p.y + (long)sig * p.y_sig + (long)b * p.y_b : nul, p.y ? ct : 0);
             R.y2 = make_rsrc((flags & F_AFF_OUT) ? p.y2 + (long)b * p.y2_b : nul, (flags & F_AFF_OUT) ? ct : 0);
@@ -812,17 +921,31 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         __syncthreads();                               // unit 0 staged
         int u = 0;
         for (int tl = 0; tl < ntiles; ++tl) {
-            #pragma unroll
-            for (int n = 0; n < NW; ++n)
+            if constexpr (POLY) {
                 #pragma unroll
-                for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < 3; ++k)
+                    #pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        #pragma unroll
+                        for (int m = 0; m < MW; ++m) acc3[k][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                #pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
-                if (active && !(p.dbg & DBG_NO_MFMA))
-                    mfma_unit<MW, NW, NSTEPS>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
+                if (active && !(p.dbg & DBG_NO_MFMA)) {
+                    if constexpr (POLY) mfma_unit_poly<MW, NW>(acc3, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
+                    else mfma_unit<MW, NW, NSTEPS>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
+                }
                 if (ch + 1 == p.nchunks) {
                     #pragma unroll
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
-                    if constexpr (EPI == EPI_GENERIC)
+                    if constexpr (POLY)
+                        ws_epilogue_poly<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg,
+                                                         (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
+                    else if constexpr (EPI == EPI_GENERIC)
                         ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg,
                                                  (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
                     else
@@ -869,6 +992,14 @@ static hipError_t launch_conv_generic(const ConvParams& p, int nsig, hipStream_t
     return hipGetLastError();
 }
 
+// tile shapes the polyphase variant is compiled for: three accumulator sets, so NW * MW <= 4
+template <int MW, int NW, int WM, int WN>
+constexpr bool poly_shape() { return WM != 4 && ((MW == 3 && NW == 1) || (MW == 2 && NW <= 2)); }
+
+bool conv_poly_shape(int MW, int NW, int WM, int WN) {
+    return WM != 4 && ((MW == 3 && NW == 1) || (MW == 2 && NW <= 2)) && WM * WN == 4;
+}
+
 template <int MW, int NW, int WM, int WN>
 static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t stream) {
     constexpr int NT = 16 * NW * WN;
@@ -881,7 +1012,20 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM
                       + sizeof(float) * (2 * (size_t)CINp + (size_t)nbuf * p.KC * p.xs);
     block = dim3(512);                                  // 4 consumer + 4 producer waves
-    if (p.ntaps == 1) {
+    if (p.mode == MODE_POLY) {
+        if constexpr (poly_shape<MW, NW, WM, WN>()) {
+            const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+#define FASTSVC_POLY(sv) \
+            if (p.s == sv) { \
+                if (aff) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_POLY, 3, EPI_AFF, sv>), grid, block, smem, stream, p); \
+                else hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_POLY, 3, EPI_PLAIN, sv>), grid, block, smem, stream, p); \
+                return hipGetLastError(); \
+            }
+            FASTSVC_POLY(2) FASTSVC_POLY(4) FASTSVC_POLY(5)
+#undef FASTSVC_POLY
+        }
+        return hipErrorInvalidValue;
+    } else if (p.ntaps == 1) {
         hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DECIMATE, 1>), grid, block, smem, stream, p);
     } else if (p.ntaps == 3 && (p.mode == MODE_STRETCH || p.mode == MODE_DIRECT)) {
         // compile-time specialised epilogue
@@ -915,6 +1059,9 @@ bool conv_pipe_supported(const ConvParams& p) {
     if (p.ntaps == 1) return p.mode == MODE_DECIMATE;          // the 1x1 residual convs of the down nets
     if (p.ntaps != 3) return false;
     if (p.mode == MODE_DIRECT) return (p.x_T % 4) == 0;
+    if (p.mode == MODE_POLY)                                   // input-rate tiles, float4 window loads
+        return (p.x_T % 4) == 0 && p.T == p.x_T && p.dil == 1 && (p.s == 2 || p.s == 4 || p.s == 5) &&
+               !p.res && !p.r1x && !(p.flags & F_PRE_NORM);
     return p.mode == MODE_STRETCH || p.mode == MODE_DECIMATE;
 }
 

@@ -41,6 +41,10 @@ struct PackedConv {
     int MW = 1, KC = 4, nchunks = 1, Q = 0, ngroups = 1;
     size_t w_off = 0, b_off = 0;      // float offsets into the blob
     size_t w_floats = 0, b_floats = 0;
+    // stretch + conv layers also carry the polyphase taps W0 | W0+W1+W2 | W2 (MODE_POLY), same
+    // fragment layout and size as the plain weights
+    bool poly = false;
+    size_t wp_off = 0;
 };
 
 // Source description used by the packer: virtual weight W[co][ci][tap] assembled from up to four
@@ -200,6 +204,12 @@ int build_plan(fastsvc_plan& P) {
         P.add_conv(&u.first, 1, cin, u.C, 3, 1, {single(p + ".conv_first")});
         P.add_conv(&u.res, 1, u.C, u.C, 3, 1, {single(p + ".residual_block.1")});
         P.add_conv(&u.up, 1, u.C, u.C, 3, 1, {single(p + ".upsample_block0.2")});
+        for (PackedConv* pc : {&u.res, &u.up}) {               // the two convs behind the stretch
+            if (pc->KC == 24 && (u.scale == 2 || u.scale == 4 || u.scale == 5)) {
+                pc->poly = true;
+                pc->wp_off = P.alloc(pc->w_floats);
+            }
+        }
         P.add_conv(&u.d3, 1, u.C, u.C, 3, 3, {single(p + ".conv_block1.1")});
         P.add_conv(&u.d9, 1, u.C, u.C, 3, 9, {single(p + ".conv_block2.1")});
         P.add_conv(&u.d27, 1, u.C, u.C, 3, 27, {single(p + ".conv_block3.1")});
@@ -321,23 +331,35 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         }
         // fragment order: [group][q][lane][m],  q = (chunk * ntaps + tap) * (KC/4) + g
         //   value = W[co = (group*MW + m)*16 + (lane & 15)][ci = chunk*KC + 4g + (lane >> 4)][tap]
-        float* wp = blob + c.w_off;
-        const int kg = c.KC / 4;
-        for (int grp = 0; grp < c.ngroups; ++grp)
-            for (int ch = 0; ch < c.nchunks; ++ch)
-                for (int tap = 0; tap < c.ntaps; ++tap)
-                    for (int g = 0; g < kg; ++g) {
-                        const int q = (ch * c.ntaps + tap) * kg + g;
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int ci = ch * c.KC + 4 * g + (lane >> 4);
-                            for (int m = 0; m < c.MW; ++m) {
-                                const int co = (grp * c.MW + m) * 16 + (lane & 15);
-                                float v = 0.f;
-                                if (co < c.cout && ci < c.cin) v = W[((size_t)co * c.cin + ci) * c.ntaps + tap];
-                                wp[(((size_t)grp * c.Q + q) * 64 + lane) * c.MW + m] = v;
+        auto pack_fragments = [&](const std::vector<float>& Wt, float* wp) {
+            const int kg = c.KC / 4;
+            for (int grp = 0; grp < c.ngroups; ++grp)
+                for (int ch = 0; ch < c.nchunks; ++ch)
+                    for (int tap = 0; tap < c.ntaps; ++tap)
+                        for (int g = 0; g < kg; ++g) {
+                            const int q = (ch * c.ntaps + tap) * kg + g;
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int ci = ch * c.KC + 4 * g + (lane >> 4);
+                                for (int m = 0; m < c.MW; ++m) {
+                                    const int co = (grp * c.MW + m) * 16 + (lane & 15);
+                                    float v = 0.f;
+                                    if (co < c.cout && ci < c.cin) v = Wt[((size_t)co * c.cin + ci) * c.ntaps + tap];
+                                    wp[(((size_t)grp * c.Q + q) * 64 + lane) * c.MW + m] = v;
+                                }
                             }
                         }
-                    }
+        };
+        pack_fragments(W, blob + c.w_off);
+        if (c.poly) {
+            // polyphase taps (fastsvc_kernels.h, MODE_POLY): slot 0 = W0, slot 1 = W0+W1+W2, slot 2 = W2
+            std::vector<float> Wp(W.size());
+            for (size_t i = 0; i + 2 < W.size(); i += 3) {
+                Wp[i] = W[i];
+                Wp[i + 1] = (float)((double)W[i] + (double)W[i + 1] + (double)W[i + 2]);
+                Wp[i + 2] = W[i + 2];
+            }
+            pack_fragments(Wp, blob + c.wp_off);
+        }
         float* bp = blob + c.b_off;
         for (int co = 0; co < c.cout; ++co) bp[co] = bias[co];
     }
@@ -502,6 +524,16 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                     const char* layer = "") {
     p.CIN = c.cin; p.KC = c.KC; p.nchunks = c.nchunks;
     p.w = blob + c.w_off; p.w_sig = pair_w_stride;
+    static const bool no_poly = std::getenv("FASTSVC_NO_POLY") != nullptr;   // A/B switch
+    const long T_out = p.T;                                  // output columns (accounting below)
+    if (p.mode == MODE_STRETCH && c.poly && !no_poly && c.dil == 1 && p.x_T % 4 == 0 && (long)p.x_T * p.s == p.T) {
+        // Stretch2d + conv at the INPUT rate (polyphase): tiles walk the input columns
+        ConvParams q = p;
+        q.mode = MODE_POLY; q.T = p.x_T; q.w = blob + c.wp_off;
+        q.Q = c.Q; q.ngroups = c.ngroups; q.COUT = c.cout; q.ntaps = c.ntaps; q.dil = c.dil; q.vec = 1;
+        if (conv_pipe_supported(q)) { p.mode = MODE_POLY; p.T = p.x_T; p.w = q.w; }
+    }
+    const bool poly = p.mode == MODE_POLY;
     p.bias = blob + c.b_off; p.bias_sig = pair_b_stride;
     p.Q = c.Q; p.ngroups = c.ngroups; p.COUT = c.cout;
     p.ntaps = c.ntaps; p.dil = c.dil;
@@ -521,7 +553,12 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         // the grid runs in ceil(workgroups / resident slots) rounds.
         struct Cand { int NW, WM, WN; };
         std::vector<Cand> cands;
-        if (c.MW == 3 && c.ngroups % 4 == 0) cands = {{4, 4, 1}, {2, 4, 1}, {4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
+        if (poly) {
+            if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{1, 2, 2}, {1, 1, 4}};
+            else if (c.MW == 3) cands = {{1, 1, 4}};
+            else cands = {{2, 1, 4}, {1, 1, 4}};
+        }
+        else if (c.MW == 3 && c.ngroups % 4 == 0) cands = {{4, 4, 1}, {2, 4, 1}, {4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         else if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         else cands = {{4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         auto xs_for = [&](int NW, int WN) {
@@ -583,12 +620,13 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             const int NT = 16 * cd.NW * cd.WN;
             const long ntx = (p.T + NT - 1) / NT;
             const long gy = (c.ngroups + cd.WM - 1) / cd.WM;
-            const int resident = (c.MW <= 2 || cd.NW == 1) ? 2 : 1;          // VGPR budget, see the kernel
+            const int resident = poly ? ((c.MW <= 2 && cd.NW == 1) ? 2 : 1)
+                                      : ((c.MW <= 2 || cd.NW == 1) ? 2 : 1);   // VGPR budget, see the kernel
             const long slots = 256L * resident;
             // unit time: MFMA stream of one consumer wave vs bytes the 256 producer threads move
             const double mfma_us = 6.0 * c.ntaps * cd.NW * c.MW * 32.0 / 2.2e3;
             const double win = NT + 2.0 * ((halo + 3) & ~3);
-            const double bytes_unit = c.KC * win * 4.0 + (double)16 * c.MW * cd.WM * NT * 4.0 *
+            const double bytes_unit = c.KC * win * 4.0 + (double)16 * c.MW * cd.WM * NT * (poly ? p.s : 1) * 4.0 *
                                       ((p.y ? 1 : 0) + ((p.flags & F_AFF_OUT) ? 3 : 0) + (p.res ? 1 : 0)) / c.nchunks;
             const double mem_us = bytes_unit / (5.0e6 / 256.0 / resident);    // ~5 TB/s shared by all slots
             // packed weights streamed from L2 by the four consumer waves (per unit, per workgroup):
@@ -618,26 +656,28 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         p.xs = (W + 15) / 32 * 32 + 16;
     }
     if (prof) {
-        const double cols = (double)p.T * p.B * nsig;
+        // algorithmic work of the layer as the reference defines it (3 taps at the OUTPUT rate for
+        // the stretched convs, whichever way they are computed)
+        const double cols = (double)T_out * p.B * nsig;
         const double flops = 2.0 * c.ntaps * c.cin * c.cout * cols;
-        double in_cols = (double)p.T;                       // source columns actually needed
-        if (p.mode == MODE_STRETCH) in_cols = (double)p.x_T;
+        double in_cols = (double)T_out;                     // source columns actually needed
+        if (p.mode == MODE_STRETCH || poly) in_cols = (double)p.x_T;
         double el = (double)c.cin * in_cols;
-        if (p.y) el += (double)c.cout * p.T;
-        if (p.flags & F_AFF_OUT) el += (double)c.cout * p.T;
-        if (p.flags & F_PRE_AFFINE) el += 2.0 * c.cin * p.T;
-        if (p.res) el += (double)c.cout * p.T;
-        if (p.r1x) el += (double)p.T;
-        if (p.flags & (F_STATS | F_AFF_OUT)) el += 2.0 * c.cout * p.T;
+        if (p.y) el += (double)c.cout * T_out;
+        if (p.flags & F_AFF_OUT) el += (double)c.cout * T_out;
+        if (p.flags & F_PRE_AFFINE) el += 2.0 * c.cin * T_out;
+        if (p.res) el += (double)c.cout * T_out;
+        if (p.r1x) el += (double)T_out;
+        if (p.flags & (F_STATS | F_AFF_OUT)) el += 2.0 * c.cout * T_out;
         const double bytes = 4.0 * (el * p.B * nsig + (double)(c.w_floats + c.b_floats) * nsig);
         char kname[40];
         if (L.pipe)
         {
             // same rule as launch_conv_pipe: compile-time epilogue kind of the 3-tap DIRECT / STRETCH launches
             int kind = 0;
-            if (c.ntaps == 3 && (p.mode == MODE_DIRECT || p.mode == MODE_STRETCH)) {
+            if (c.ntaps == 3 && (p.mode == MODE_DIRECT || p.mode == MODE_STRETCH || poly)) {
                 const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
-                kind = aff ? 4 : (p.mode == MODE_STRETCH ? 1 : p.r1x ? 3 : p.res ? 2 : 1);
+                kind = aff ? 4 : ((p.mode == MODE_STRETCH || poly) ? 1 : p.r1x ? 3 : p.res ? 2 : 1);
             }
             std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN,
                           p.mode, c.ntaps, kind);

@@ -150,3 +150,29 @@ def test_oracle_against_live_reference():
                     torch.from_numpy(b.spk_emb)).numpy()
     y = O.forward_as_executed(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb).numpy()
     assert np.abs(y - y_ref).max() <= TOL
+
+
+@pytest.mark.parametrize("s", [2, 4, 5])
+def test_polyphase_identity_of_stretched_conv(s):
+    """The algebra the MODE_POLY kernel relies on (SURVEY note P), checked against stock torch ops:
+    Conv3_d1(Stretch_s(x))[s*j + ph] = z[j] + (ph == 0) a[j] + (ph == s-1) c[j] with
+    z = (W0+W1+W2) x[j], a = W0 (x[j-1] - x[j]), c = W2 (x[j+1] - x[j]) and zero padding."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(100 + s)
+    C, T = 6, 17
+    x = torch.randn(2, C, T, generator=g, dtype=torch.float64)
+    w = torch.randn(C, C, 3, generator=g, dtype=torch.float64)
+    bias = torch.randn(C, generator=g, dtype=torch.float64)
+    ref = F.conv1d(torch.repeat_interleave(x, s, dim=-1), w, bias, padding=1)
+    xm = F.pad(x, (1, 0))[..., :-1]
+    xp = F.pad(x, (0, 1))[..., 1:]
+    mm = lambda wk, v: torch.einsum("oc,bct->bot", wk, v)
+    z = mm(w.sum(-1), x)
+    a = mm(w[..., 0], xm - x)
+    c = mm(w[..., 2], xp - x)
+    out = z.repeat_interleave(s, dim=-1).clone()
+    out[..., 0::s] += a
+    out[..., s - 1::s] += c
+    out += bias[None, :, None]
+    assert float((out - ref).abs().max()) < 1e-12

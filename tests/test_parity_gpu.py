@@ -240,6 +240,39 @@ def test_autotuned_launch_shapes_keep_parity(dev):
     assert float((y0 - y2).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("F,expect_poly", [(40, (True, True, True, True)), (42, (False, True, True, True)),
+                                           (41, (False, False, True, True))])
+def test_polyphase_stretch_convs_taps_and_fallback(dev, F, expect_poly):
+    """Stretch2d + conv (upsample.py:21-50 + fastsvc.py:57-62,72-75) runs at the INPUT rate
+    (kernel mode 3, s-times fewer MACs) whenever the block's input length is a multiple of 4 and
+    falls back to the gathered 3-tap kernel (mode 2) otherwise; both must reproduce the oracle's
+    xr (stretched residual conv) and u1 (FiLM-affined up conv) taps of every block."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 41)
+    B = 2
+    b = S.synth_batch(cfg, B, F, 42)
+    plan = A.Plan(cfg)
+    blob = plan.pack(sd).to(dev)
+    ws = torch.zeros(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    recs = []
+    y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), workspace=ws, profile=recs)
+    torch.cuda.synchronize()
+    ref, taps = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft,
+                                b.spk_emb, return_taps=True)
+    assert float((y.cpu() - ref).abs().max()) <= TIGHT
+    kern = {r["layer"]: r["kernel"] for r in recs}
+    for i in range(cfg.n_stages):
+        for layer in (f"up.{i}.res_stretch", f"up.{i}.up_stretch"):
+            k = kern[layer]              # conv_mfma_ws<MW,NW,WM,WN,mode,ntaps,kind> or the generic conv_mfma<..>
+            mode = int(k.split("<")[1].split(",")[4]) if k.startswith("conv_mfma_ws<") else 2
+            assert mode == (3 if expect_poly[i] else 2), (layer, k)
+        for name in ("xr", "u1"):
+            got = plan.tap(f"up.{i}.{name}", B, F, ws).cpu()
+            want = taps[f"up.{i}.{name}"]
+            assert float((got - want).abs().max()) <= TIGHT * max(1.0, float(want.abs().max())), (i, name)
+
+
 def test_signal_generator_matches_reference_sine(dev):
     """SignalGenerator on the GPU vs the reference's own output (golden, noise_amp=0):
     the reference accumulates the phase in fp32 (features.py:188-190), ours in f64 mod 1, so the
