@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--autotune", action="store_true",
                     help="run the untimed device-side autotune pass (cf. cudnn.benchmark) instead of "
                          "the static launch cost model")
+    ap.add_argument("--no-table", action="store_true",
+                    help="ignore the shipped launch-shape table (svcc23_fastsvc_amd/tuned_mi355x.json)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -170,7 +172,8 @@ def main():
     wl = S.WORKLOADS[args.workload]
     B, F = wl["B"], wl["F"]
     T = F * cfg.hop
-    plan = A.Plan(cfg)
+    plan = A.Plan(cfg, load_shipped_table=not args.no_table)
+    n_table = sum(1 for k in plan.tuned_shapes() if k.split("|")[1] == str(B))
 
     # weights: rank 0 folds + packs, everyone receives the kernel-layout blob (RCCL broadcast)
     if rank == 0:
@@ -245,8 +248,9 @@ def main():
             "rtf_24k": 24000.0 / value,
             "alg_gflop_per_step": plan.flops_per_sample * B * T / 1e9,
             "e2e_alg_tflops_per_gpu": plan.flops_per_sample * B * T / (elapsed / args.steps) / 1e12,
-            "launch_shapes": "static cost model" if not args.autotune else
-                             f"autotuned on device ({getattr(plan, 'last_autotune_trials', 0)} timed trials, untimed)",
+            "launch_shapes": (f"autotuned on device ({plan.last_autotune_trials} timed trials, untimed)" if args.autotune
+                              else f"shipped table tuned_mi355x.json ({n_table} entries for this workload), else static cost model"
+                              if n_table else "static cost model"),
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -121,6 +121,17 @@ int fastsvc_autotune(const fastsvc_plan* plan, const void* dev_blob,
                      float* out, int32_t B, int32_t F,
                      void* workspace, size_t workspace_bytes, void* stream, int32_t* n_trials);
 
+/* Launch-shape table.  fastsvc_autotune stores its winners in the plan under keys
+ * "<layer>|<B>|<T>"; these entry points export them and load them back (a table measured once on an
+ * MI355X ships as svcc23_fastsvc_amd/tuned_mi355x.json, so production runs need no trial launches).
+ * An entry whose shape is not compiled for that layer is ignored at launch time (cost model instead).
+ *   fastsvc_tuned_count: number of entries;
+ *   fastsvc_tuned_get:   entry `index` in key order; key_out holds >= 96 bytes; shape = NW, WM, WN, tpw;
+ *   fastsvc_tuned_set:   insert / replace one entry. */
+int fastsvc_tuned_count(const fastsvc_plan* plan);
+int fastsvc_tuned_get(const fastsvc_plan* plan, int32_t index, char* key_out, int32_t shape_out[4]);
+int fastsvc_tuned_set(const fastsvc_plan* plan, const char* key, const int32_t shape[4]);
+
 /* Per-launch timing of one forward (bench.py roofline accounting).  Same arguments as
  * fastsvc_forward; brackets every kernel launch with hipEvents on `stream`, synchronises the
  * stream at the end and fills one record per launch: the layer it computes, the kernel symbol

@@ -94,6 +94,9 @@ struct ConvLaunch {
 bool conv_pipe_supported(const ConvParams& p);
 // tile shapes the polyphase (MODE_POLY) variant of the pipelined kernel is compiled for
 bool conv_poly_shape(int MW, int NW, int WM, int WN);
+// workgroups per CU allowed by the register budget of the pipelined variant (epilogue kind:
+// 0 generic, 1 plain, 2 residual, 3 rank-1 residual, 4 FiLM-affine)
+int conv_ws_resident(int MW, int NW, int mode, int epi_kind);
 
 // generic k in {1,3} dilated conv, MFMA f32 16x16x4
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);

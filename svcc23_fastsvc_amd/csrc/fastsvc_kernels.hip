@@ -614,7 +614,7 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
     const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;     // max(v, slope*v): identity for 1
     const float* biasp = p.bias + (long)sig * p.bias_sig;                  // padded to the channel tiles
     const int shift_soff = p.COUT * p.T * 4;
-    constexpr int G = (EPI == EPI_AFF) ? 1 : NW;                           // items whose loads fly together
+    constexpr int G = (EPI == EPI_AFF) ? (NW == 2 ? 2 : 1) : NW;           // items whose loads fly together (register budget)
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int cot = (mg * MW + m) * 16 + (lane & 15);
@@ -728,11 +728,18 @@ __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiR
 // Register budget: 128 VGPRs (two workgroups per CU) where that fits without spills, else 256.
 // Polyphase with MW == 3 carries three accumulator sets next to the 54-register weight ring and
 // a 2*S-load epilogue: 256 (those layers launch about one workgroup per CU anyway).
-template <int MW, int NW, int MODE>
-constexpr int ws_min_waves() { return (MODE == MODE_POLY) ? (MW <= 2 && NW == 1 ? 4 : 2) : ((MW <= 2 || NW == 1) ? 4 : 2); }
+// MW == 3, NW == 2 fits 128 only with the plain / residual epilogues (no extra epilogue operands).
+constexpr bool NTAPS_IS_3_DIRECT(int mode) { return mode == MODE_DIRECT; }
+template <int MW, int NW, int MODE, int EPI>
+constexpr int ws_min_waves() {
+    if (MODE == MODE_POLY) return (MW <= 2 && NW == 1) ? 4 : 2;
+    if (MW <= 2 || NW == 1) return 4;
+    if (NW == 2 && NTAPS_IS_3_DIRECT(MODE) && (EPI == EPI_PLAIN || EPI == EPI_RES)) return 4;
+    return 2;
+}
 
 template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC, int S = 1>
-__global__ __launch_bounds__(512, (ws_min_waves<MW, NW, MODE>()))
+__global__ __launch_bounds__(512, (ws_min_waves<MW, NW, MODE, EPI>()))
 void conv_mfma_ws_kernel(const ConvParams p) {
     constexpr int NSTEPS = 6 * NTAPS;
     constexpr int NT = 16 * NW * WN;
@@ -995,6 +1002,14 @@ static hipError_t launch_conv_generic(const ConvParams& p, int nsig, hipStream_t
 // tile shapes the polyphase variant is compiled for: three accumulator sets, so NW * MW <= 4
 template <int MW, int NW, int WM, int WN>
 constexpr bool poly_shape() { return WM != 4 && ((MW == 3 && NW == 1) || (MW == 2 && NW <= 2)); }
+
+int conv_ws_resident(int MW, int NW, int mode, int epi_kind) {
+    // workgroups per CU the register budget of the compiled variant allows (see ws_min_waves)
+    if (mode == MODE_POLY) return (MW <= 2 && NW == 1) ? 2 : 1;
+    if (MW <= 2 || NW == 1) return 2;
+    if (NW == 2 && mode == MODE_DIRECT && (epi_kind == EPI_PLAIN || epi_kind == EPI_RES)) return 2;
+    return 1;
+}
 
 bool conv_poly_shape(int MW, int NW, int WM, int WN) {
     return WM != 4 && ((MW == 3 && NW == 1) || (MW == 2 && NW <= 2)) && WM * WN == 4;

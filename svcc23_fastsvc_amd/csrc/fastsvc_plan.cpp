@@ -551,6 +551,12 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         // start-up (launch, slot set-up, first window in flight) plus tpw * nchunks units, a unit
         // being bounded by the consumer wave's MFMA stream or by the producers' window traffic;
         // the grid runs in ceil(workgroups / resident slots) rounds.
+        // compile-time epilogue kind of the launch (same rule as launch_conv_pipe)
+        int epi_kind = 0;
+        if (c.ntaps == 3 && (p.mode == MODE_DIRECT || p.mode == MODE_STRETCH || poly)) {
+            const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+            epi_kind = aff ? 4 : ((p.mode == MODE_STRETCH || poly) ? 1 : p.r1x ? 3 : p.res ? 2 : 1);
+        }
         struct Cand { int NW, WM, WN; };
         std::vector<Cand> cands;
         if (poly) {
@@ -572,8 +578,13 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
             auto it = g_tune.plan->tuned.find(key);
             if (it != g_tune.plan->tuned.end()) {
-                L.NW = it->second.NW; L.WM = it->second.WM; L.WN = it->second.WN; p.tpw = it->second.tpw;
-                have = true;
+                // a loaded table may be stale: only shapes this launch is compiled for are taken
+                for (const Cand& cd : cands)
+                    if (cd.NW == it->second.NW && cd.WM == it->second.WM && cd.WN == it->second.WN &&
+                        it->second.tpw >= 1 && it->second.tpw <= 64) {
+                        L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; p.tpw = it->second.tpw;
+                        have = true;
+                    }
             }
         }
         if (!have && g_tune.tuning && g_tune.plan) {
@@ -614,14 +625,13 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         // start-up (launch, slot set-up, first window in flight) plus tpw * nchunks units, a unit
         // being bounded by the consumer wave's MFMA stream or by the producers' window traffic;
         // the grid runs in ceil(workgroups / resident slots) rounds.
-        const double startup_us = 4.0;
+        static const double startup_us = std::getenv("FASTSVC_STARTUP_US") ? std::atof(std::getenv("FASTSVC_STARTUP_US")) : 4.0;
         double best_t = 1e30;
         for (const Cand& cd : cands) {
             const int NT = 16 * cd.NW * cd.WN;
             const long ntx = (p.T + NT - 1) / NT;
             const long gy = (c.ngroups + cd.WM - 1) / cd.WM;
-            const int resident = poly ? ((c.MW <= 2 && cd.NW == 1) ? 2 : 1)
-                                      : ((c.MW <= 2 || cd.NW == 1) ? 2 : 1);   // VGPR budget, see the kernel
+            const int resident = conv_ws_resident(c.MW, cd.NW, p.mode, epi_kind);   // VGPR budget, see the kernel
             const long slots = 256L * resident;
             // unit time: MFMA stream of one consumer wave vs bytes the 256 producer threads move
             const double mfma_us = 6.0 * c.ntaps * cd.NW * c.MW * 32.0 / 2.2e3;
@@ -645,6 +655,12 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         }
         }
         L.pipe = 1;
+        {
+            static const bool verbose = std::getenv("FASTSVC_VERBOSE_SHAPES") != nullptr;   // tuning aid
+            if (verbose && prof)
+                std::fprintf(stderr, "[fastsvc] %-20s mode %d  MW %d NW %d WM %d WN %d tpw %d\n", layer, p.mode,
+                             L.MW, L.NW, L.WM, L.WN, p.tpw);
+        }
         const int NT = 16 * L.NW * L.WN;
         const int W = NT + 2 * ((halo + 3) & ~3);
         p.xs = (W + 15) / 32 * 32 + 16;
@@ -957,6 +973,31 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     HIP_TRY(launch_pointwise_out(x, blob + P.last.w_off, blob + P.last.b_off, out, B, Cx,
                                  P.cfg.out_channels, (int)T, stream));
     if (prof) HIP_TRY(prof->end());
+    return FASTSVC_OK;
+}
+
+int fastsvc_tuned_count(const fastsvc_plan* plan) {
+    if (!plan) return 0;
+    std::lock_guard<std::mutex> lock(plan->tune_mu);
+    return (int)plan->tuned.size();
+}
+
+int fastsvc_tuned_get(const fastsvc_plan* plan, int32_t index, char* key_out, int32_t shape_out[4]) {
+    if (!plan || !key_out || !shape_out) return fail(FASTSVC_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(plan->tune_mu);
+    if (index < 0 || index >= (int32_t)plan->tuned.size()) return fail(FASTSVC_E_INVALID, "index out of range");
+    auto it = plan->tuned.begin();
+    std::advance(it, index);
+    std::snprintf(key_out, 96, "%s", it->first.c_str());
+    shape_out[0] = it->second.NW; shape_out[1] = it->second.WM; shape_out[2] = it->second.WN; shape_out[3] = it->second.tpw;
+    return FASTSVC_OK;
+}
+
+int fastsvc_tuned_set(const fastsvc_plan* plan, const char* key, const int32_t shape[4]) {
+    if (!plan || !key || !shape) return fail(FASTSVC_E_INVALID, "null argument");
+    if (std::strlen(key) >= 96) return fail(FASTSVC_E_INVALID, "key too long");
+    std::lock_guard<std::mutex> lock(plan->tune_mu);
+    plan->tuned[key] = fastsvc_plan::Choice{shape[0], shape[1], shape[2], shape[3]};
     return FASTSVC_OK;
 }
 

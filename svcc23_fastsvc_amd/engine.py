@@ -7,8 +7,9 @@ if the shared library is missing or the tensors are not on a GPU, this module ra
 from __future__ import annotations
 
 import ctypes
+import json
 import os
-from typing import Dict, Mapping, Optional, Tuple
+from typing import Dict, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -18,12 +19,16 @@ from .synth import GeneratorConfig
 _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfastsvc_hip.so")
 MAX_STAGES = 8
+# launch shapes measured once on an MI355X by tools/tune_shapes.py (fastsvc_autotune winners for
+# the BASELINE.json workloads); other (B, F) fall back to the static cost model or model.autotune
+TUNED_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_mi355x.json")
 
 # every symbol include/fastsvc_hip.h declares (checked by tests/test_boundary.py)
 ABI_SYMBOLS = (
     "fastsvc_abi_version", "fastsvc_last_error", "fastsvc_plan_create", "fastsvc_plan_destroy",
     "fastsvc_weight_blob_bytes", "fastsvc_pack_weights", "fastsvc_workspace_bytes",
-    "fastsvc_forward", "fastsvc_autotune", "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
+    "fastsvc_forward", "fastsvc_autotune", "fastsvc_tuned_count", "fastsvc_tuned_get", "fastsvc_tuned_set",
+    "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
     "fastsvc_flops_per_sample", "fastsvc_signal_scratch_bytes", "fastsvc_signal_generate",
 )
 
@@ -84,6 +89,12 @@ def load_library():
     lib.fastsvc_forward.restype = ctypes.c_int
     lib.fastsvc_autotune.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, ctypes.POINTER(i32)]
     lib.fastsvc_autotune.restype = ctypes.c_int
+    lib.fastsvc_tuned_count.argtypes = [vp]
+    lib.fastsvc_tuned_count.restype = ctypes.c_int
+    lib.fastsvc_tuned_get.argtypes = [vp, i32, ctypes.c_char_p, ctypes.POINTER(i32 * 4)]
+    lib.fastsvc_tuned_get.restype = ctypes.c_int
+    lib.fastsvc_tuned_set.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32 * 4)]
+    lib.fastsvc_tuned_set.restype = ctypes.c_int
     lib.fastsvc_forward_profile.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp,
                                             ctypes.POINTER(_LaunchRecord), i32, ctypes.POINTER(i32)]
     lib.fastsvc_forward_profile.restype = ctypes.c_int
@@ -116,7 +127,7 @@ def _check(lib, rc: int, what: str):
 class Plan:
     """Host-only plan (layer table + blob / workspace layout) for one generator configuration."""
 
-    def __init__(self, cfg: GeneratorConfig):
+    def __init__(self, cfg: GeneratorConfig, load_shipped_table: bool = True):
         self.cfg = cfg
         self.lib = load_library()
         if cfg.n_stages > MAX_STAGES or len(cfg.upsampling_scales) != cfg.n_stages:
@@ -133,6 +144,42 @@ class Plan:
         handle = ctypes.c_void_p()
         _check(self.lib, self.lib.fastsvc_plan_create(ctypes.byref(c), ctypes.byref(handle)), "fastsvc_plan_create")
         self._h = handle
+        self.last_autotune_trials = 0
+        if load_shipped_table:
+            self.load_tuned_file(TUNED_TABLE_PATH, missing_ok=True)
+
+    # ---- launch-shape table (fastsvc_autotune winners) ----
+    def config_signature(self) -> str:
+        c = self.cfg
+        return "in%d_mid%s_up%s_out%d_spk%d" % (c.in_channels, "-".join(map(str, c.mid_channels)),
+                                                "-".join(map(str, c.upsampling_scales)), c.out_channels,
+                                                c.spk_emb_size if c.use_spk_emb else 0)
+
+    def tuned_shapes(self) -> dict:
+        """{"<layer>|<B>|<T>": [NW, WM, WN, tiles_per_workgroup]} currently held by the plan."""
+        out = {}
+        key = ctypes.create_string_buffer(96)
+        shape = (ctypes.c_int32 * 4)()
+        for i in range(int(self.lib.fastsvc_tuned_count(self._h))):
+            _check(self.lib, self.lib.fastsvc_tuned_get(self._h, i, key, ctypes.byref(shape)), "fastsvc_tuned_get")
+            out[key.value.decode()] = [int(v) for v in shape]
+        return out
+
+    def load_tuned(self, table: Mapping[str, Sequence[int]]) -> int:
+        for k, v in table.items():
+            shape = (ctypes.c_int32 * 4)(*[int(x) for x in v])
+            _check(self.lib, self.lib.fastsvc_tuned_set(self._h, k.encode(), ctypes.byref(shape)), "fastsvc_tuned_set")
+        return len(table)
+
+    def load_tuned_file(self, path: str, missing_ok: bool = False) -> int:
+        """Load this configuration's section of a tuned-shape JSON file (tools/tune_shapes.py)."""
+        if not os.path.exists(path):
+            if missing_ok:
+                return 0
+            raise FileNotFoundError(path)
+        with open(path) as f:
+            doc = json.load(f)
+        return self.load_tuned(doc.get("tables", {}).get(self.config_signature(), {}))
 
     def __del__(self):
         h = getattr(self, "_h", None)

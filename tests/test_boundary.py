@@ -172,3 +172,24 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_launch_shape_table_roundtrip_and_shipped_file():
+    """fastsvc_tuned_set/get are host-only: entries round-trip in key order, replace on re-insert,
+    and the shipped MI355X table parses and only names shapes the pipelined kernel is built for."""
+    import json
+    from svcc23_fastsvc_amd.engine import TUNED_TABLE_PATH
+    plan = A.Plan(S.FULL_CONFIG, load_shipped_table=False)
+    assert plan.tuned_shapes() == {}
+    plan.load_tuned({"up.0.d3|8|1200": [1, 2, 2, 1], "film.2.heads|8|4800": [2, 2, 2, 1]})
+    plan.load_tuned({"up.0.d3|8|1200": [2, 2, 2, 3]})
+    assert plan.tuned_shapes() == {"film.2.heads|8|4800": [2, 2, 2, 1], "up.0.d3|8|1200": [2, 2, 2, 3]}
+    doc = json.load(open(TUNED_TABLE_PATH))
+    table = doc["tables"][plan.config_signature()]
+    assert len(table) > 40
+    for key, (nw, wm, wn, tpw) in table.items():
+        layer, b, t = key.split("|")
+        assert int(b) >= 1 and int(t) >= 1 and layer
+        assert nw in (1, 2, 4) and wm * wn == 4 and 1 <= tpw <= 16
+    shipped = A.Plan(S.FULL_CONFIG)
+    assert shipped.tuned_shapes() == {k: list(v) for k, v in table.items()}

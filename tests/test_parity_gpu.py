@@ -273,6 +273,26 @@ def test_polyphase_stretch_convs_taps_and_fallback(dev, F, expect_poly):
             assert float((got - want).abs().max()) <= TIGHT * max(1.0, float(want.abs().max())), (i, name)
 
 
+def test_stale_launch_shape_entries_are_ignored(dev):
+    """A table entry naming a tile shape the layer is not compiled for (or nonsense) must not break
+    the forward: run_conv falls back to the cost model for that launch."""
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 5)
+    b = S.synth_batch(cfg, 2, 40, 6)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    ref_plan = A.Plan(cfg, load_shipped_table=False)
+    blob = ref_plan.pack(sd).to(dev)
+    y0 = ref_plan.forward(blob, *ins).cpu()
+    plan = A.Plan(cfg, load_shipped_table=False)
+    T3 = 40 * 160
+    plan.load_tuned({f"up.3.d3|2|{T3}": [4, 4, 1, 2],          # WM=4 needs 4 channel groups: C=24 has one
+                     f"up.3.up_stretch|2|{T3 // 5}": [4, 1, 4, 1],   # polyphase is not built for NW=4
+                     f"film.2.heads|2|{40 * 8}": [3, 7, 9, 100],
+                     f"down.2.c2_d2|2|{40 * 8}": [2, 2, 2, 1]})      # a valid one
+    y1 = plan.forward(blob, *ins).cpu()
+    assert float((y0 - y1).abs().max()) <= 2e-5
+
+
 def test_signal_generator_matches_reference_sine(dev):
     """SignalGenerator on the GPU vs the reference's own output (golden, noise_amp=0):
     the reference accumulates the phase in fp32 (features.py:188-190), ours in f64 mod 1, so the

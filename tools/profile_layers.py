@@ -16,6 +16,8 @@ ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
 ws = torch.empty(plan.workspace_bytes(wl["B"], wl["F"]), dtype=torch.uint8, device=dev)
 for _ in range(2):
     plan.forward(blob, *ins, workspace=ws)
+if os.environ.get("FASTSVC_AUTOTUNE"):          # time every launch shape first, profile the tuned ones
+    plan.forward(blob, *ins, workspace=ws, autotune=True)
 N = 5
 acc = None
 for _ in range(N):

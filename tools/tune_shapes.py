@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Measure the launch-shape table on the GPU in front of us (run through gpurun on an MI355X):
+
+    python tools/tune_shapes.py [cfg1 cfg2 cfg3 ...] -> svcc23_fastsvc_amd/tuned_mi355x.json
+                                                      (also copied to gpurun_out/ so it comes back)
+
+For every workload it runs fastsvc_autotune (each pipelined conv times all its candidate tile shapes
+and tiles-per-workgroup on the device) REPS times and keeps, per layer, the shape that won most
+often.  Keys are "<layer>|<B>|<T>", so entries of different workloads do not collide."""
+import collections, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import svcc23_fastsvc_amd as A
+from svcc23_fastsvc_amd import synth as S
+from svcc23_fastsvc_amd.engine import TUNED_TABLE_PATH
+
+REPS = 3
+names = sys.argv[1:] or ["cfg1", "cfg2"]
+cfg = S.FULL_CONFIG
+dev = torch.device("cuda:0")
+votes = collections.defaultdict(collections.Counter)
+sig = None
+for name in names:
+    wl = S.WORKLOADS[name]
+    b = S.synth_batch(cfg, wl["B"], wl["F"], wl["seed"])
+    ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
+    for rep in range(REPS):
+        plan = A.Plan(cfg, load_shipped_table=False)
+        sig = plan.config_signature()
+        blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
+        ws = torch.empty(plan.workspace_bytes(wl["B"], wl["F"]), dtype=torch.uint8, device=dev)
+        plan.forward(blob, *ins, workspace=ws)
+        plan.forward(blob, *ins, workspace=ws, autotune=True)
+        for k, v in plan.tuned_shapes().items():
+            votes[k][tuple(v)] += 1
+        print(f"{name} rep {rep}: {plan.last_autotune_trials} trials", file=sys.stderr)
+table = {k: list(c.most_common(1)[0][0]) for k, c in sorted(votes.items())}
+doc = {"tables": {}}
+if os.path.exists(TUNED_TABLE_PATH):
+    doc = json.load(open(TUNED_TABLE_PATH))
+doc["device"] = torch.cuda.get_device_name(0)
+doc["format"] = "tables[config signature][layer|B|T] = [NW, WM, WN, tiles_per_workgroup]"
+doc["tables"].setdefault(sig, {}).update(table)
+with open(TUNED_TABLE_PATH, "w") as f:
+    json.dump(doc, f, indent=1, sort_keys=True)
+os.makedirs("gpurun_out", exist_ok=True)
+shutil.copy(TUNED_TABLE_PATH, "gpurun_out/tuned_mi355x.json")
+print(f"{len(table)} entries -> {TUNED_TABLE_PATH}")
