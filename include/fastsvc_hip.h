@@ -126,11 +126,12 @@ int fastsvc_autotune(const fastsvc_plan* plan, const void* dev_blob,
  * MI355X ships as svcc23_fastsvc_amd/tuned_mi355x.json, so production runs need no trial launches).
  * An entry whose shape is not compiled for that layer is ignored at launch time (cost model instead).
  *   fastsvc_tuned_count: number of entries;
- *   fastsvc_tuned_get:   entry `index` in key order; key_out holds >= 96 bytes; shape = NW, WM, WN, tpw;
+ *   fastsvc_tuned_get:   entry `index` in key order; key_out holds >= 96 bytes; shape = NW, WM, WN,
+ *                        tiles per workgroup, algorithm (0 = as launched, 1 = Winograd F(2,3) along time);
  *   fastsvc_tuned_set:   insert / replace one entry. */
 int fastsvc_tuned_count(const fastsvc_plan* plan);
-int fastsvc_tuned_get(const fastsvc_plan* plan, int32_t index, char* key_out, int32_t shape_out[4]);
-int fastsvc_tuned_set(const fastsvc_plan* plan, const char* key, const int32_t shape[4]);
+int fastsvc_tuned_get(const fastsvc_plan* plan, int32_t index, char* key_out, int32_t shape_out[5]);
+int fastsvc_tuned_set(const fastsvc_plan* plan, const char* key, const int32_t shape[5]);
 
 /* Per-launch timing of one forward (bench.py roofline accounting).  Same arguments as
  * fastsvc_forward; brackets every kernel launch with hipEvents on `stream`, synchronises the

@@ -18,7 +18,16 @@ enum : int {
     // i.e. three input-rate 1-tap products instead of three output-rate ones: s times fewer MACs.
     // Geometry: T (tiles, x_T) is the INPUT length, the output tensors have T * s columns; the
     // packed weights hold W0 | W0+W1+W2 | W2 in the three tap slots (fastsvc_plan.cpp packer).
-    MODE_POLY = 3
+    MODE_POLY = 3,
+    // k=3 conv with dilation d in {1,2,4} as Winograd F(2,3) along time: per output pair
+    // (t, t+d) and input channel, with d0..d3 = x[t-d], x[t], x[t+d], x[t+2d],
+    //     m0 = (d0-d2) g0, m1 = (d1+d2) g1, m2 = (d2-d1) g2, m3 = (d1-d3) g3,
+    //     y[t] = m0+m1+m2,  y[t+d] = m1-m2-m3,   g = w0 | (w0+w1+w2)/2 | (w0-w1+w2)/2 | w2
+    // four products per two outputs instead of six.  A 16-row MFMA tile holds 16 pairs = 32
+    // consecutive outputs (pair m = p*d + r  <->  t = 2d*p + r); the window is staged de-interleaved
+    // into 2d phase planes (x[t] -> plane t % 2d, position t / 2d) so every component is a
+    // unit-stride LDS read.  ps = plane stride in floats; packed weights hold the four g planes.
+    MODE_WINO = 4
 };
 
 enum : int {
@@ -75,6 +84,7 @@ struct ConvParams {
     int ntaps, dil, mode, s, flags;
     int B;                       // batch per signal; gridDim.z = nsig * B
     int xs;                      // LDS row stride in floats (== 16 mod 32, >= NT + 2*halo)
+    int ps;                      // MODE_WINO: phase-plane stride in floats inside an LDS row
     int vec;                     // 1: T % 4 == 0 and all row bases 16-byte aligned -> float4 epilogue
     int tpw;                     // pipelined kernel: consecutive time tiles walked by one workgroup
     int dbg;                     // ablation switches for profiling (FASTSVC_DBG env var); 0 in production

@@ -269,6 +269,61 @@ __device__ __forceinline__ void mfma_unit_poly(f32x4 (&acc)[3][NW][MW], const fl
     if (ws.next >= ws.total) ws.next = 0;
 }
 
+// Winograd F(2,3) unit (MODE_WINO).  Weight steps of a unit are packed HALF-major:
+// step = (half * 4 + component) * 3 + k-group-in-half, so the same stream feeds either a unit-deep
+// ring (RING = 24 slots) or a half-unit ring (RING = 12: the NW = 1 variant must fit 128 VGPRs next
+// to its four accumulator sets; a slot then flies for half a unit = 12 steps).
+// xr / xrd: this lane's LDS addresses of d1 = x[t] (plane r) and d2 = x[t+d] (plane r+d) for
+// k-group 0 of M-tile 0; d3 = x[t+2d] is the next entry of plane r, d0 = x[t-d] the previous entry
+// of plane r+d.  M-tile n starts 16 pairs = 16/D plane positions further on.
+template <int MW, int NW, int D, int RING>
+__device__ __forceinline__ void mfma_unit_wino(f32x4 (&acc)[4][NW][MW], const float* xr, const float* xrd, int XS,
+                                               UnitWeightStream<MW, RING>& ws) {
+    constexpr int TSTEP = 16 / D;
+    constexpr int STEP_BYTES = UnitWeightStream<MW, RING>::STEP_BYTES;
+    float av[2][4][NW];                                     // [ring][d0,d1,d2,d3][n]
+    auto fetch = [&](int slot, int j) {
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            av[slot][1][n] = xr[j * 4 * XS + n * TSTEP];
+            av[slot][3][n] = xr[j * 4 * XS + n * TSTEP + 1];
+            av[slot][2][n] = xrd[j * 4 * XS + n * TSTEP];
+            av[slot][0][n] = xrd[j * 4 * XS + n * TSTEP - 1];
+        }
+    };
+    fetch(0, 0);
+    #pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        #pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int j = 3 * h + jj;
+            if (j + 1 < 6) fetch((j + 1) & 1, j + 1);
+            #pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int slot = (RING == 24 ? h * 12 : 0) + c * 3 + jj;
+                #pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    const float d0 = av[j & 1][0][n], d1 = av[j & 1][1][n], d2 = av[j & 1][2][n], d3 = av[j & 1][3][n];
+                    const float a = c == 0 ? d0 - d2 : c == 1 ? d1 + d2 : c == 2 ? d2 - d1 : d1 - d3;
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m)
+                        acc[c][n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wfrag_get<MW>(ws.wr[slot], m), acc[c][n][m], 0, 0, 0);
+                }
+                ws.wr[slot] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + slot * STEP_BYTES);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (RING == 12) {                                   // next half-unit
+            ws.next += UnitWeightStream<MW, RING>::UNIT_BYTES;
+            if (ws.next >= ws.total) ws.next = 0;
+        }
+    }
+    if (RING == 24) {
+        ws.next += UnitWeightStream<MW, RING>::UNIT_BYTES;
+        if (ws.next >= ws.total) ws.next = 0;
+    }
+}
+
 // Epilogue of one time tile.  D layout (16x16x4 f32): lane holds column j = lane & 15 (output
 // channel) and rows i = (lane >> 4) * 4 + r (time), r = 0..3 -> four consecutive time steps per
 // lane.  s1/s2 accumulate the InstanceNorm partial sums across the tiles a workgroup walks.
@@ -725,6 +780,51 @@ __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiR
     }
 }
 
+// Winograd epilogue: a lane holds m0..m3 of FOUR consecutive pairs of one output channel = the 8
+// consecutive outputs starting at tcol0 + 32 n + 8 (lane >> 4).  The even/odd interleave depends on
+// the dilation: D=1 e0 o0 e1 o1 | e2 o2 e3 o3;  D=2 e0 e1 o0 o1 | e2 e3 o2 o3;  D=4 e0..e3 | o0..o3.
+template <int MW, int NW, int EPI, int D>
+__device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[4][NW][MW],
+                                                 int sig, int mg, int tcol0, bool active, int lane) {
+    if (!active) return;                                   // whole wave (uniform)
+    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
+    const float* biasp = p.bias + (long)sig * p.bias_sig;
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const bool cok = cot < p.COUT;
+        const int co = cok ? cot : 0;
+        const float bias = biasp[cot];                     // padded array: always in bounds
+        const int rowoff = co * p.T;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int t = tcol0 + n * 32 + (lane >> 4) * 8;
+            int off[2];
+            f32x4 l0[2];
+            #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                off[h] = (cok && t + 4 * h < p.T) ? (rowoff + t + 4 * h) * 4 : OOB_OFF;
+                if (EPI == EPI_RES) l0[h] = buf_load4(R.res, off[h], 0);
+            }
+            const f32x4 m1 = acc[1][n][m], m2 = acc[2][n][m];
+            const f32x4 e = acc[0][n][m] + m1 + m2 + bias;
+            const f32x4 o = m1 - m2 - acc[3][n][m] + bias;
+            f32x4 v[2];
+            if (D == 1) { v[0] = f32x4{e.x, o.x, e.y, o.y}; v[1] = f32x4{e.z, o.z, e.w, o.w}; }
+            else if (D == 2) { v[0] = f32x4{e.x, e.y, o.x, o.y}; v[1] = f32x4{e.z, e.w, o.z, o.w}; }
+            else { v[0] = e; v[1] = o; }
+            #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 w = v[h];
+                w.x = fmaxf(w.x, w.x * slope); w.y = fmaxf(w.y, w.y * slope);
+                w.z = fmaxf(w.z, w.z * slope); w.w = fmaxf(w.w, w.w * slope);
+                if (EPI == EPI_RES) w += l0[h];
+                buf_store4(R.y, off[h], w);
+            }
+        }
+    }
+}
+
 // Register budget: 128 VGPRs (two workgroups per CU) where that fits without spills, else 256.
 // Polyphase with MW == 3 carries three accumulator sets next to the 54-register weight ring and
 // a 2*S-load epilogue: 256 (those layers launch about one workgroup per CU anyway).
@@ -733,6 +833,7 @@ constexpr bool NTAPS_IS_3_DIRECT(int mode) { return mode == MODE_DIRECT; }
 template <int MW, int NW, int MODE, int EPI>
 constexpr int ws_min_waves() {
     if (MODE == MODE_POLY) return (MW <= 2 && NW == 1) ? 4 : 2;
+    if (MODE == MODE_WINO) return (MW == 2 && NW == 1) ? 4 : 2;   // four accumulator sets + a 24-slot weight ring
     if (MW <= 2 || NW == 1) return 4;
     if (NW == 2 && NTAPS_IS_3_DIRECT(MODE) && (EPI == EPI_PLAIN || EPI == EPI_RES)) return 4;
     return 2;
@@ -741,8 +842,9 @@ constexpr int ws_min_waves() {
 template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC, int S = 1>
 __global__ __launch_bounds__(512, (ws_min_waves<MW, NW, MODE, EPI>()))
 void conv_mfma_ws_kernel(const ConvParams p) {
-    constexpr int NSTEPS = 6 * NTAPS;
-    constexpr int NT = 16 * NW * WN;
+    constexpr bool WINO = (MODE == MODE_WINO);                         // S carries the dilation D
+    constexpr int NSTEPS = WINO ? 24 : 6 * NTAPS;                      // weight ring slots
+    constexpr int NT = (WINO ? 32 : 16) * NW * WN;                     // output columns per workgroup tile
     constexpr int NPROD = 256;                                         // producer threads
     constexpr int ITEMS = StageGeom<NT, NPROD>::ITEMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -877,7 +979,26 @@ void conv_mfma_ws_kernel(const ConvParams p) {
                         v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
                     }
                 }
-                *reinterpret_cast<f32x4*>(Xs + loff[i]) = v;
+                if constexpr (WINO) {
+                    // de-interleave into the 2*D phase planes: x[t] -> plane t % 2D, position t / 2D
+                    // (relative to tile start - 8; the window starts at tile start - 4)
+                    float* row = Xs + (rq[i] >> 16) * XS;
+                    const int u = (rq[i] & 0xffff) + 4;
+                    const int PS = p.ps;
+                    if (S == 1) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<f32x2*>(row + (u >> 1)) = f32x2{v.x, v.z};
+                        *reinterpret_cast<f32x2*>(row + PS + (u >> 1)) = f32x2{v.y, v.w};
+                    } else if (S == 2) {
+                        float* d = row + (u >> 2);
+                        d[0] = v.x; d[PS] = v.y; d[2 * PS] = v.z; d[3 * PS] = v.w;
+                    } else {
+                        float* d = row + (u & 7) * PS + (u >> 3);
+                        d[0] = v.x; d[PS] = v.y; d[2 * PS] = v.z; d[3 * PS] = v.w;
+                    }
+                } else {
+                    *reinterpret_cast<f32x4*>(Xs + loff[i]) = v;
+                }
             }
         };
 
@@ -906,13 +1027,19 @@ void conv_mfma_ws_kernel(const ConvParams p) {
     } else {
         // ================================ CONSUMER WAVES ================================
         constexpr bool POLY = (MODE == MODE_POLY);
-        f32x4 acc[POLY ? 1 : NW][MW];
+        f32x4 acc[(POLY || WINO) ? 1 : NW][MW];
         f32x4 acc3[3][POLY ? NW : 1][MW];              // polyphase: a / z / c accumulator sets
+        f32x4 acc4[4][WINO ? NW : 1][MW];              // Winograd: m0..m3
         float s1[MW], s2[MW];
         UnitWeightStream<MW, NSTEPS> wst;
         wst.init(p.w + (long)sig * p.w_sig + (long)(active ? mg : 0) * p.Q * 64 * MW,
                  (p.dbg & DBG_NO_WEIGHTS) ? NSTEPS : p.Q, lane);
         const int colbase = (lane >> 4) * XS + (lane & 15) + wave_n * (NW * 16) + (halo_al - halo);
+        // Winograd: pair index of this lane in M-tile 0 -> (plane position, residue) -> plane r / r+D
+        const int wpair = wave_n * (NW * 16) + (lane & 15);
+        const int wq = (lane >> 4) * XS + wpair / S + 4 / S;
+        const int colr = wq + (wpair % S) * p.ps;
+        const int colrd = wq + (wpair % S + S) * p.ps;
         EpiRsrc R;
         {
             const long ct = (long)p.COUT * p.T * (POLY ? S : 1);     // polyphase: outputs have T * S columns
@@ -928,7 +1055,14 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         __syncthreads();                               // unit 0 staged
         int u = 0;
         for (int tl = 0; tl < ntiles; ++tl) {
-            if constexpr (POLY) {
+            if constexpr (WINO) {
+                #pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    #pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        #pragma unroll
+                        for (int m = 0; m < MW; ++m) acc4[k][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if constexpr (POLY) {
                 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     #pragma unroll
@@ -943,13 +1077,17 @@ void conv_mfma_ws_kernel(const ConvParams p) {
             }
             for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
                 if (active && !(p.dbg & DBG_NO_MFMA)) {
-                    if constexpr (POLY) mfma_unit_poly<MW, NW>(acc3, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
+                    if constexpr (WINO) mfma_unit_wino<MW, NW, S, NSTEPS>(acc4, Xs0 + (u & 1) * bufsz + colr, Xs0 + (u & 1) * bufsz + colrd, XS, wst);
+                    else if constexpr (POLY) mfma_unit_poly<MW, NW>(acc3, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
                     else mfma_unit<MW, NW, NSTEPS>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
                 }
                 if (ch + 1 == p.nchunks) {
                     #pragma unroll
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
-                    if constexpr (POLY)
+                    if constexpr (WINO)
+                        ws_epilogue_wino<MW, NW, EPI, S>(p, R, acc4, sig, mg,
+                                                         (tile0 + tl) * NT + wave_n * (NW * 32), active, lane);
+                    else if constexpr (POLY)
                         ws_epilogue_poly<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg,
                                                          (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
                     else if constexpr (EPI == EPI_GENERIC)
@@ -1006,6 +1144,7 @@ constexpr bool poly_shape() { return WM != 4 && ((MW == 3 && NW == 1) || (MW == 
 int conv_ws_resident(int MW, int NW, int mode, int epi_kind) {
     // workgroups per CU the register budget of the compiled variant allows (see ws_min_waves)
     if (mode == MODE_POLY) return (MW <= 2 && NW == 1) ? 2 : 1;
+    if (mode == MODE_WINO) return (MW == 2 && NW == 1) ? 2 : 1;
     if (MW <= 2 || NW == 1) return 2;
     if (NW == 2 && mode == MODE_DIRECT && (epi_kind == EPI_PLAIN || epi_kind == EPI_RES)) return 2;
     return 1;
@@ -1017,7 +1156,7 @@ bool conv_poly_shape(int MW, int NW, int WM, int WN) {
 
 template <int MW, int NW, int WM, int WN>
 static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t stream) {
-    constexpr int NT = 16 * NW * WN;
+    const int NT = (p.mode == MODE_WINO ? 32 : 16) * NW * WN;
     const int ntx = (p.T + NT - 1) / NT;
     const int tpw = p.tpw > 0 ? p.tpw : 1;
     dim3 grid((ntx + tpw - 1) / tpw, (p.ngroups + WM - 1) / WM, nsig * p.B);
@@ -1027,6 +1166,23 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM
                       + sizeof(float) * (2 * (size_t)CINp + (size_t)nbuf * p.KC * p.xs);
     block = dim3(512);                                  // 4 consumer + 4 producer waves
+    if (p.mode == MODE_WINO) {
+        if constexpr ((MW == 3 && NW <= 2) || (MW == 2 && NW == 1)) {
+            const bool res = p.res != nullptr;
+#define FASTSVC_WINO(dv) \
+            if (p.dil == dv) { \
+                if (res) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RES, dv>), grid, block, smem, stream, p); \
+                else hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_PLAIN, dv>), grid, block, smem, stream, p); \
+                return hipGetLastError(); \
+            }
+            FASTSVC_WINO(1) FASTSVC_WINO(2) FASTSVC_WINO(4)
+#undef FASTSVC_WINO
+        }
+        return hipErrorInvalidValue;
+    }
+    if constexpr (MW == 2 && WM != 1) {
+        return hipErrorInvalidValue;                        // (2,1,2,2) / (2,1,4,1) exist for Winograd only
+    } else
     if (p.mode == MODE_POLY) {
         if constexpr (poly_shape<MW, NW, WM, WN>()) {
             const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
@@ -1074,6 +1230,9 @@ bool conv_pipe_supported(const ConvParams& p) {
     if (p.ntaps == 1) return p.mode == MODE_DECIMATE;          // the 1x1 residual convs of the down nets
     if (p.ntaps != 3) return false;
     if (p.mode == MODE_DIRECT) return (p.x_T % 4) == 0;
+    if (p.mode == MODE_WINO)                                   // F(2,3) along time: plain / residual epilogue only
+        return (p.x_T % 4) == 0 && p.T == p.x_T && (p.dil == 1 || p.dil == 2 || p.dil == 4) && !p.r1x &&
+               !(p.flags & (F_STATS | F_AFF_OUT)) && p.ps > 0;
     if (p.mode == MODE_POLY)                                   // input-rate tiles, float4 window loads
         return (p.x_T % 4) == 0 && p.T == p.x_T && p.dil == 1 && (p.s == 2 || p.s == 4 || p.s == 5) &&
                !p.res && !p.r1x && !(p.flags & F_PRE_NORM);
@@ -1085,6 +1244,7 @@ hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t s
 #define FASTSVC_PIPE(mw, nw, wm, wn) \
         if (cfg.MW == mw && cfg.NW == nw && cfg.WM == wm && cfg.WN == wn) return launch_conv_pipe<mw, nw, wm, wn>(p, cfg.nsig, stream);
         FASTSVC_PIPE(2, 4, 1, 4) FASTSVC_PIPE(2, 2, 1, 4) FASTSVC_PIPE(2, 1, 1, 4)
+        FASTSVC_PIPE(2, 1, 2, 2) FASTSVC_PIPE(2, 1, 4, 1)
         FASTSVC_PIPE(3, 4, 1, 4) FASTSVC_PIPE(3, 2, 1, 4) FASTSVC_PIPE(3, 1, 1, 4)
         FASTSVC_PIPE(3, 4, 2, 2) FASTSVC_PIPE(3, 2, 2, 2) FASTSVC_PIPE(3, 1, 2, 2)
         FASTSVC_PIPE(3, 4, 4, 1) FASTSVC_PIPE(3, 2, 4, 1)

@@ -45,6 +45,17 @@ struct PackedConv {
     // fragment layout and size as the plain weights
     bool poly = false;
     size_t wp_off = 0;
+    // k=3, d in {1,2,4}, 48 | C_out layers also carry the Winograd F(2,3) weights
+    // g = w0 | (w0+w1+w2)/2 | (w0-w1+w2)/2 | w2 (MODE_WINO): 4 "taps", Qw = 4 * nchunks * 6 k-steps
+    bool wino = false;
+    size_t ww_off = 0;
+    long ww_pair = 0;                 // lft -> sine stride of the Winograd weights (paired convs)
+    int Qw = 0;
+    // the same with 32-channel groups (MW = 2; 32 | C_out): four accumulator sets + the weight
+    // ring then fit 128 VGPRs, i.e. two workgroups per CU
+    bool wino2 = false;
+    size_t ww2_off = 0;
+    long ww2_pair = 0;
 };
 
 // Source description used by the packer: virtual weight W[co][ci][tap] assembled from up to four
@@ -99,7 +110,7 @@ struct fastsvc_plan {
     std::vector<RawParam*> raw_jobs;
     double flops_per_sample = 0.0;
     // autotuned launch choices (fastsvc_autotune), keyed by "layer|B|T"; guarded by tune_mu
-    struct Choice { int NW, WM, WN, tpw; };
+    struct Choice { int NW, WM, WN, tpw, algo; };    // algo: 0 direct / as launched, 1 Winograd F(2,3)
     mutable std::mutex tune_mu;
     mutable std::map<std::string, Choice> tuned;
 
@@ -127,6 +138,21 @@ struct fastsvc_plan {
         for (int i = 0; i < npair; ++i) plan_conv(c[i], cin, cout, ntaps, dil);
         for (int i = 0; i < npair; ++i) c[i].w_off = alloc(c[i].w_floats);
         for (int i = 0; i < npair; ++i) c[i].b_off = alloc(c[i].b_floats);
+        for (int i = 0; i < npair; ++i) {
+            if (ntaps == 3 && (dil == 1 || dil == 2 || dil == 4) && c[i].KC == 24 && c[i].MW == 3) c[i].wino = true;
+        }
+        for (int i = 0; i < npair; ++i)
+            if (c[i].wino) {
+                c[i].Qw = 4 * c[i].nchunks * 6;
+                c[i].ww_off = alloc((size_t)c[i].ngroups * c[i].Qw * 64 * c[i].MW);
+            }
+        if (npair == 2 && c[0].wino) c[0].ww_pair = (long)(c[1].ww_off - c[0].ww_off);
+        for (int i = 0; i < npair; ++i)
+            if (c[i].wino && cout % 32 == 0) {
+                c[i].wino2 = true;
+                c[i].ww2_off = alloc((size_t)(cout / 32) * c[i].Qw * 64 * 2);
+            }
+        if (npair == 2 && c[0].wino2) c[0].ww2_pair = (long)(c[1].ww2_off - c[0].ww2_off);
         for (int i = 0; i < npair; ++i) pack_jobs.emplace_back(&c[i], src[i]);
     }
 
@@ -331,25 +357,59 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         }
         // fragment order: [group][q][lane][m],  q = (chunk * ntaps + tap) * (KC/4) + g
         //   value = W[co = (group*MW + m)*16 + (lane & 15)][ci = chunk*KC + 4g + (lane >> 4)][tap]
-        auto pack_fragments = [&](const std::vector<float>& Wt, float* wp) {
+        auto pack_fragments = [&](const std::vector<float>& Wt, float* wp, int ntaps) {
             const int kg = c.KC / 4;
+            const int Q = ntaps * c.nchunks * kg;
             for (int grp = 0; grp < c.ngroups; ++grp)
                 for (int ch = 0; ch < c.nchunks; ++ch)
-                    for (int tap = 0; tap < c.ntaps; ++tap)
+                    for (int tap = 0; tap < ntaps; ++tap)
                         for (int g = 0; g < kg; ++g) {
-                            const int q = (ch * c.ntaps + tap) * kg + g;
+                            const int q = (ch * ntaps + tap) * kg + g;
                             for (int lane = 0; lane < 64; ++lane) {
                                 const int ci = ch * c.KC + 4 * g + (lane >> 4);
                                 for (int m = 0; m < c.MW; ++m) {
                                     const int co = (grp * c.MW + m) * 16 + (lane & 15);
                                     float v = 0.f;
-                                    if (co < c.cout && ci < c.cin) v = Wt[((size_t)co * c.cin + ci) * c.ntaps + tap];
-                                    wp[(((size_t)grp * c.Q + q) * 64 + lane) * c.MW + m] = v;
+                                    if (co < c.cout && ci < c.cin) v = Wt[((size_t)co * c.cin + ci) * ntaps + tap];
+                                    wp[(((size_t)grp * Q + q) * 64 + lane) * c.MW + m] = v;
                                 }
                             }
                         }
         };
-        pack_fragments(W, blob + c.w_off);
+        pack_fragments(W, blob + c.w_off, c.ntaps);
+        if (c.wino) {
+            // Winograd F(2,3) weight transform G w (fastsvc_kernels.h, MODE_WINO), in f64
+            std::vector<float> Ww((size_t)c.cout * c.cin * 4);
+            for (size_t i = 0; i < (size_t)c.cout * c.cin; ++i) {
+                const double w0 = W[3 * i], w1 = W[3 * i + 1], w2 = W[3 * i + 2];
+                Ww[4 * i] = (float)w0;
+                Ww[4 * i + 1] = (float)(0.5 * (w0 + w1 + w2));
+                Ww[4 * i + 2] = (float)(0.5 * (w0 - w1 + w2));
+                Ww[4 * i + 3] = (float)w2;
+            }
+            // step order inside a chunk: (half * 4 + component) * 3 + k-group-in-half (mfma_unit_wino)
+            auto pack_wino = [&](float* wp, int MWp) {
+                const int ngrp = (c.cout + 16 * MWp - 1) / (16 * MWp);
+                for (int grp = 0; grp < ngrp; ++grp)
+                    for (int ch = 0; ch < c.nchunks; ++ch)
+                        for (int h = 0; h < 2; ++h)
+                            for (int comp = 0; comp < 4; ++comp)
+                                for (int jj = 0; jj < 3; ++jj) {
+                                    const int q = ch * 24 + (h * 4 + comp) * 3 + jj;
+                                    for (int lane = 0; lane < 64; ++lane) {
+                                        const int ci = ch * c.KC + 4 * (3 * h + jj) + (lane >> 4);
+                                        for (int m = 0; m < MWp; ++m) {
+                                            const int co = (grp * MWp + m) * 16 + (lane & 15);
+                                            float v = 0.f;
+                                            if (co < c.cout && ci < c.cin) v = Ww[((size_t)co * c.cin + ci) * 4 + comp];
+                                            wp[(((size_t)grp * c.Qw + q) * 64 + lane) * MWp + m] = v;
+                                        }
+                                    }
+                                }
+            };
+            pack_wino(blob + c.ww_off, c.MW);
+            if (c.wino2) pack_wino(blob + c.ww2_off, 2);
+        }
         if (c.poly) {
             // polyphase taps (fastsvc_kernels.h, MODE_POLY): slot 0 = W0, slot 1 = W0+W1+W2, slot 2 = W2
             std::vector<float> Wp(W.size());
@@ -358,7 +418,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                 Wp[i + 1] = (float)((double)W[i] + (double)W[i + 1] + (double)W[i + 2]);
                 Wp[i + 2] = W[i + 2];
             }
-            pack_fragments(Wp, blob + c.wp_off);
+            pack_fragments(Wp, blob + c.wp_off, c.ntaps);
         }
         float* bp = blob + c.b_off;
         for (int co = 0; co < c.cout; ++co) bp[co] = bias[co];
@@ -557,7 +617,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
             epi_kind = aff ? 4 : ((p.mode == MODE_STRETCH || poly) ? 1 : p.r1x ? 3 : p.res ? 2 : 1);
         }
-        struct Cand { int NW, WM, WN; };
+        struct Cand { int NW, WM, WN, algo; };       // algo 0: as launched, 1: Winograd (MW of the layer), 2: Winograd MW = 2
         std::vector<Cand> cands;
         if (poly) {
             if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{1, 2, 2}, {1, 1, 4}};
@@ -567,13 +627,44 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         else if (c.MW == 3 && c.ngroups % 4 == 0) cands = {{4, 4, 1}, {2, 4, 1}, {4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         else if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         else cands = {{4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
-        auto xs_for = [&](int NW, int WN) {
-            const int W = 16 * NW * WN + 2 * ((halo + 3) & ~3);
-            return (W + 15) / 32 * 32 + 16;
+        // Winograd F(2,3) variants of the same launch (fastsvc_kernels.h, MODE_WINO)
+        static const int wino_env = std::getenv("FASTSVC_WINO") ? std::atoi(std::getenv("FASTSVC_WINO")) : -1;
+        const bool wino_ok = c.wino && wino_env != 0 && p.mode == MODE_DIRECT && p.x_T % 4 == 0 && !p.r1x &&
+                             !(p.flags & (F_STATS | F_AFF_OUT | F_PRE_AFFINE));
+        if (wino_ok) {
+            const size_t nd = cands.size();
+            for (size_t i = 0; i < nd; ++i)
+                if (cands[i].NW <= 2) cands.push_back(Cand{cands[i].NW, cands[i].WM, cands[i].WN, 1});
+            if (c.wino2) {
+                const int ng2 = c.cout / 32;
+                cands.push_back(Cand{1, 1, 4, 2});
+                if (ng2 % 2 == 0) cands.push_back(Cand{1, 2, 2, 2});
+                if (ng2 % 4 == 0) cands.push_back(Cand{1, 4, 1, 2});
+            }
+        }
+        auto round_to = [](int v, int rem, int mod) { int r = v / mod * mod + rem; return r < v ? r + mod : r; };
+        // LDS geometry of a candidate: row stride (== 16 mod 32) and, for Winograd, the phase-plane
+        // stride that keeps the component reads conflict-free (planes land 16/D banks apart)
+        auto geometry = [&](const Cand& cd, ConvParams& q) {
+            if (cd.algo >= 1) {
+                const int NTo = 32 * cd.NW * cd.WN, D = c.dil;
+                const int Q = (NTo + 16) / (2 * D);
+                const int ps = D == 1 ? (Q + 1) / 2 * 2 : D == 2 ? round_to(Q, 8, 32) : round_to(Q, 12, 32);
+                q.ps = ps;
+                q.xs = round_to(2 * D * ps, 16, 32);
+                q.mode = MODE_WINO; q.Q = c.Qw;
+                if (cd.algo == 2) { q.w = blob + c.ww2_off; q.w_sig = c.ww2_pair; q.ngroups = c.cout / 32; }
+                else { q.w = blob + c.ww_off; q.w_sig = c.ww_pair; }
+            } else {
+                const int W = 16 * cd.NW * cd.WN + 2 * ((halo + 3) & ~3);
+                q.xs = (W + 15) / 32 * 32 + 16;
+                q.ps = 0;
+            }
         };
         char key[96];
         std::snprintf(key, sizeof(key), "%s|%d|%d", layer, p.B, p.T);
         bool have = false;
+        Cand best = cands[0];
         if (g_tune.plan) {
             std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
             auto it = g_tune.plan->tuned.find(key);
@@ -581,8 +672,8 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 // a loaded table may be stale: only shapes this launch is compiled for are taken
                 for (const Cand& cd : cands)
                     if (cd.NW == it->second.NW && cd.WM == it->second.WM && cd.WN == it->second.WN &&
-                        it->second.tpw >= 1 && it->second.tpw <= 64) {
-                        L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; p.tpw = it->second.tpw;
+                        cd.algo == it->second.algo && it->second.tpw >= 1 && it->second.tpw <= 64) {
+                        best = cd; p.tpw = it->second.tpw;
                         have = true;
                     }
             }
@@ -597,11 +688,13 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             ConvParams q = p;
             q.flags &= ~F_STATS;
             for (const Cand& cd : cands) {
-                const int NT = 16 * cd.NW * cd.WN;
+                const int NT = (cd.algo >= 1 ? 32 : 16) * cd.NW * cd.WN;
                 const long ntx = (p.T + NT - 1) / NT;
+                q = p; q.flags &= ~F_STATS;
+                geometry(cd, q);
                 for (int tpw : tpws) {
-                    q.tpw = tpw; q.xs = xs_for(cd.NW, cd.WN);
-                    ConvLaunch Lq{c.MW, cd.NW, cd.WM, cd.WN, nsig, 1};
+                    q.tpw = tpw;
+                    ConvLaunch Lq{cd.algo == 2 ? 2 : c.MW, cd.NW, cd.WM, cd.WN, nsig, 1};
                     hipError_t e = launch_conv(q, Lq, stream);            // warm
                     if (e != hipSuccess) return e;
                     hipEventRecord(e0, stream);
@@ -611,13 +704,13 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                     float ms = 0.f;
                     hipEventElapsedTime(&ms, e0, e1);
                     ++g_tune.trials;
-                    if (ms < best_ms) { best_ms = ms; L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; p.tpw = tpw; }
+                    if (ms < best_ms) { best_ms = ms; best = cd; p.tpw = tpw; }
                     if (tpw >= ntx) break;                                // larger tpw changes nothing
                 }
             }
             hipEventDestroy(e0); hipEventDestroy(e1);
             std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
-            g_tune.plan->tuned[key] = fastsvc_plan::Choice{L.NW, L.WM, L.WN, p.tpw};
+            g_tune.plan->tuned[key] = fastsvc_plan::Choice{best.NW, best.WM, best.WN, p.tpw, best.algo};
             have = true;
         }
         if (!have) {
@@ -628,20 +721,23 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         static const double startup_us = std::getenv("FASTSVC_STARTUP_US") ? std::atof(std::getenv("FASTSVC_STARTUP_US")) : 4.0;
         double best_t = 1e30;
         for (const Cand& cd : cands) {
-            const int NT = 16 * cd.NW * cd.WN;
+            if ((cd.algo >= 1) != (wino_ok && wino_env >= 1)) continue;      // Winograd only on request (or by table / tuner)
+            if (wino_env >= 1 && wino_ok && c.wino2 && (cd.algo == 2) != (wino_env == 2)) continue;   // FASTSVC_WINO=2: the MW = 2 variants
+            const int NT = (cd.algo >= 1 ? 32 : 16) * cd.NW * cd.WN;
+            const int cMW = cd.algo == 2 ? 2 : c.MW;
             const long ntx = (p.T + NT - 1) / NT;
-            const long gy = (c.ngroups + cd.WM - 1) / cd.WM;
-            const int resident = conv_ws_resident(c.MW, cd.NW, p.mode, epi_kind);   // VGPR budget, see the kernel
+            const long gy = ((cd.algo == 2 ? c.cout / 32 : c.ngroups) + cd.WM - 1) / cd.WM;
+            const int resident = conv_ws_resident(cMW, cd.NW, cd.algo >= 1 ? (int)MODE_WINO : p.mode, epi_kind);   // VGPR budget, see the kernel
             const long slots = 256L * resident;
             // unit time: MFMA stream of one consumer wave vs bytes the 256 producer threads move
-            const double mfma_us = 6.0 * c.ntaps * cd.NW * c.MW * 32.0 / 2.2e3;
+            const double mfma_us = 6.0 * (cd.algo >= 1 ? 4 : c.ntaps) * cd.NW * cMW * 32.0 / 2.2e3;
             const double win = NT + 2.0 * ((halo + 3) & ~3);
-            const double bytes_unit = c.KC * win * 4.0 + (double)16 * c.MW * cd.WM * NT * (poly ? p.s : 1) * 4.0 *
+            const double bytes_unit = c.KC * win * 4.0 + (double)16 * cMW * cd.WM * NT * (poly ? p.s : 1) * 4.0 *
                                       ((p.y ? 1 : 0) + ((p.flags & F_AFF_OUT) ? 3 : 0) + (p.res ? 1 : 0)) / c.nchunks;
             const double mem_us = bytes_unit / (5.0e6 / 256.0 / resident);    // ~5 TB/s shared by all slots
             // packed weights streamed from L2 by the four consumer waves (per unit, per workgroup):
             // ~16 TB/s of L2 shared by all resident workgroups; this is what punishes small NW
-            const double wbytes_unit = 4.0 * 6.0 * c.ntaps * 64.0 * c.MW * 4.0;
+            const double wbytes_unit = 4.0 * 6.0 * c.ntaps * 64.0 * cMW * 4.0;
             const double l2_us = wbytes_unit / (16.0e6 / 256.0 / resident);
             double unit_us = mfma_us > mem_us ? mfma_us : mem_us;
             if (l2_us > unit_us) unit_us = l2_us;
@@ -650,20 +746,20 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 const long wgs = ((ntx + tpw - 1) / tpw) * gy * zb;
                 const long rounds = (wgs + slots - 1) / slots;
                 const double t = rounds * (startup_us + tpw * c.nchunks * unit_us);
-                if (t < best_t * 0.999) { best_t = t; L.NW = cd.NW; L.WM = cd.WM; L.WN = cd.WN; p.tpw = tpw; }
+                if (t < best_t * 0.999) { best_t = t; best = cd; p.tpw = tpw; }
             }
         }
         }
         L.pipe = 1;
+        L.NW = best.NW; L.WM = best.WM; L.WN = best.WN;
+        if (best.algo == 2) L.MW = 2;
+        geometry(best, p);
         {
             static const bool verbose = std::getenv("FASTSVC_VERBOSE_SHAPES") != nullptr;   // tuning aid
             if (verbose && prof)
                 std::fprintf(stderr, "[fastsvc] %-20s mode %d  MW %d NW %d WM %d WN %d tpw %d\n", layer, p.mode,
                              L.MW, L.NW, L.WM, L.WN, p.tpw);
         }
-        const int NT = 16 * L.NW * L.WN;
-        const int W = NT + 2 * ((halo + 3) & ~3);
-        p.xs = (W + 15) / 32 * 32 + 16;
     } else {
         int NW = 4;
         while (NW > 1 && ((p.T + 64 * NW - 1) / (64 * NW)) * zb * c.ngroups < 768) NW >>= 1;
@@ -691,7 +787,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         {
             // same rule as launch_conv_pipe: compile-time epilogue kind of the 3-tap DIRECT / STRETCH launches
             int kind = 0;
-            if (c.ntaps == 3 && (p.mode == MODE_DIRECT || p.mode == MODE_STRETCH || poly)) {
+            if (c.ntaps == 3 && (p.mode == MODE_DIRECT || p.mode == MODE_STRETCH || poly || p.mode == MODE_WINO)) {
                 const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
                 kind = aff ? 4 : ((p.mode == MODE_STRETCH || poly) ? 1 : p.r1x ? 3 : p.res ? 2 : 1);
             }
@@ -763,8 +859,16 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     g_tune.plan = plan;
     // per-launch profiling and autotuning run on ONE stream so that every kernel is timed alone
     ExecCtx* ctx = (serial || g_tune.tuning || prof) ? nullptr : exec_ctx_for_current_device();
-    hipStream_t s_film = ctx ? ctx->aux[0] : stream;      // FiLM nets of stages 0..n-2
-    hipStream_t s_side = ctx ? ctx->aux[1] : stream;      // 1x1 / stretch residual convs
+    // FASTSVC_STREAMS: bit 0 = residual-conv helper stream, bit 1 = FiLM helper stream (experiments)
+    // Measured with tuned launch shapes: the FiLM stream pays from ~10^5 samples per call (cfg2 -2 %),
+    // below that the fork/join events cost more than the overlap (cfg1 +4 %); the residual-conv
+    // stream costs 2-15 % everywhere (two extra fork/joins per stage) and is off by default.
+    static const int streams_env = std::getenv("FASTSVC_STREAMS") ? std::atoi(std::getenv("FASTSVC_STREAMS")) : -1;
+    int64_t hop_all = 1;
+    for (int i = 0; i < plan->n; ++i) hop_all *= plan->cfg.upsampling_scales[i];
+    const int streams_mask = streams_env >= 0 ? streams_env : ((int64_t)B * F * hop_all >= 150000 ? 2 : 0);
+    hipStream_t s_film = (ctx && (streams_mask & 2)) ? ctx->aux[0] : stream;      // FiLM nets of stages 0..n-2
+    hipStream_t s_side = (ctx && (streams_mask & 1)) ? ctx->aux[1] : stream;      // 1x1 / stretch residual convs
     int evi = 0;
     // `to` waits for everything enqueued on `from` so far
     auto order_after = [&](hipStream_t from, hipStream_t to) -> hipError_t {
@@ -982,7 +1086,7 @@ int fastsvc_tuned_count(const fastsvc_plan* plan) {
     return (int)plan->tuned.size();
 }
 
-int fastsvc_tuned_get(const fastsvc_plan* plan, int32_t index, char* key_out, int32_t shape_out[4]) {
+int fastsvc_tuned_get(const fastsvc_plan* plan, int32_t index, char* key_out, int32_t shape_out[5]) {
     if (!plan || !key_out || !shape_out) return fail(FASTSVC_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lock(plan->tune_mu);
     if (index < 0 || index >= (int32_t)plan->tuned.size()) return fail(FASTSVC_E_INVALID, "index out of range");
@@ -990,14 +1094,15 @@ int fastsvc_tuned_get(const fastsvc_plan* plan, int32_t index, char* key_out, in
     std::advance(it, index);
     std::snprintf(key_out, 96, "%s", it->first.c_str());
     shape_out[0] = it->second.NW; shape_out[1] = it->second.WM; shape_out[2] = it->second.WN; shape_out[3] = it->second.tpw;
+    shape_out[4] = it->second.algo;
     return FASTSVC_OK;
 }
 
-int fastsvc_tuned_set(const fastsvc_plan* plan, const char* key, const int32_t shape[4]) {
+int fastsvc_tuned_set(const fastsvc_plan* plan, const char* key, const int32_t shape[5]) {
     if (!plan || !key || !shape) return fail(FASTSVC_E_INVALID, "null argument");
     if (std::strlen(key) >= 96) return fail(FASTSVC_E_INVALID, "key too long");
     std::lock_guard<std::mutex> lock(plan->tune_mu);
-    plan->tuned[key] = fastsvc_plan::Choice{shape[0], shape[1], shape[2], shape[3]};
+    plan->tuned[key] = fastsvc_plan::Choice{shape[0], shape[1], shape[2], shape[3], shape[4]};
     return FASTSVC_OK;
 }
 

@@ -91,9 +91,9 @@ def load_library():
     lib.fastsvc_autotune.restype = ctypes.c_int
     lib.fastsvc_tuned_count.argtypes = [vp]
     lib.fastsvc_tuned_count.restype = ctypes.c_int
-    lib.fastsvc_tuned_get.argtypes = [vp, i32, ctypes.c_char_p, ctypes.POINTER(i32 * 4)]
+    lib.fastsvc_tuned_get.argtypes = [vp, i32, ctypes.c_char_p, ctypes.POINTER(i32 * 5)]
     lib.fastsvc_tuned_get.restype = ctypes.c_int
-    lib.fastsvc_tuned_set.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32 * 4)]
+    lib.fastsvc_tuned_set.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32 * 5)]
     lib.fastsvc_tuned_set.restype = ctypes.c_int
     lib.fastsvc_forward_profile.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp,
                                             ctypes.POINTER(_LaunchRecord), i32, ctypes.POINTER(i32)]
@@ -156,10 +156,10 @@ class Plan:
                                                 c.spk_emb_size if c.use_spk_emb else 0)
 
     def tuned_shapes(self) -> dict:
-        """{"<layer>|<B>|<T>": [NW, WM, WN, tiles_per_workgroup]} currently held by the plan."""
+        """{"<layer>|<B>|<T>": [NW, WM, WN, tiles_per_workgroup, algorithm]} currently held by the plan."""
         out = {}
         key = ctypes.create_string_buffer(96)
-        shape = (ctypes.c_int32 * 4)()
+        shape = (ctypes.c_int32 * 5)()
         for i in range(int(self.lib.fastsvc_tuned_count(self._h))):
             _check(self.lib, self.lib.fastsvc_tuned_get(self._h, i, key, ctypes.byref(shape)), "fastsvc_tuned_get")
             out[key.value.decode()] = [int(v) for v in shape]
@@ -167,7 +167,8 @@ class Plan:
 
     def load_tuned(self, table: Mapping[str, Sequence[int]]) -> int:
         for k, v in table.items():
-            shape = (ctypes.c_int32 * 4)(*[int(x) for x in v])
+            v = list(v) + [0] * (5 - len(v))                  # older 4-entry tables: algorithm 0
+            shape = (ctypes.c_int32 * 5)(*[int(x) for x in v])
             _check(self.lib, self.lib.fastsvc_tuned_set(self._h, k.encode(), ctypes.byref(shape)), "fastsvc_tuned_set")
         return len(table)
 

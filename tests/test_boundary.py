@@ -182,14 +182,14 @@ def test_launch_shape_table_roundtrip_and_shipped_file():
     plan = A.Plan(S.FULL_CONFIG, load_shipped_table=False)
     assert plan.tuned_shapes() == {}
     plan.load_tuned({"up.0.d3|8|1200": [1, 2, 2, 1], "film.2.heads|8|4800": [2, 2, 2, 1]})
-    plan.load_tuned({"up.0.d3|8|1200": [2, 2, 2, 3]})
-    assert plan.tuned_shapes() == {"film.2.heads|8|4800": [2, 2, 2, 1], "up.0.d3|8|1200": [2, 2, 2, 3]}
+    plan.load_tuned({"up.0.d3|8|1200": [2, 2, 2, 3, 1]})           # 5th entry: algorithm (0 when absent)
+    assert plan.tuned_shapes() == {"film.2.heads|8|4800": [2, 2, 2, 1, 0], "up.0.d3|8|1200": [2, 2, 2, 3, 1]}
     doc = json.load(open(TUNED_TABLE_PATH))
     table = doc["tables"][plan.config_signature()]
     assert len(table) > 40
-    for key, (nw, wm, wn, tpw) in table.items():
+    for key, (nw, wm, wn, tpw, algo) in table.items():
         layer, b, t = key.split("|")
         assert int(b) >= 1 and int(t) >= 1 and layer
-        assert nw in (1, 2, 4) and wm * wn == 4 and 1 <= tpw <= 16
+        assert nw in (1, 2, 4) and wm * wn == 4 and 1 <= tpw <= 16 and algo in (0, 1, 2)
     shipped = A.Plan(S.FULL_CONFIG)
     assert shipped.tuned_shapes() == {k: list(v) for k, v in table.items()}

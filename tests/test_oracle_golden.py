@@ -176,3 +176,30 @@ def test_polyphase_identity_of_stretched_conv(s):
     out[..., s - 1::s] += c
     out += bias[None, :, None]
     assert float((out - ref).abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("d", [1, 2, 4])
+def test_winograd_f23_identity_of_dilated_conv(d):
+    """The algebra of the MODE_WINO kernel, against stock torch ops: for output pairs (t, t+d) of a
+    k=3 conv with dilation d, m0 = (d0-d2) g0, m1 = (d1+d2) g1, m2 = (d2-d1) g2, m3 = (d1-d3) g3 with
+    g = w0 | (w0+w1+w2)/2 | (w0-w1+w2)/2 | w2 give y[t] = m0+m1+m2 and y[t+d] = m1-m2-m3; pairs tile
+    the axis as t = 2d*p + r (r < d), zero padding outside [0, T)."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(200 + d)
+    C, T = 5, 8 * d * 3
+    x = torch.randn(2, C, T, generator=g, dtype=torch.float64)
+    w = torch.randn(C, C, 3, generator=g, dtype=torch.float64)
+    ref = F.conv1d(x, w, None, padding=d, dilation=d)
+    xp = F.pad(x, (d, 2 * d))                       # xp[t + d] = x[t]
+    t_e = torch.tensor([2 * d * p + r for p in range(T // (2 * d)) for r in range(d)])
+    d0, d1, d2, d3 = (xp[..., t_e + k * d] for k in range(4))
+    mm = lambda wk, v: torch.einsum("oc,bct->bot", wk, v)
+    m0 = mm(w[..., 0], d0 - d2)
+    m1 = mm(w.sum(-1) / 2, d1 + d2)
+    m2 = mm((w[..., 0] - w[..., 1] + w[..., 2]) / 2, d2 - d1)
+    m3 = mm(w[..., 2], d1 - d3)
+    out = torch.zeros_like(ref)
+    out[..., t_e] = m0 + m1 + m2
+    out[..., t_e + d] = m1 - m2 - m3
+    assert float((out - ref).abs().max()) < 1e-12

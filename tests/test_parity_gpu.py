@@ -293,6 +293,59 @@ def test_stale_launch_shape_entries_are_ignored(dev):
     assert float((y0 - y1).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("algo", [1, 2])
+def test_winograd_time_convs_match_oracle_taps(dev, algo):
+    """The d in {1,2,4} k=3 convs of the wide layers can run as Winograd F(2,3) along time (kernel
+    mode 4; algo 1 = 48-channel groups, algo 2 = 32-channel groups).  Force it on every eligible
+    launch through the launch-shape table and check the taps those layers produce (down-chain
+    outputs, FiLM scale/shift, conv_first) and the waveform against the oracle."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 51)
+    B, F = 2, 44                                   # T_k = 88 .. 7040: partial tiles at every rate
+    b = S.synth_batch(cfg, B, F, 52)
+    plan = A.Plan(cfg, load_shipped_table=False)
+    blob = plan.pack(sd).to(dev)
+    rates = {0: 160 * F, 1: 32 * F, 2: 8 * F, 3: 2 * F}
+    table = {}
+    for k in (1, 2, 3):                            # stage 0 has C = 24: not eligible
+        for layer in ("c2_d2", "c3_d4"):
+            table[f"down.{k}.{layer}|{B}|{rates[k]}"] = [1, 1, 4, 1, algo]
+        table[f"film.{k}.conv|{B}|{rates[k]}"] = [1, 1, 4, 2, algo]
+        table[f"film.{k}.heads|{B}|{rates[k]}"] = [1, 1, 4, 1, algo]
+    table[f"film.0.heads|{B}|{rates[0]}"] = [2 if algo == 1 else 1, 1, 4, 3, algo]
+    for i, t_in in enumerate((F, 2 * F, 8 * F)):
+        table[f"up.{i}.conv_first|{B}|{t_in}"] = [1, 1, 4, 1, algo]
+    plan.load_tuned(table)
+    ws = torch.zeros(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    recs = []
+    y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), workspace=ws, profile=recs)
+    torch.cuda.synchronize()
+    kern = {r["layer"]: r["kernel"] for r in recs}
+    n_wino = sum(1 for k in kern.values() if k.startswith("conv_mfma_ws<") and k.split(",")[4] == "4")
+    # eligible: down.k c2/c3 and film.k conv/heads for k = 1..3, film.0.heads, conv_first of blocks
+    # 0..2 = 16 launches; the 48-channel ones (stage 1, film.0.heads, up.2.conv_first) have no
+    # 32-channel grouping, which leaves 11 for algo 2 (those entries are ignored -> cost model)
+    assert n_wino == (16 if algo == 1 else 11), sorted(kern.items())
+    ref, taps = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft,
+                                b.spk_emb, return_taps=True)
+    assert float((y.cpu() - ref).abs().max()) <= TIGHT
+
+    def close(got, want, what):
+        assert float((got.cpu() - want).abs().max()) <= TIGHT * max(1.0, float(want.abs().max())), what
+
+    for k in range(cfg.n_stages):
+        h = plan.tap(f"down_h.{k}", B, F, ws)
+        close(h[:B], taps[f"down_lft.{k}"], f"down_lft.{k}")
+        close(h[B:], taps[f"down_sine.{k}"], f"down_sine.{k}")
+        ss = plan.tap(f"ss.{k}", B, F, ws)
+        C = ss.shape[1] // 2
+        close(ss[:, :C], taps[f"scale.{k}"], f"scale.{k}")
+        close(ss[:, C:], taps[f"shift.{k}"], f"shift.{k}")
+    for i in range(cfg.n_stages):
+        close(plan.tap(f"up.{i}.a", B, F, ws), taps[f"up.{i}.a"], f"up.{i}.a")
+
+
 def test_signal_generator_matches_reference_sine(dev):
     """SignalGenerator on the GPU vs the reference's own output (golden, noise_amp=0):
     the reference accumulates the phase in fp32 (features.py:188-190), ours in f64 mod 1, so the
