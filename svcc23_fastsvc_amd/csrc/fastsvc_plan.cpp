@@ -668,6 +668,21 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (g_tune.plan) {
             std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
             auto it = g_tune.plan->tuned.find(key);
+            const bool exact = it != g_tune.plan->tuned.end();
+            if (!exact && !g_tune.tuning) {
+                // no entry for this (B, T): take the layer's entry measured at the nearest problem size
+                // (total columns, log scale) - the shapes are generic, only their ranking is size-bound
+                const std::string prefix = std::string(layer) + "|";
+                const double want = std::log((double)p.B * (double)p.T);
+                double best_d = 1e30;
+                for (auto jt = g_tune.plan->tuned.lower_bound(prefix);
+                     jt != g_tune.plan->tuned.end() && jt->first.compare(0, prefix.size(), prefix) == 0; ++jt) {
+                    int kb = 0, kt = 0;
+                    if (std::sscanf(jt->first.c_str() + prefix.size(), "%d|%d", &kb, &kt) != 2 || kb < 1 || kt < 1) continue;
+                    const double d = std::fabs(std::log((double)kb * (double)kt) - want);
+                    if (d < best_d) { best_d = d; it = jt; }
+                }
+            }
             if (it != g_tune.plan->tuned.end()) {
                 // a loaded table may be stale: only shapes this launch is compiled for are taken
                 for (const Cand& cd : cands)
@@ -676,6 +691,15 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                         best = cd; p.tpw = it->second.tpw;
                         have = true;
                     }
+                if (have && !exact) {
+                    // tiles-per-workgroup measured at another size: keep at least two rounds of workgroups
+                    const int NT = (best.algo >= 1 ? 32 : 16) * best.NW * best.WN;
+                    const long ntx = (p.T + NT - 1) / NT;
+                    const int cMW = best.algo == 2 ? 2 : c.MW;
+                    const long gy = ((best.algo == 2 ? c.cout / 32 : c.ngroups) + best.WM - 1) / best.WM;
+                    const long slots = 256L * conv_ws_resident(cMW, best.NW, best.algo >= 1 ? (int)MODE_WINO : p.mode, epi_kind);
+                    while (p.tpw > 1 && ((ntx + p.tpw - 1) / p.tpw) * gy * zb < 2 * slots) --p.tpw;
+                }
             }
         }
         if (!have && g_tune.tuning && g_tune.plan) {
