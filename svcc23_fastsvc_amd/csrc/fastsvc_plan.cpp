@@ -815,8 +815,9 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
                 kind = aff ? 4 : ((p.mode == MODE_STRETCH || poly) ? 1 : p.r1x ? 3 : p.res ? 2 : 1);
             }
-            std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN,
-                          p.mode, c.ntaps, kind);
+            // the template arguments of the instance that runs (last one: polyphase stretch / Winograd dilation)
+            std::snprintf(kname, sizeof(kname), "conv_mfma_ws<%d,%d,%d,%d,%d,%d,%d,%d>", L.MW, L.NW, L.WM, L.WN,
+                          p.mode, c.ntaps, kind, poly ? p.s : p.mode == MODE_WINO ? c.dil : 1);
         }
         else
             std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d,1,4>", L.MW, L.NW);

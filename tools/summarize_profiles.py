@@ -30,7 +30,7 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
 write = per_kernel(os.path.join(src, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE")
-rows, js, merged = [], {}, {}
+rows, js = [], {}
 for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     if "fastsvc" not in k:
         continue
@@ -38,14 +38,11 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     w_kib = write[k][0] / write[k][1] if k in write else 0.0
     hbm = (2.0 * f_kib + w_kib) * 1024.0
     rows.append((k, fetch[k][1], f_kib, w_kib, hbm))
-    # template arguments: MW, NW, WM, WN, mode, ntaps, epilogue kind[, polyphase stretch S]; bench.py
-    # names kernels by the first seven, so the S variants of one polyphase shape are averaged by launches
-    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>", k)
+    # template arguments: MW, NW, WM, WN, mode, ntaps, epilogue kind, S (polyphase stretch / Winograd
+    # dilation, else 1) - bench.py names the kernels by the same eight numbers
+    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", k)
     if m:
-        name = "conv_mfma_ws<%s,%s,%s,%s,%s,%s,%s>" % m.groups()
-        tot = merged.setdefault(name, [0.0, 0])
-        tot[0] += hbm * fetch[k][1]; tot[1] += fetch[k][1]
-        js[name] = tot[0] / tot[1]
+        js["conv_mfma_ws<%s,%s,%s,%s,%s,%s,%s,%s>" % m.groups()] = hbm
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
     if m:
         js["conv_mfma<%s,%s,%s,%s>" % m.groups()] = hbm
