@@ -100,13 +100,15 @@ struct ConvLaunch {
     int pipe;    // 1: pipelined float4 kernel, 0: generic scalar-staging kernel (WM=1, WN=4)
 };
 
-// the pipelined kernel needs T % 4 == 0, DIRECT (x_T % 4 == 0) or STRETCH (no affine) indexing
+// the pipelined kernel needs 24-channel K chunks and no fused input affine; any row length
 bool conv_pipe_supported(const ConvParams& p);
 // tile shapes the polyphase (MODE_POLY) variant of the pipelined kernel is compiled for
 bool conv_poly_shape(int MW, int NW, int WM, int WN);
 // workgroups per CU allowed by the register budget of the pipelined variant (epilogue kind:
 // 0 generic, 1 plain, 2 residual, 3 rank-1 residual, 4 FiLM-affine)
 int conv_ws_resident(int MW, int NW, int mode, int epi_kind);
+// whether that variant handles rows that are not a multiple of 4 long (S: polyphase stretch, else 1)
+bool conv_ws_tail_ok(int MW, int NW, int mode, int epi_kind, int S);
 
 // generic k in {1,3} dilated conv, MFMA f32 16x16x4
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);

@@ -25,6 +25,9 @@ namespace fastsvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// compile-time epilogue kinds of the pipelined kernel (see ws_epilogue_kind)
+enum : int { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RES = 2, EPI_RANK1 = 3, EPI_AFF = 4 };
+
 __device__ __forceinline__ float lrelu(float v) { return v >= 0.f ? v : LRELU_SLOPE * v; }
 
 __device__ __forceinline__ int div_small(int t, int s) {
@@ -596,6 +599,45 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
 }
+// Rows need not be a multiple of 4 long (T_k = 2F, F for odd frame counts): every float4 access is
+// only dword-aligned then, and the float4 that straddles the end of a row is handled by element:
+// nv = number of its elements that belong to the row (4 everywhere else, 0 for lanes off the tile).
+__device__ __forceinline__ void buf_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
+    if (nv >= 4) {
+        buf_store4(r, voff, v);
+    } else {
+        // element stores with the offset pushed out of range for the elements past the row end
+        // (dropped by the descriptor); no per-element branches
+        const float e0 = v[0], e1 = v[1], e2 = v[2];
+        const int far = 0x7ffffff0;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e0), r, nv >= 1 ? voff : far, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e1), r, nv >= 2 ? voff + 4 : far, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e2), r, nv >= 3 ? voff + 8 : far, 0, 0);
+    }
+}
+__device__ __forceinline__ f32x4 keep_first(f32x4 v, int nv) {      // zero the elements past the row end
+    if (nv < 4) v.w = 0.f;
+    if (nv < 3) v.z = 0.f;
+    if (nv < 2) v.y = 0.f;
+    if (nv < 1) v.x = 0.f;
+    return v;
+}
+__device__ __forceinline__ int row_valid(int t, int T) { return min(4, max(0, T - t)); }
+// The variants that sit at the 128-VGPR limit are compiled WITHOUT the row-end handling (they are the
+// full-rate shapes, whose rows are 160 F long); run_conv only launches them when T % 4 == 0.
+template <bool TAIL>
+__device__ __forceinline__ void store_row4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
+    if constexpr (TAIL) buf_store4_n(r, voff, v, nv); else buf_store4(r, voff, v);
+}
+template <bool TAIL>
+__device__ __forceinline__ f32x4 keep_row(f32x4 v, int nv) {
+    if constexpr (TAIL) return keep_first(v, nv); else return v;
+}
+template <int MW, int NW, int MODE, int EPI, int S>
+constexpr bool ws_tail_ok() {
+    if (MODE == MODE_POLY) return !(MW == 2 && S == 5 && EPI == EPI_AFF);
+    return !(MW == 2 && NW == 4);
+}
 
 // Tile epilogue of the wave-specialised kernel (T % 4 == 0).  Every tensor is addressed through a
 // buffer descriptor (wave-uniform base in SGPRs) plus ONE 32-bit byte offset per (channel, time)
@@ -633,6 +675,8 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 16 + (lane >> 4) * 4;
             if (t >= p.T) continue;
+            constexpr bool TAIL = ws_tail_ok<MW, NW, MODE_DIRECT, EPI_GENERIC, 1>();
+            const int nv = TAIL ? row_valid(t, p.T) : 4;
             const int off = (rowoff + t) * 4;
             f32x4 v = acc[n][m];
             v += bias;
@@ -641,10 +685,10 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
             }
             if (p.res) v += buf_load4(R.res, off, 0);
             if (p.r1x) v += buf_load4(R.r1x, t * 4, 0) * r1w + r1b;
-            if (p.y) buf_store4(R.y, off, v);
+            if (p.y) store_row4<TAIL>(R.y, off, v, nv);
             if (flags & (F_STATS | F_AFF_OUT)) {
-                const f32x4 u = buf_load4(R.ss, off, 0) * v + buf_load4(R.ss, off, shift_soff);
-                if (flags & F_AFF_OUT) buf_store4(R.y2, off, u);
+                const f32x4 u = keep_row<TAIL>(buf_load4(R.ss, off, 0) * v + buf_load4(R.ss, off, shift_soff), nv);
+                if (flags & F_AFF_OUT) store_row4<TAIL>(R.y2, off, u, nv);
                 s1[m] += (u.x + u.y) + (u.z + u.w);
                 s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
             }
@@ -657,7 +701,6 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
 // after each load: ~3 serialised memory latencies per item, 8 items per tile.  Here the kind is a
 // template parameter, the code is straight-line, out-of-range lanes use an offset beyond every
 // descriptor (loads return 0, stores are dropped) and the loads of G items are issued together.
-enum : int { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RES = 2, EPI_RANK1 = 3, EPI_AFF = 4 };
 constexpr int OOB_OFF = 0x7ffffff0;
 
 template <int MW, int NW, int EPI>
@@ -670,6 +713,7 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
     const float* biasp = p.bias + (long)sig * p.bias_sig;                  // padded to the channel tiles
     const int shift_soff = p.COUT * p.T * 4;
     constexpr int G = (EPI == EPI_AFF) ? (NW == 2 ? 2 : 1) : NW;           // items whose loads fly together (register budget)
+    constexpr bool TAIL = ws_tail_ok<MW, NW, MODE_DIRECT, EPI, 1>();
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int cot = (mg * MW + m) * 16 + (lane & 15);
@@ -681,12 +725,13 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
         const int rowoff = co * p.T;
         #pragma unroll
         for (int n0 = 0; n0 < NW; n0 += G) {
-            int off[G];
+            int off[G], nv[G];
             f32x4 l0[G], l1[G], l2[G];
             #pragma unroll
             for (int g = 0; g < G; ++g) {                  // every load of the group first
                 const int t = tcol0 + (n0 + g) * 16 + (lane >> 4) * 4;
                 const bool ok = cok && t < p.T;
+                nv[g] = TAIL ? (ok ? row_valid(t, p.T) : 0) : 4;
                 off[g] = ok ? (rowoff + t) * 4 : OOB_OFF;
                 if (EPI == EPI_RES) l0[g] = buf_load4(R.res, off[g], 0);
                 if (EPI == EPI_RANK1) l0[g] = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
@@ -704,10 +749,10 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
                 v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
                 if (EPI == EPI_RES || EPI == EPI_AFF) v += l0[g];
                 if (EPI == EPI_RANK1) v += l0[g] * r1w + r1b;
-                buf_store4(R.y, off[g], v);                           // dropped when y is absent
+                store_row4<TAIL>(R.y, off[g], v, nv[g]);              // dropped when y is absent
                 if (EPI == EPI_AFF) {
-                    const f32x4 u = l1[g] * v + l2[g];
-                    buf_store4(R.y2, off[g], u);
+                    const f32x4 u = keep_row<TAIL>(l1[g] * v + l2[g], nv[g]);
+                    store_row4<TAIL>(R.y2, off[g], u, nv[g]);
                     s1[m] += (u.x + u.y) + (u.z + u.w);
                     s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
                 }
@@ -740,6 +785,8 @@ __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiR
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 16 + (lane >> 4) * 4;            // input-rate column
             const bool ok = cok && t < p.T;
+            constexpr bool TAIL = ws_tail_ok<MW, NW, MODE_POLY, EPI, S>();
+            const int nvo = TAIL ? (ok ? row_valid(t, p.T) * S : 0) : 4 * S;   // valid output samples of this lane
             const int off0 = ok ? (rowoff + t * S) * 4 : OOB_OFF;
             // first / last phase of each input column (bias folded in); the middle phases are z + bias
             const f32x4 zz = acc[1][n][m] + bias;
@@ -767,10 +814,11 @@ __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiR
                         f32x4 v = f32x4{phase_value(4 * q), phase_value(4 * q + 1), phase_value(4 * q + 2), phase_value(4 * q + 3)};
                         v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
                         v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
-                        buf_store4(R.y, off0 + q * 16, v);             // dropped when y is absent
+                        const int nv = min(4, max(0, nvo - 4 * q));
+                        store_row4<TAIL>(R.y, off0 + q * 16, v, nv);   // dropped when y is absent
                         if (EPI == EPI_AFF) {
-                            const f32x4 u = l1[g] * v + l2[g];
-                            buf_store4(R.y2, off0 + q * 16, u);
+                            const f32x4 u = keep_row<TAIL>(l1[g] * v + l2[g], nv);
+                            store_row4<TAIL>(R.y2, off0 + q * 16, u, nv);
                             s1[m] += (u.x + u.y) + (u.z + u.w);
                             s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
                         }
@@ -799,10 +847,11 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 32 + (lane >> 4) * 8;
-            int off[2];
+            int off[2], nv[2];
             f32x4 l0[2];
             #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                nv[h] = cok ? row_valid(t + 4 * h, p.T) : 0;
                 off[h] = (cok && t + 4 * h < p.T) ? (rowoff + t + 4 * h) * 4 : OOB_OFF;
                 if (EPI == EPI_RES) l0[h] = buf_load4(R.res, off[h], 0);
             }
@@ -819,7 +868,7 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
                 w.x = fmaxf(w.x, w.x * slope); w.y = fmaxf(w.y, w.y * slope);
                 w.z = fmaxf(w.z, w.z * slope); w.w = fmaxf(w.w, w.w * slope);
                 if (EPI == EPI_RES) w += l0[h];
-                buf_store4(R.y, off[h], w);
+                buf_store4_n(R.y, off[h], w, nv[h]);
             }
         }
     }
@@ -965,12 +1014,15 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         auto pcommit = [&](int un, const f32x4 (&px)[ITEMS], unsigned okmask, float* Xs) {
             if (p.dbg & DBG_NO_COMMIT) return;
             const int ch = un % p.nchunks;
+            const int t_start = (tile0 + un / p.nchunks) * NT - halo_al;
+            const bool tailmode = (p.T & 3) != 0;              // rows are not a multiple of 4 long
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 if (loff[i] < 0) continue;
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};          // zero "same" padding / channel padding
                 if (okmask & (1u << i)) {
                     v = px[i];
+
                     if (flags & F_PRE_NORM) {
                         const float2 ab = ncoef[ch * p.KC + (rq[i] >> 16)];
                         v = v * ab.x + ab.y;
@@ -978,6 +1030,9 @@ void conv_mfma_ws_kernel(const ConvParams p) {
                     if (flags & F_PRE_LRELU) {
                         v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
                     }
+                    // the float4 that straddles the row end also holds the head of the next row: the
+                    // conv's zero padding starts there (after the prologue transforms, like every pad)
+                    if (tailmode) v = keep_first(v, p.T - (t_start + (rq[i] & 0xffff)));
                 }
                 if constexpr (WINO) {
                     // de-interleave into the 2*D phase planes: x[t] -> plane t % 2D, position t / 2D
@@ -1150,6 +1205,12 @@ int conv_ws_resident(int MW, int NW, int mode, int epi_kind) {
     return 1;
 }
 
+bool conv_ws_tail_ok(int MW, int NW, int mode, int epi_kind, int S) {
+    // variants compiled with the row-end (T % 4 != 0) handling, see ws_tail_ok
+    if (mode == MODE_POLY) return !(MW == 2 && S == 5 && epi_kind == EPI_AFF);
+    return !(MW == 2 && NW == 4);
+}
+
 bool conv_poly_shape(int MW, int NW, int WM, int WN) {
     return WM != 4 && ((MW == 3 && NW == 1) || (MW == 2 && NW <= 2)) && WM * WN == 4;
 }
@@ -1225,16 +1286,16 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
 }
 
 bool conv_pipe_supported(const ConvParams& p) {
-    if (!p.vec || p.KC != 24) return false;                    // 6 k-steps per tap per chunk, compiled in
+    if (p.KC != 24) return false;                              // 6 k-steps per tap per chunk, compiled in
     if (p.flags & F_PRE_AFFINE) return false;                  // only the generic kernel fuses the affine
     if (p.ntaps == 1) return p.mode == MODE_DECIMATE;          // the 1x1 residual convs of the down nets
     if (p.ntaps != 3) return false;
-    if (p.mode == MODE_DIRECT) return (p.x_T % 4) == 0;
+    if (p.mode == MODE_DIRECT) return true;                    // any row length (element masks at the row end)
     if (p.mode == MODE_WINO)                                   // F(2,3) along time: plain / residual epilogue only
-        return (p.x_T % 4) == 0 && p.T == p.x_T && (p.dil == 1 || p.dil == 2 || p.dil == 4) && !p.r1x &&
+        return p.T == p.x_T && (p.dil == 1 || p.dil == 2 || p.dil == 4) && !p.r1x &&
                !(p.flags & (F_STATS | F_AFF_OUT)) && p.ps > 0;
     if (p.mode == MODE_POLY)                                   // input-rate tiles, float4 window loads
-        return (p.x_T % 4) == 0 && p.T == p.x_T && p.dil == 1 && (p.s == 2 || p.s == 4 || p.s == 5) &&
+        return p.T == p.x_T && p.dil == 1 && (p.s == 2 || p.s == 4 || p.s == 5) &&
                !p.res && !p.r1x && !(p.flags & F_PRE_NORM);
     return p.mode == MODE_STRETCH || p.mode == MODE_DECIMATE;
 }

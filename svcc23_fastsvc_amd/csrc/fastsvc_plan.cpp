@@ -586,12 +586,14 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
     p.w = blob + c.w_off; p.w_sig = pair_w_stride;
     static const bool no_poly = std::getenv("FASTSVC_NO_POLY") != nullptr;   // A/B switch
     const long T_out = p.T;                                  // output columns (accounting below)
-    if (p.mode == MODE_STRETCH && c.poly && !no_poly && c.dil == 1 && p.x_T % 4 == 0 && (long)p.x_T * p.s == p.T) {
+    if (p.mode == MODE_STRETCH && c.poly && !no_poly && c.dil == 1 && (long)p.x_T * p.s == p.T) {
         // Stretch2d + conv at the INPUT rate (polyphase): tiles walk the input columns
         ConvParams q = p;
         q.mode = MODE_POLY; q.T = p.x_T; q.w = blob + c.wp_off;
         q.Q = c.Q; q.ngroups = c.ngroups; q.COUT = c.cout; q.ntaps = c.ntaps; q.dil = c.dil; q.vec = 1;
-        if (conv_pipe_supported(q)) { p.mode = MODE_POLY; p.T = p.x_T; p.w = q.w; }
+        const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+        const bool tail_fine = (p.x_T % 4) == 0 || conv_ws_tail_ok(c.MW, 1, MODE_POLY, aff ? 4 : 1, p.s);
+        if (conv_pipe_supported(q) && tail_fine) { p.mode = MODE_POLY; p.T = p.x_T; p.w = q.w; }
     }
     const bool poly = p.mode == MODE_POLY;
     p.bias = blob + c.b_off; p.bias_sig = pair_b_stride;
@@ -629,7 +631,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         else cands = {{4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         // Winograd F(2,3) variants of the same launch (fastsvc_kernels.h, MODE_WINO)
         static const int wino_env = std::getenv("FASTSVC_WINO") ? std::atoi(std::getenv("FASTSVC_WINO")) : -1;
-        const bool wino_ok = c.wino && wino_env != 0 && p.mode == MODE_DIRECT && p.x_T % 4 == 0 && !p.r1x &&
+        const bool wino_ok = c.wino && wino_env != 0 && p.mode == MODE_DIRECT && !p.r1x &&
                              !(p.flags & (F_STATS | F_AFF_OUT | F_PRE_AFFINE));
         if (wino_ok) {
             const size_t nd = cands.size();
@@ -641,6 +643,14 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 if (ng2 % 2 == 0) cands.push_back(Cand{1, 2, 2, 2});
                 if (ng2 % 4 == 0) cands.push_back(Cand{1, 4, 1, 2});
             }
+        }
+        if ((p.T & 3) != 0) {
+            // rows that are not a multiple of 4 long: only the variants compiled with the row-end handling
+            std::vector<Cand> keep;
+            for (const Cand& cd : cands)
+                if (conv_ws_tail_ok(cd.algo == 2 ? 2 : c.MW, cd.NW, cd.algo >= 1 ? (int)MODE_WINO : p.mode, epi_kind,
+                                    poly ? p.s : 1)) keep.push_back(cd);
+            if (!keep.empty()) cands.swap(keep);       // (never empty: NW <= 2 variants always have it)
         }
         auto round_to = [](int v, int rem, int mod) { int r = v / mod * mod + rem; return r < v ? r + mod : r; };
         // LDS geometry of a candidate: row stride (== 16 mod 32) and, for Winograd, the phase-plane

@@ -161,6 +161,39 @@ def test_ragged_sizes_vs_oracle(dev, B, F, spk):
     assert float((y - ref).abs().max()) <= TIGHT * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("F", [41, 42, 43])
+def test_frame_counts_not_multiple_of_four_stay_on_the_fast_path(dev, F):
+    """T_k = F, 2F are then not float4-aligned: the pipelined kernels treat the float4 that
+    straddles a row end by element (masked staging, element stores, masked InstanceNorm sums) instead
+    of falling back to the scalar kernel.  Every tap must match the oracle and no conv may be
+    launched on the generic kernel."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 61)
+    B = 3
+    b = S.synth_batch(cfg, B, F, 62)
+    plan = A.Plan(cfg)
+    blob = plan.pack(sd).to(dev)
+    ws = torch.zeros(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    recs = []
+    y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), workspace=ws, profile=recs)
+    torch.cuda.synchronize()
+    assert not [r["layer"] for r in recs if r["kernel"].startswith("conv_mfma<")]
+    ref, taps = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft,
+                                b.spk_emb, return_taps=True)
+    assert float((y.cpu() - ref).abs().max()) <= TIGHT
+    for k in range(cfg.n_stages):
+        h = plan.tap(f"down_h.{k}", B, F, ws).cpu()
+        for sig, sl in (("lft", slice(0, B)), ("sine", slice(B, 2 * B))):
+            want = taps[f"down_{sig}.{k}"]
+            assert float((h[sl] - want).abs().max()) <= TIGHT * max(1.0, float(want.abs().max()))
+    for i in range(cfg.n_stages):
+        for name in ("a", "xr", "u1", "xmid", "u2", "u3", "out"):
+            got = plan.tap(f"up.{i}.{name}", B, F, ws).cpu()
+            want = taps[f"up.{i}.{name}"]
+            assert float((got - want).abs().max()) <= TIGHT * max(1.0, float(want.abs().max())), (i, name)
+
+
 def test_batch_items_do_not_bleed(dev):
     """Zero padding is per utterance: item b of a batch == the same utterance run alone
     (InstanceNorm statistics and conv halos never cross batch items)."""
@@ -240,13 +273,14 @@ def test_autotuned_launch_shapes_keep_parity(dev):
     assert float((y0 - y2).abs().max()) <= 2e-5
 
 
-@pytest.mark.parametrize("F,expect_poly", [(40, (True, True, True, True)), (42, (False, True, True, True)),
-                                           (41, (False, False, True, True))])
+@pytest.mark.parametrize("F,expect_poly", [(40, (True, True, True, True)), (42, (True, True, True, True)),
+                                           (41, (True, True, True, True))])
 def test_polyphase_stretch_convs_taps_and_fallback(dev, F, expect_poly):
     """Stretch2d + conv (upsample.py:21-50 + fastsvc.py:57-62,72-75) runs at the INPUT rate
-    (kernel mode 3, s-times fewer MACs) whenever the block's input length is a multiple of 4 and
-    falls back to the gathered 3-tap kernel (mode 2) otherwise; both must reproduce the oracle's
-    xr (stretched residual conv) and u1 (FiLM-affined up conv) taps of every block."""
+    (kernel mode 3, s-times fewer MACs), also when the block's input length is not a multiple of 4
+    (row-end handling by element); the gathered 3-tap kernel (mode 2) remains for the configurations
+    the polyphase variant is not built for.  Must reproduce the oracle's xr (stretched residual
+    conv) and u1 (FiLM-affined up conv) taps of every block."""
     O = _oracle()
     cfg = S.FULL_CONFIG
     sd = S.synth_state_dict(cfg, 41)
