@@ -27,7 +27,12 @@ enum : int {
     // consecutive outputs (pair m = p*d + r  <->  t = 2d*p + r); the window is staged de-interleaved
     // into 2d phase planes (x[t] -> plane t % 2d, position t / 2d) so every component is a
     // unit-stride LDS read.  ps = plane stride in floats; packed weights hold the four g planes.
-    MODE_WINO = 4
+    MODE_WINO = 4,
+    // First two convs of a down-sampling stage in ONE launch (fastsvc.py:164-173): both read the
+    // decimated input h[..., ::s];  y = Conv3_d1(lrelu(hd)) + bias  and  y2 = Conv1x1(hd) + bias2.
+    // The window is staged raw, the consumer applies LeakyReLU to the three tap operands and feeds a
+    // second accumulator set with the raw centre column; 4 weight "taps" per k-group (w0 w1 w2 | w1x1).
+    MODE_DEC2 = 5
 };
 
 enum : int {
@@ -61,8 +66,10 @@ struct ConvParams {
     float* y;
     long y_sig, y_b;
     int T, COUT;
-    float* y2;                   // (B, COUT, T): scale_out * y + shift_out  (F_AFF_OUT)
-    long y2_b;
+    float* y2;                   // (B, COUT, T): scale_out * y + shift_out  (F_AFF_OUT); MODE_DEC2: the 1x1 output
+    long y2_b, y2_sig;
+    const float* bias2;          // MODE_DEC2: bias of the 1x1 conv
+    long bias2_sig;
     // optional residual, same geometry as y
     const float* res;
     long res_sig, res_b;

@@ -327,6 +327,46 @@ __device__ __forceinline__ void mfma_unit_wino(f32x4 (&acc)[4][NW][MW], const fl
     }
 }
 
+// MODE_DEC2 unit: acc[0] += lrelu(x[t-1]) w0 + lrelu(x[t]) w1 + lrelu(x[t+1]) w2,  acc[1] += x[t] w1x1.
+// Weight steps are packed half-major like the Winograd ones (component 3 = the 1x1 weights).
+template <int MW, int NW>
+__device__ __forceinline__ void mfma_unit_dec2(f32x4 (&acc)[2][NW][MW], const float* xa0, int XS,
+                                               UnitWeightStream<MW, 24>& ws) {
+    constexpr int STEP_BYTES = UnitWeightStream<MW, 24>::STEP_BYTES;
+    float av[2][3][NW];
+    auto fetch = [&](int slot, int j) {
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            #pragma unroll
+            for (int n = 0; n < NW; ++n) av[slot][tap][n] = xa0[tap + j * 4 * XS + n * 16];
+    };
+    fetch(0, 0);
+    #pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        #pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int j = 3 * h + jj;
+            if (j + 1 < 6) fetch((j + 1) & 1, j + 1);
+            #pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int slot = h * 12 + c * 3 + jj;
+                #pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    const float raw = av[j & 1][c == 3 ? 1 : c][n];
+                    const float a = c == 3 ? raw : fmaxf(raw, raw * LRELU_SLOPE);
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m)
+                        acc[c == 3][n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wfrag_get<MW>(ws.wr[slot], m), acc[c == 3][n][m], 0, 0, 0);
+                }
+                ws.wr[slot] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + slot * STEP_BYTES);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    ws.next += UnitWeightStream<MW, 24>::UNIT_BYTES;
+    if (ws.next >= ws.total) ws.next = 0;
+}
+
 // Epilogue of one time tile.  D layout (16x16x4 f32): lane holds column j = lane & 15 (output
 // channel) and rows i = (lane >> 4) * 4 + r (time), r = 0..3 -> four consecutive time steps per
 // lane.  s1/s2 accumulate the InstanceNorm partial sums across the tiles a workgroup walks.
@@ -635,7 +675,7 @@ __device__ __forceinline__ f32x4 keep_row(f32x4 v, int nv) {
 }
 template <int MW, int NW, int MODE, int EPI, int S>
 constexpr bool ws_tail_ok() {
-    if (MODE == MODE_POLY) return !(MW == 2 && S == 5 && EPI == EPI_AFF);
+    if (MODE == MODE_POLY) return !(MW == 2 && S >= 4 && EPI == EPI_AFF);
     return !(MW == 2 && NW == 4);
 }
 
@@ -843,6 +883,8 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
         const bool cok = cot < p.COUT;
         const int co = cok ? cot : 0;
         const float bias = biasp[cot];                     // padded array: always in bounds
+        float r1w = 0.f, r1b = 0.f;
+        if (EPI == EPI_RANK1) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
         const int rowoff = co * p.T;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
@@ -851,9 +893,11 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
             f32x4 l0[2];
             #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                const bool ok = cok && t + 4 * h < p.T;
                 nv[h] = cok ? row_valid(t + 4 * h, p.T) : 0;
-                off[h] = (cok && t + 4 * h < p.T) ? (rowoff + t + 4 * h) * 4 : OOB_OFF;
+                off[h] = ok ? (rowoff + t + 4 * h) * 4 : OOB_OFF;
                 if (EPI == EPI_RES) l0[h] = buf_load4(R.res, off[h], 0);
+                if (EPI == EPI_RANK1) l0[h] = buf_load4(R.r1x, ok ? (t + 4 * h) * 4 : OOB_OFF, 0);
             }
             const f32x4 m1 = acc[1][n][m], m2 = acc[2][n][m];
             const f32x4 e = acc[0][n][m] + m1 + m2 + bias;
@@ -868,8 +912,35 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
                 w.x = fmaxf(w.x, w.x * slope); w.y = fmaxf(w.y, w.y * slope);
                 w.z = fmaxf(w.z, w.z * slope); w.w = fmaxf(w.w, w.w * slope);
                 if (EPI == EPI_RES) w += l0[h];
+                if (EPI == EPI_RANK1) w += l0[h] * r1w + r1b;
                 buf_store4_n(R.y, off[h], w, nv[h]);
             }
+        }
+    }
+}
+
+// MODE_DEC2 epilogue: two plain outputs, y = acc[0] + bias, y2 = acc[1] + bias2.
+template <int MW, int NW>
+__device__ __forceinline__ void ws_epilogue_dec2(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[2][NW][MW],
+                                                 int sig, int mg, int tcol0, bool active, int lane) {
+    if (!active) return;
+    const float* biasp = p.bias + (long)sig * p.bias_sig;
+    const float* bias2p = p.bias2 + (long)sig * p.bias2_sig;
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const bool cok = cot < p.COUT;
+        const int co = cok ? cot : 0;
+        const float bias = biasp[cot], bias2 = bias2p[cot];          // padded arrays
+        const int rowoff = co * p.T;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int t = tcol0 + n * 16 + (lane >> 4) * 4;
+            const bool ok = cok && t < p.T;
+            const int nv = ok ? row_valid(t, p.T) : 0;
+            const int off = ok ? (rowoff + t) * 4 : OOB_OFF;
+            buf_store4_n(R.y, off, acc[0][n][m] + bias, nv);
+            buf_store4_n(R.y2, off, acc[1][n][m] + bias2, nv);
         }
     }
 }
@@ -883,6 +954,7 @@ template <int MW, int NW, int MODE, int EPI>
 constexpr int ws_min_waves() {
     if (MODE == MODE_POLY) return (MW <= 2 && NW == 1) ? 4 : 2;
     if (MODE == MODE_WINO) return (MW == 2 && NW == 1) ? 4 : 2;   // four accumulator sets + a 24-slot weight ring
+    if (MODE == MODE_DEC2) return MW <= 2 ? 4 : 2;                // two accumulator sets + a 24-slot weight ring
     if (MW <= 2 || NW == 1) return 4;
     if (NW == 2 && NTAPS_IS_3_DIRECT(MODE) && (EPI == EPI_PLAIN || EPI == EPI_RES)) return 4;
     return 2;
@@ -892,7 +964,8 @@ template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GEN
 __global__ __launch_bounds__(512, (ws_min_waves<MW, NW, MODE, EPI>()))
 void conv_mfma_ws_kernel(const ConvParams p) {
     constexpr bool WINO = (MODE == MODE_WINO);                         // S carries the dilation D
-    constexpr int NSTEPS = WINO ? 24 : 6 * NTAPS;                      // weight ring slots
+    constexpr bool DEC2 = (MODE == MODE_DEC2);
+    constexpr int NSTEPS = (WINO || DEC2) ? 24 : 6 * NTAPS;            // weight ring slots
     constexpr int NT = (WINO ? 32 : 16) * NW * WN;                     // output columns per workgroup tile
     constexpr int NPROD = 256;                                         // producer threads
     constexpr int ITEMS = StageGeom<NT, NPROD>::ITEMS;
@@ -998,7 +1071,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
                     px[i].y = buf_load1(xr, o + 4 * (int)udiv_small(ph + 1, p.s), soff);
                     px[i].z = buf_load1(xr, o + 4 * (int)udiv_small(ph + 2, p.s), soff);
                     px[i].w = buf_load1(xr, o + 4 * (int)udiv_small(ph + 3, p.s), soff);
-                } else if (MODE == MODE_DECIMATE) {
+                } else if (MODE == MODE_DECIMATE || MODE == MODE_DEC2) {
                     const int o = (ro + t * p.s) * 4;           // x[..., ::s]; negative t -> out of range -> 0
                     px[i].x = buf_load1(xr, o, soff);
                     px[i].y = buf_load1(xr, o + 4 * p.s, soff);
@@ -1082,9 +1155,10 @@ void conv_mfma_ws_kernel(const ConvParams p) {
     } else {
         // ================================ CONSUMER WAVES ================================
         constexpr bool POLY = (MODE == MODE_POLY);
-        f32x4 acc[(POLY || WINO) ? 1 : NW][MW];
+        f32x4 acc[(POLY || WINO || DEC2) ? 1 : NW][MW];
         f32x4 acc3[3][POLY ? NW : 1][MW];              // polyphase: a / z / c accumulator sets
         f32x4 acc4[4][WINO ? NW : 1][MW];              // Winograd: m0..m3
+        f32x4 acc2[2][DEC2 ? NW : 1][MW];              // fused decimating convs: k=3 / 1x1
         float s1[MW], s2[MW];
         UnitWeightStream<MW, NSTEPS> wst;
         wst.init(p.w + (long)sig * p.w_sig + (long)(active ? mg : 0) * p.Q * 64 * MW,
@@ -1100,7 +1174,8 @@ void conv_mfma_ws_kernel(const ConvParams p) {
             const long ct = (long)p.COUT * p.T * (POLY ? S : 1);     // polyphase: outputs have T * S columns
             const float* nul = p.bias;                  // any valid address for unused descriptors
             R.y = make_rsrc(p.y ? p.y + (long)sig * p.y_sig + (long)b * p.y_b : nul, p.y ? ct : 0);
-            R.y2 = make_rsrc((flags & F_AFF_OUT) ? p.y2 + (long)b * p.y2_b : nul, (flags & F_AFF_OUT) ? ct : 0);
+            const bool has_y2 = DEC2 || (flags & F_AFF_OUT);
+            R.y2 = make_rsrc(has_y2 ? p.y2 + (long)sig * p.y2_sig + (long)b * p.y2_b : nul, has_y2 ? ct : 0);
             R.res = make_rsrc(p.res ? p.res + (long)sig * p.res_sig + (long)b * p.res_b : nul, p.res ? ct : 0);
             R.ss = make_rsrc((flags & (F_STATS | F_AFF_OUT)) ? p.ss_out + (long)b * p.ss_out_b : nul,
                              (flags & (F_STATS | F_AFF_OUT)) ? 2 * ct : 0);
@@ -1110,7 +1185,14 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         __syncthreads();                               // unit 0 staged
         int u = 0;
         for (int tl = 0; tl < ntiles; ++tl) {
-            if constexpr (WINO) {
+            if constexpr (DEC2) {
+                #pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    #pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        #pragma unroll
+                        for (int m = 0; m < MW; ++m) acc2[k][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if constexpr (WINO) {
                 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     #pragma unroll
@@ -1132,14 +1214,18 @@ void conv_mfma_ws_kernel(const ConvParams p) {
             }
             for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
                 if (active && !(p.dbg & DBG_NO_MFMA)) {
-                    if constexpr (WINO) mfma_unit_wino<MW, NW, S, NSTEPS>(acc4, Xs0 + (u & 1) * bufsz + colr, Xs0 + (u & 1) * bufsz + colrd, XS, wst);
+                    if constexpr (DEC2) mfma_unit_dec2<MW, NW>(acc2, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
+                    else if constexpr (WINO) mfma_unit_wino<MW, NW, S, NSTEPS>(acc4, Xs0 + (u & 1) * bufsz + colr, Xs0 + (u & 1) * bufsz + colrd, XS, wst);
                     else if constexpr (POLY) mfma_unit_poly<MW, NW>(acc3, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
                     else mfma_unit<MW, NW, NSTEPS>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
                 }
                 if (ch + 1 == p.nchunks) {
                     #pragma unroll
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
-                    if constexpr (WINO)
+                    if constexpr (DEC2)
+                        ws_epilogue_dec2<MW, NW>(p, R, acc2, sig, mg,
+                                                 (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
+                    else if constexpr (WINO)
                         ws_epilogue_wino<MW, NW, EPI, S>(p, R, acc4, sig, mg,
                                                          (tile0 + tl) * NT + wave_n * (NW * 32), active, lane);
                     else if constexpr (POLY)
@@ -1200,6 +1286,7 @@ int conv_ws_resident(int MW, int NW, int mode, int epi_kind) {
     // workgroups per CU the register budget of the compiled variant allows (see ws_min_waves)
     if (mode == MODE_POLY) return (MW <= 2 && NW == 1) ? 2 : 1;
     if (mode == MODE_WINO) return (MW == 2 && NW == 1) ? 2 : 1;
+    if (mode == MODE_DEC2) return MW <= 2 ? 2 : 1;
     if (MW <= 2 || NW == 1) return 2;
     if (NW == 2 && mode == MODE_DIRECT && (epi_kind == EPI_PLAIN || epi_kind == EPI_RES)) return 2;
     return 1;
@@ -1207,7 +1294,7 @@ int conv_ws_resident(int MW, int NW, int mode, int epi_kind) {
 
 bool conv_ws_tail_ok(int MW, int NW, int mode, int epi_kind, int S) {
     // variants compiled with the row-end (T % 4 != 0) handling, see ws_tail_ok
-    if (mode == MODE_POLY) return !(MW == 2 && S == 5 && epi_kind == EPI_AFF);
+    if (mode == MODE_POLY) return !(MW == 2 && S >= 4 && epi_kind == EPI_AFF);
     return !(MW == 2 && NW == 4);
 }
 
@@ -1230,6 +1317,17 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     if (p.mode == MODE_WINO) {
         if constexpr ((MW == 3 && NW <= 2) || (MW == 2 && NW == 1)) {
             const bool res = p.res != nullptr;
+            if constexpr (MW == 2) {                        // rank-1 residual: the stage-0 chain (C_in = 1 residual path)
+                if (p.r1x) {
+                    if (p.dil == 4) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 4>), grid, block, smem, stream, p);
+                    else if (p.dil == 2) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 2>), grid, block, smem, stream, p);
+                    else if (p.dil == 1) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 1>), grid, block, smem, stream, p);
+                    else return hipErrorInvalidValue;
+                    return hipGetLastError();
+                }
+            } else if (p.r1x) {
+                return hipErrorInvalidValue;
+            }
 #define FASTSVC_WINO(dv) \
             if (p.dil == dv) { \
                 if (res) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RES, dv>), grid, block, smem, stream, p); \
@@ -1243,6 +1341,13 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     }
     if constexpr (MW == 2 && WM != 1) {
         return hipErrorInvalidValue;                        // (2,1,2,2) / (2,1,4,1) exist for Winograd only
+    } else
+    if (p.mode == MODE_DEC2) {
+        if constexpr (NW <= 2) {
+            hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DEC2, 3>), grid, block, smem, stream, p);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
     } else
     if (p.mode == MODE_POLY) {
         if constexpr (poly_shape<MW, NW, WM, WN>()) {
@@ -1288,11 +1393,12 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
 bool conv_pipe_supported(const ConvParams& p) {
     if (p.KC != 24) return false;                              // 6 k-steps per tap per chunk, compiled in
     if (p.flags & F_PRE_AFFINE) return false;                  // only the generic kernel fuses the affine
+    if (p.mode == MODE_DEC2) return p.ntaps == 3 && p.dil == 1 && p.bias2 && p.y2 && !p.res && !p.r1x && p.flags == 0;
     if (p.ntaps == 1) return p.mode == MODE_DECIMATE;          // the 1x1 residual convs of the down nets
     if (p.ntaps != 3) return false;
     if (p.mode == MODE_DIRECT) return true;                    // any row length (element masks at the row end)
     if (p.mode == MODE_WINO)                                   // F(2,3) along time: plain / residual epilogue only
-        return p.T == p.x_T && (p.dil == 1 || p.dil == 2 || p.dil == 4) && !p.r1x &&
+        return p.T == p.x_T && (p.dil == 1 || p.dil == 2 || p.dil == 4) &&
                !(p.flags & (F_STATS | F_AFF_OUT)) && p.ps > 0;
     if (p.mode == MODE_POLY)                                   // input-rate tiles, float4 window loads
         return p.T == p.x_T && p.dil == 1 && (p.s == 2 || p.s == 4 || p.s == 5) &&

@@ -56,6 +56,11 @@ struct PackedConv {
     bool wino2 = false;
     size_t ww2_off = 0;
     long ww2_pair = 0;
+    // MODE_DEC2 (first k=3 conv of a down stage + the stage's 1x1 residual conv in one launch):
+    // w_off holds 4 "taps" per k-group (w0 w1 w2 | w1x1), Q = 24 * nchunks; second bias at b2_off
+    bool dec2 = false;
+    size_t b2_off = 0;
+    long b2_pair = 0;
 };
 
 // Source description used by the packer: virtual weight W[co][ci][tap] assembled from up to four
@@ -64,6 +69,7 @@ struct PackSource {
     // pieces: (layer name, co offset, ci offset); all pieces share ntaps
     struct Piece { std::string layer; int co_off; int ci_off; };
     std::vector<Piece> pieces;
+    bool dec2 = false;          // pieces = {k=3 conv, 1x1 conv}: packed as MODE_DEC2
 };
 
 struct RawParam {            // weights kept in plain row-major layout (VALU kernels)
@@ -77,6 +83,7 @@ struct DownStage {
     // k == 0: c1 and the 1x1 are raw (C_in == 1); k >= 1: packed
     RawParam c1_raw[2], r_raw[2];
     PackedConv r[2], c1[2], c2[2], c3[2];
+    PackedConv rc1[2];           // c1 and r fused (MODE_DEC2) when the stage qualifies (24-channel K chunks)
     PackedConv film[2];
     PackedConv heads;
 };
@@ -139,7 +146,7 @@ struct fastsvc_plan {
         for (int i = 0; i < npair; ++i) c[i].w_off = alloc(c[i].w_floats);
         for (int i = 0; i < npair; ++i) c[i].b_off = alloc(c[i].b_floats);
         for (int i = 0; i < npair; ++i) {
-            if (ntaps == 3 && (dil == 1 || dil == 2 || dil == 4) && c[i].KC == 24 && c[i].MW == 3) c[i].wino = true;
+            if (ntaps == 3 && (dil == 1 || dil == 2 || dil == 4) && c[i].KC == 24 && c[i].MW >= 2) c[i].wino = true;
         }
         for (int i = 0; i < npair; ++i)
             if (c[i].wino) {
@@ -148,12 +155,35 @@ struct fastsvc_plan {
             }
         if (npair == 2 && c[0].wino) c[0].ww_pair = (long)(c[1].ww_off - c[0].ww_off);
         for (int i = 0; i < npair; ++i)
-            if (c[i].wino && cout % 32 == 0) {
+            if (c[i].wino && c[i].MW == 3 && cout % 32 == 0) {
                 c[i].wino2 = true;
                 c[i].ww2_off = alloc((size_t)(cout / 32) * c[i].Qw * 64 * 2);
             }
         if (npair == 2 && c[0].wino2) c[0].ww2_pair = (long)(c[1].ww2_off - c[0].ww2_off);
         for (int i = 0; i < npair; ++i) pack_jobs.emplace_back(&c[i], src[i]);
+    }
+
+    // the fused k=3 + 1x1 decimating pair of a down stage (lft / sine twins)
+    void add_dec2(PackedConv* c, int cin, int cout, const std::string (&c1_layer)[2], const std::string (&r_layer)[2]) {
+        for (int i = 0; i < 2; ++i) {
+            plan_conv(c[i], cin, cout, 3, 1);
+            if (c[i].KC != 24) return;                      // tiny generators keep the two generic launches
+        }
+        for (int i = 0; i < 2; ++i) {
+            c[i].dec2 = true;
+            c[i].Q = 24 * c[i].nchunks;
+            c[i].w_floats = (size_t)c[i].ngroups * c[i].Q * 64 * c[i].MW;
+        }
+        for (int i = 0; i < 2; ++i) c[i].w_off = alloc(c[i].w_floats);
+        for (int i = 0; i < 2; ++i) c[i].b_off = alloc(c[i].b_floats);
+        for (int i = 0; i < 2; ++i) c[i].b2_off = alloc(c[i].b_floats);
+        c[0].b2_pair = (long)(c[1].b2_off - c[0].b2_off);
+        for (int i = 0; i < 2; ++i) {
+            PackSource src;
+            src.dec2 = true;
+            src.pieces = {{c1_layer[i], 0, 0}, {r_layer[i], 0, 0}};
+            pack_jobs.emplace_back(&c[i], src);
+        }
     }
 
     void add_raw(RawParam* r, int npair, const std::vector<std::string>& layers, size_t wf, size_t bf) {
@@ -201,6 +231,9 @@ int build_plan(fastsvc_plan& P) {
         } else {
             P.add_conv(d.r, 2, cin, d.C, 1, 1, {single(pl + ".residual_block.0"), single(ps + ".residual_block.0")});
             P.add_conv(d.c1, 2, cin, d.C, 3, 1, {single(pl + ".downsample_block.2"), single(ps + ".downsample_block.2")});
+            const std::string c1_layers[2] = {pl + ".downsample_block.2", ps + ".downsample_block.2"};
+            const std::string r_layers[2] = {pl + ".residual_block.0", ps + ".residual_block.0"};
+            P.add_dec2(d.rc1, cin, d.C, c1_layers, r_layers);
         }
         P.add_conv(d.c2, 2, d.C, d.C, 3, 2, {single(pl + ".downsample_block.4"), single(ps + ".downsample_block.4")});
         P.add_conv(d.c3, 2, d.C, d.C, 3, 4, {single(pl + ".downsample_block.6"), single(ps + ".downsample_block.6")});
@@ -336,6 +369,35 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
     for (const auto& job : plan->pack_jobs) {
         const PackedConv& c = *job.first;
         const PackSource& src = job.second;
+        if (src.dec2) {
+            // MODE_DEC2: components w0 w1 w2 (k=3 conv) | w1x1, step order inside a chunk
+            // (half * 4 + component) * 3 + k-group-in-half (mfma_unit_dec2)
+            HostLayer L3, L1;
+            int rc = fetch_layer(sd, src.pieces[0].layer, c.cout, (size_t)c.cin * 3, L3);
+            if (rc != FASTSVC_OK) return rc;
+            rc = fetch_layer(sd, src.pieces[1].layer, c.cout, (size_t)c.cin, L1);
+            if (rc != FASTSVC_OK) return rc;
+            float* wp = blob + c.w_off;
+            for (int grp = 0; grp < c.ngroups; ++grp)
+                for (int ch = 0; ch < c.nchunks; ++ch)
+                    for (int h = 0; h < 2; ++h)
+                        for (int comp = 0; comp < 4; ++comp)
+                            for (int jj = 0; jj < 3; ++jj) {
+                                const int q = ch * 24 + (h * 4 + comp) * 3 + jj;
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int ci = ch * c.KC + 4 * (3 * h + jj) + (lane >> 4);
+                                    for (int m = 0; m < c.MW; ++m) {
+                                        const int co = (grp * c.MW + m) * 16 + (lane & 15);
+                                        float v = 0.f;
+                                        if (co < c.cout && ci < c.cin)
+                                            v = comp < 3 ? L3.w[((size_t)co * c.cin + ci) * 3 + comp] : L1.w[(size_t)co * c.cin + ci];
+                                        wp[(((size_t)grp * c.Q + q) * 64 + lane) * c.MW + m] = v;
+                                    }
+                                }
+                            }
+            for (int co = 0; co < c.cout; ++co) { blob[c.b_off + co] = L3.b[co]; blob[c.b2_off + co] = L1.b[co]; }
+            continue;
+        }
         // virtual dense weight W[co][ci][tap] and bias
         std::vector<float> W((size_t)c.cout * c.cin * c.ntaps, 0.f);
         std::vector<float> bias(c.cout, 0.f);
@@ -597,6 +659,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
     }
     const bool poly = p.mode == MODE_POLY;
     p.bias = blob + c.b_off; p.bias_sig = pair_b_stride;
+    if (c.dec2) { p.bias2 = blob + c.b2_off; p.bias2_sig = c.b2_pair; }
     p.Q = c.Q; p.ngroups = c.ngroups; p.COUT = c.cout;
     p.ntaps = c.ntaps; p.dil = c.dil;
     p.vec = (p.T % 4 == 0) ? 1 : 0;
@@ -629,14 +692,19 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         else if (c.MW == 3 && c.ngroups % 4 == 0) cands = {{4, 4, 1}, {2, 4, 1}, {4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         else if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{4, 2, 2}, {2, 2, 2}, {1, 2, 2}, {4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
         else cands = {{4, 1, 4}, {2, 1, 4}, {1, 1, 4}};
+        if (p.mode == MODE_DEC2) {                      // two accumulator sets: compiled for NW <= 2
+            std::vector<Cand> keep;
+            for (const Cand& cd : cands) if (cd.NW <= 2) keep.push_back(cd);
+            cands.swap(keep);
+        }
         // Winograd F(2,3) variants of the same launch (fastsvc_kernels.h, MODE_WINO)
         static const int wino_env = std::getenv("FASTSVC_WINO") ? std::atoi(std::getenv("FASTSVC_WINO")) : -1;
-        const bool wino_ok = c.wino && wino_env != 0 && p.mode == MODE_DIRECT && !p.r1x &&
+        const bool wino_ok = c.wino && wino_env != 0 && p.mode == MODE_DIRECT && (!p.r1x || c.MW == 2) &&
                              !(p.flags & (F_STATS | F_AFF_OUT | F_PRE_AFFINE));
         if (wino_ok) {
             const size_t nd = cands.size();
             for (size_t i = 0; i < nd; ++i)
-                if (cands[i].NW <= 2) cands.push_back(Cand{cands[i].NW, cands[i].WM, cands[i].WN, 1});
+                if (cands[i].NW <= (c.MW == 2 ? 1 : 2)) cands.push_back(Cand{cands[i].NW, cands[i].WM, cands[i].WN, 1});
             if (c.wino2) {
                 const int ng2 = c.cout / 32;
                 cands.push_back(Cand{1, 1, 4, 2});
@@ -805,7 +873,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         // algorithmic work of the layer as the reference defines it (3 taps at the OUTPUT rate for
         // the stretched convs, whichever way they are computed)
         const double cols = (double)T_out * p.B * nsig;
-        const double flops = 2.0 * c.ntaps * c.cin * c.cout * cols;
+        const double flops = 2.0 * (c.dec2 ? 4 : c.ntaps) * c.cin * c.cout * cols;    // DEC2: k=3 conv + 1x1
         double in_cols = (double)T_out;                     // source columns actually needed
         if (p.mode == MODE_STRETCH || poly) in_cols = (double)p.x_T;
         double el = (double)c.cin * in_cols;
@@ -864,9 +932,12 @@ int fastsvc_workspace_tap(const fastsvc_plan* plan, int32_t B, int32_t F, const 
 int fastsvc_forward_launch_count(const fastsvc_plan* plan, int32_t with_spk_emb) {
     if (!plan) return 0;
     const int n = plan->n;
-    // kernels only: [speaker projection] + down stage 0 (3) + stages >= 1 (4 each)
-    // + FiLM (2 per stage) + up blocks (6 each) + conv_last
-    return (with_spk_emb ? 1 : 0) + 3 + 4 * (n - 1) + 2 * n + 6 * n + 1;
+    // kernels only: [speaker projection] + down stage 0 (3) + stages >= 1 (3 each with the fused
+    // c1 + 1x1 launch, else 4) + FiLM (2 per stage) + up blocks (6 each) + conv_last
+    static const bool no_dec2 = std::getenv("FASTSVC_NO_DEC2") != nullptr;
+    int down = 3;
+    for (int k = 1; k < n; ++k) down += (plan->down[k].rc1[0].dec2 && !no_dec2) ? 3 : 4;
+    return (with_spk_emb ? 1 : 0) + down + 2 * n + 6 * n + 1;
 }
 
 #define HIP_TRY(expr)                                                                          \
@@ -985,12 +1056,22 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             ConvParams p = base;                                   // r = conv1x1(h_{k-1}[::s])
             p.x = hprev; p.x_sig = (long)B * Cprev * Tprev; p.x_b = (long)Cprev * Tprev; p.x_T = (int)Tprev;
             p.mode = MODE_DECIMATE; p.s = d.scale;
+            static const bool no_dec2 = std::getenv("FASTSVC_NO_DEC2") != nullptr;      // A/B switch
+            if (d.rc1[0].dec2 && !no_dec2) {
+                // both convs of the decimated input in one launch: c1 -> y, r -> y2
+                p.mode = MODE_DEC2;
+                p.y = c1; p.y_sig = tsig; p.y_b = tb;
+                p.y2 = r; p.y2_sig = tsig; p.y2_b = tb;
+                HIP_TRY(run_conv(d.rc1[0], blob, p, 2, (long)(d.rc1[1].w_off - d.rc1[0].w_off),
+                                 (long)(d.rc1[1].b_off - d.rc1[0].b_off), stream, prof, ("down." + s + ".c1_res1x1").c_str()));
+            } else {
             p.y = r; p.y_sig = tsig; p.y_b = tb;
             HIP_TRY(order_after(stream, s_side));                  // h_{k-1} is ready
             HIP_TRY(run_conv(d.r[0], blob, p, 2, (long)(d.r[1].w_off - d.r[0].w_off), (long)(d.r[1].b_off - d.r[0].b_off), s_side, prof, ("down." + s + ".res1x1").c_str()));
             p.flags = F_PRE_LRELU;                                 // c1 = conv3_d1(lrelu(h_{k-1}[::s]))
             p.y = c1;
             HIP_TRY(run_conv(d.c1[0], blob, p, 2, (long)(d.c1[1].w_off - d.c1[0].w_off), (long)(d.c1[1].b_off - d.c1[0].b_off), stream, prof, ("down." + s + ".c1").c_str()));
+            }
         }
         {
             ConvParams p = base;                                   // c2 = conv3_d2(lrelu(c1))
