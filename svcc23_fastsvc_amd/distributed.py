@@ -4,7 +4,7 @@ The generator forward has no cross-utterance coupling (InstanceNorm is per (b, c
 row; SURVEY.md §8 e), so the path shards by UTTERANCE with no collective on the data path:
 
   * weights: rank 0 folds weight-norm and packs the kernel-layout blob once, then broadcasts it
-    (`broadcast_packed_weights`, 11 MB fp32) - the other ranks never touch the checkpoint;
+    (`broadcast_packed_weights`, 34.5 MB fp32: every kernel-layout copy of the weights) - the other ranks never touch the checkpoint;
   * work: the utterance list is split by a longest-processing-time greedy so that every rank gets
     the same number of frames (`shard_utterances`); each rank runs the single-GPU path on
     same-length buckets (padding would change the InstanceNorm statistics, so utterances are
