@@ -40,7 +40,7 @@ enum {
     FASTSVC_E_MISSING = -2,      /* a state-dict tensor is missing or has the wrong element count */
     FASTSVC_E_WORKSPACE = -3,    /* workspace too small */
     FASTSVC_E_HIP = -4,          /* a HIP runtime call or kernel launch failed */
-    FASTSVC_E_UNSUPPORTED = -5   /* valid in the reference, not implemented here yet (e.g. ragged lengths) */
+    FASTSVC_E_UNSUPPORTED = -5   /* valid in the reference, not implemented here */
 };
 
 /* Constructor kwargs of FastSVCGenerator (fastsvc.py:238-246; egs/svcc23/fastsvc1/conf/fastsvc.yaml:23-29). */
@@ -94,7 +94,11 @@ size_t fastsvc_workspace_bytes(const fastsvc_plan* plan, int32_t B, int32_t F);
  *   spk_emb  (B, spk_emb_size)     device, or NULL (reference: spk_emb=None skips InstanceNorm and
  *                                  the speaker bias, fastsvc.py:134-140)
  *   out      (B, out_channels, T)  device, written
- *   lengths  must be NULL (all utterances F frames); per-utterance lengths -> FASTSVC_E_UNSUPPORTED
+ *   lengths  NULL (all utterances F frames) or DEVICE pointer to B int32 frame counts, 1 <= lengths[b] <= F:
+ *            a ragged batch.  Inputs and outputs keep the padded shapes above; utterance b is computed
+ *            exactly as if it were run alone with lengths[b] frames (zero "same" padding at its own
+ *            end, InstanceNorm over its own length); out[b, :, lengths[b]*hop:] is set to zero and the
+ *            padding of the inputs is never read.  (The reference batches equal-length crops only.)
  *   dev_blob packed weights on the same device; workspace >= fastsvc_workspace_bytes(B, F)
  *   stream   hipStream_t (void* to keep this header free of HIP includes)
  * Launches are asynchronous on `stream`; the caller synchronises. */

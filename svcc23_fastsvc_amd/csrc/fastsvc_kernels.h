@@ -92,6 +92,14 @@ struct ConvParams {
     int B;                       // batch per signal; gridDim.z = nsig * B
     int xs;                      // LDS row stride in floats (== 16 mod 32, >= NT + 2*halo)
     int ps;                      // MODE_WINO: phase-plane stride in floats inside an LDS row
+    // Row pitches (floats) of the input / output tensors.  T and x_T are the VALID row lengths; they
+    // equal the pitches unless the batch is ragged: with `lens` (device, B frame counts) the kernels
+    // use T = lens[b] * len_mul and x_T = lens[b] * xlen_mul for utterance b (masks, tiles,
+    // InstanceNorm length) while rows keep the pitch of the longest utterance.
+    int ldx, ldy;
+    const int* lens;
+    int len_mul, xlen_mul;
+    int frames_ld;               // host side only: padded frame count F (run_conv derives len_mul = T / F)
     int vec;                     // 1: T % 4 == 0 and all row bases 16-byte aligned -> float4 epilogue
     int tpw;                     // pipelined kernel: consecutive time tiles walked by one workgroup
     int dbg;                     // ablation switches for profiling (FASTSVC_DBG env var); 0 in production
@@ -122,12 +130,13 @@ hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t s
 
 // down-sampling stage 0, first conv (C_in = 1, k = 3, d = 1, LeakyReLU on the input):
 //   y[sig][b][co][t] = bias[co] + sum_tap w[co][tap] * lrelu(x[sig][b][t + tap - 1])
+//   lens / len_mul: ragged batches (valid length of utterance b = lens[b] * len_mul, rows keep pitch T)
 hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, long w_sig, long b_sig,
-                           float* y, int nsig, int B, int C, int T, hipStream_t stream);
+                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream);
 
 // conv_last: 1x1, y[b][o][t] = bias[o] + sum_c w[o][c] * x[b][c][t]
 hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
-                                int B, int C, int O, int T, hipStream_t stream);
+                                int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream);
 
 // speaker bias for all up blocks: p[blk][b][c] = bias + W[c] . (e / max(||e||, 1e-12))
 struct SpkBlock {

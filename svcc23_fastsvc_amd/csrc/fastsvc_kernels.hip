@@ -399,11 +399,11 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
         const float bias = biasp[co];
         float r1w = 0.f, r1b = 0.f;
         if (r1x) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
-        float* yrow = ybase ? ybase + (long)co * p.T : nullptr;
-        float* y2row = y2base ? y2base + (long)co * p.T : nullptr;
-        const float* rrow = resbase ? resbase + (long)co * p.T : nullptr;
-        const float* scrow = ssob ? ssob + (long)co * p.T : nullptr;
-        const float* shrow = ssob ? ssob + (long)(p.COUT + co) * p.T : nullptr;
+        float* yrow = ybase ? ybase + (long)co * p.ldy : nullptr;
+        float* y2row = y2base ? y2base + (long)co * p.ldy : nullptr;
+        const float* rrow = resbase ? resbase + (long)co * p.ldy : nullptr;
+        const float* scrow = ssob ? ssob + (long)co * p.ldy : nullptr;
+        const float* shrow = ssob ? ssob + (long)(p.COUT + co) * p.ldy : nullptr;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 16 + (lane >> 4) * 4;
@@ -494,7 +494,7 @@ __device__ __forceinline__ void norm_constants(const ConvParams& p, int b, int C
 // ---------------------------------------------------------------------------------------------
 template <int MW, int NW, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN)
-void conv_mfma_kernel(const ConvParams p) {
+void conv_mfma_kernel(const ConvParams p0) {
     constexpr int NWAVES = WM * WN;
     constexpr int NTHREADS = 64 * NWAVES;
     constexpr int NT = 16 * NW * WN;
@@ -506,9 +506,16 @@ void conv_mfma_kernel(const ConvParams p) {
     const int wave_m = wave / WN;
     const int wave_n = wave - wave_m * WN;
     const int z = blockIdx.z;
-    const int sig = z / p.B;
-    const int b = z - sig * p.B;
+    const int sig = z / p0.B;
+    const int b = z - sig * p0.B;
+    ConvParams p = p0;                                  // ragged batch: this utterance's row lengths
+    if (p0.lens) {
+        const int frames = p0.lens[b];
+        p.T = frames * p0.len_mul;
+        p.x_T = frames * p0.xlen_mul;
+    }
     const int t0 = blockIdx.x * NT;
+    if (t0 >= p.T) return;
     const int mg = blockIdx.y * WM + wave_m;
     const bool active = mg < p.ngroups;
     const int halo = (p.ntaps == 3) ? p.dil : 0;
@@ -551,13 +558,13 @@ void conv_mfma_kernel(const ConvParams p) {
                 for (int j = lane; j < W; j += 64) row[j] = 0.f;
                 continue;
             }
-            const float* xrow = xbase + (long)ci * p.x_T;
+            const float* xrow = xbase + (long)ci * p.ldx;
             const float* scrow = nullptr;
             const float* shrow = nullptr;
             float mean = 0.f, rstd = 1.f, pb = 0.f;
             if (flags & F_PRE_AFFINE) {
-                scrow = ssbase + (long)ci * p.x_T;
-                shrow = ssbase + (long)(p.CIN + ci) * p.x_T;
+                scrow = ssbase + (long)ci * p.ldx;
+                shrow = ssbase + (long)(p.CIN + ci) * p.ldx;
             }
             if (flags & F_PRE_NORM) { mean = nmean[ci]; rstd = nrstd[ci]; pb = nspk[ci]; }
             for (int j = lane; j < W; j += 64) {
@@ -702,7 +709,7 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
     }
     if (!active) return;
     const float* biasp = p.bias + (long)sig * p.bias_sig;
-    const int shift_soff = p.COUT * p.T * 4;              // shift rows follow the scale rows
+    const int shift_soff = p.COUT * p.ldy * 4;            // shift rows follow the scale rows
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int co = (mg * MW + m) * 16 + (lane & 15);
@@ -710,7 +717,7 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
         const float bias = biasp[co];
         float r1w = 0.f, r1b = 0.f;
         if (p.r1x) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
-        const int rowoff = co * p.T;
+        const int rowoff = co * p.ldy;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 16 + (lane >> 4) * 4;
@@ -751,7 +758,7 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
     if (!active) return;                                   // whole wave (uniform)
     const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;     // max(v, slope*v): identity for 1
     const float* biasp = p.bias + (long)sig * p.bias_sig;                  // padded to the channel tiles
-    const int shift_soff = p.COUT * p.T * 4;
+    const int shift_soff = p.COUT * p.ldy * 4;
     constexpr int G = (EPI == EPI_AFF) ? (NW == 2 ? 2 : 1) : NW;           // items whose loads fly together (register budget)
     constexpr bool TAIL = ws_tail_ok<MW, NW, MODE_DIRECT, EPI, 1>();
     #pragma unroll
@@ -762,7 +769,7 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
         const float bias = biasp[cot];                     // padded array: always in bounds
         float r1w = 0.f, r1b = 0.f;
         if (EPI == EPI_RANK1) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
-        const int rowoff = co * p.T;
+        const int rowoff = co * p.ldy;
         #pragma unroll
         for (int n0 = 0; n0 < NW; n0 += G) {
             int off[G], nv[G];
@@ -811,7 +818,7 @@ __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiR
                                                  int mg, int tcol0, bool active, int lane) {
     if (!active) return;                                   // whole wave (uniform)
     const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
-    const int T_out = p.T * S;
+    const int T_out = p.ldy;                               // output row pitch
     const int shift_soff = p.COUT * T_out * 4;
     constexpr int G = (MW <= 2 && NW == 1) ? (S < 4 ? S : 4) : S;  // output float4s whose loads fly together (register budget)
     #pragma unroll
@@ -885,7 +892,7 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
         const float bias = biasp[cot];                     // padded array: always in bounds
         float r1w = 0.f, r1b = 0.f;
         if (EPI == EPI_RANK1) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
-        const int rowoff = co * p.T;
+        const int rowoff = co * p.ldy;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 32 + (lane >> 4) * 8;
@@ -932,7 +939,7 @@ __device__ __forceinline__ void ws_epilogue_dec2(const ConvParams& p, const EpiR
         const bool cok = cot < p.COUT;
         const int co = cok ? cot : 0;
         const float bias = biasp[cot], bias2 = bias2p[cot];          // padded arrays
-        const int rowoff = co * p.T;
+        const int rowoff = co * p.ldy;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 16 + (lane >> 4) * 4;
@@ -962,7 +969,7 @@ constexpr int ws_min_waves() {
 
 template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC, int S = 1>
 __global__ __launch_bounds__(512, (ws_min_waves<MW, NW, MODE, EPI>()))
-void conv_mfma_ws_kernel(const ConvParams p) {
+void conv_mfma_ws_kernel(const ConvParams p0) {
     constexpr bool WINO = (MODE == MODE_WINO);                         // S carries the dilation D
     constexpr bool DEC2 = (MODE == MODE_DEC2);
     constexpr int NSTEPS = (WINO || DEC2) ? 24 : 6 * NTAPS;            // weight ring slots
@@ -979,8 +986,16 @@ void conv_mfma_ws_kernel(const ConvParams p) {
     const int wave_m = cw / WN;
     const int wave_n = cw - wave_m * WN;
     const int z = blockIdx.z;
-    const int sig = z / p.B;
-    const int b = z - sig * p.B;
+    const int sig = z / p0.B;
+    const int b = z - sig * p0.B;
+    // ragged batch: this utterance's own row lengths (tiles, masks, InstanceNorm length); the row
+    // pitches ldx / ldy stay those of the longest utterance
+    ConvParams p = p0;
+    if (p0.lens) {
+        const int frames = p0.lens[b];
+        p.T = frames * p0.len_mul;
+        p.x_T = frames * p0.xlen_mul;
+    }
     const int mg = blockIdx.y * WM + wave_m;
     const bool active = !producer && mg < p.ngroups;
     const int halo = (NTAPS == 3) ? p.dil : 0;
@@ -992,6 +1007,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
     const int ntx = (p.T + NT - 1) / NT;
     const int tile0 = blockIdx.x * p.tpw;
     const int ntiles = min(p.tpw, ntx - tile0);
+    if (ntiles <= 0) return;                                           // ragged batch: nothing of this utterance here
     const int nunits = ntiles * p.nchunks;
 
     double* sstat = reinterpret_cast<double*>(smem_raw);                       // [WM*MW*16][2]
@@ -1045,21 +1061,21 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         // tensor (columns before the first / after the last row, channel padding) read as 0 in
         // hardware, everything else is real memory and is masked by `okmask` where it is padding.
         const __amdgpu_buffer_rsrc_t xr =
-            make_rsrc(p.x + (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.x_T);
+            make_rsrc(p.x + (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
 
         // unconditional loads of unit `un` into a register set; validity in the mask
         auto pload = [&](int un, f32x4 (&px)[ITEMS], unsigned& okmask) {
             const int tl = un / p.nchunks;
             const int ch = un - tl * p.nchunks;
             const int t_start = (tile0 + tl) * NT - halo_al;
-            const int soff = ch * p.KC * p.x_T * 4;
+            const int soff = ch * p.KC * p.ldx * 4;
             const int rows_left = p.CIN - ch * p.KC;          // rows >= this are channel padding
             okmask = 0;
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const int r = rq[i] >> 16;
                 const int t = t_start + (rq[i] & 0xffff);
-                const int ro = r * p.x_T;
+                const int ro = r * p.ldx;
                 const bool ok = loff[i] >= 0 && (unsigned)t < (unsigned)p.T && r < rows_left;
                 okmask |= (ok ? 1u : 0u) << i;
                 if (MODE == MODE_STRETCH) {
@@ -1171,7 +1187,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
         const int colrd = wq + (wpair % S + S) * p.ps;
         EpiRsrc R;
         {
-            const long ct = (long)p.COUT * p.T * (POLY ? S : 1);     // polyphase: outputs have T * S columns
+            const long ct = (long)p.COUT * p.ldy;       // rows of y / y2 / res / scale / shift at the output pitch
             const float* nul = p.bias;                  // any valid address for unused descriptors
             R.y = make_rsrc(p.y ? p.y + (long)sig * p.y_sig + (long)b * p.y_b : nul, p.y ? ct : 0);
             const bool has_y2 = DEC2 || (flags & F_AFF_OUT);
@@ -1179,7 +1195,7 @@ void conv_mfma_ws_kernel(const ConvParams p) {
             R.res = make_rsrc(p.res ? p.res + (long)sig * p.res_sig + (long)b * p.res_b : nul, p.res ? ct : 0);
             R.ss = make_rsrc((flags & (F_STATS | F_AFF_OUT)) ? p.ss_out + (long)b * p.ss_out_b : nul,
                              (flags & (F_STATS | F_AFF_OUT)) ? 2 * ct : 0);
-            R.r1x = make_rsrc(p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nul, p.r1x ? p.T : 0);
+            R.r1x = make_rsrc(p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nul, p.r1x ? p.ldy : 0);
         }
         setup_shared();
         __syncthreads();                               // unit 0 staged
@@ -1434,12 +1450,13 @@ hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t s
 __global__ __launch_bounds__(256)
 void in1_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                      const float* __restrict__ bias, long w_sig, long b_sig, float* __restrict__ y,
-                     int B, int C, int T) {
+                     int B, int C, int ld, const int* __restrict__ lens, int len_mul) {
     const int z = blockIdx.z;
     const int sig = z / B;
+    const int T = lens ? lens[z - sig * B] * len_mul : ld;          // valid length of this utterance (pitch ld)
     const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (t >= T) return;
-    const float* xr = x + (long)z * T;
+    const float* xr = x + (long)z * ld;
     float xv[6];
     #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -1448,14 +1465,14 @@ void in1_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
     }
     const float* ws = w + sig * w_sig;
     const float* bs = bias + sig * b_sig;
-    float* yb = y + (long)z * C * T;
-    const bool full = (t + 3 < T) && ((T & 3) == 0);
+    float* yb = y + (long)z * C * ld;
+    const bool full = (t + 3 < T) && ((ld & 3) == 0);
     for (int co = 0; co < C; ++co) {
         const float w0 = ws[co * 3 + 0], w1 = ws[co * 3 + 1], w2 = ws[co * 3 + 2], bb = bs[co];
         float o[4];
         #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = bb + (w0 * xv[i] + w1 * xv[i + 1]) + w2 * xv[i + 2];
-        float* yr = yb + (long)co * T + t;
+        float* yr = yb + (long)co * ld + t;
         if (full) {
             *reinterpret_cast<f32x4*>(yr) = f32x4{o[0], o[1], o[2], o[3]};
         } else {
@@ -1465,9 +1482,9 @@ void in1_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
 }
 
 hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, long w_sig, long b_sig,
-                           float* y, int nsig, int B, int C, int T, hipStream_t stream) {
+                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream) {
     dim3 grid((T + 1023) / 1024, 1, nsig * B);
-    hipLaunchKernelGGL(in1_conv_kernel, grid, dim3(256), 0, stream, x, w, bias, w_sig, b_sig, y, B, C, T);
+    hipLaunchKernelGGL(in1_conv_kernel, grid, dim3(256), 0, stream, x, w, bias, w_sig, b_sig, y, B, C, T, lens, len_mul);
     return hipGetLastError();
 }
 
@@ -1477,32 +1494,41 @@ hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, lo
 __global__ __launch_bounds__(256)
 void pointwise_out_kernel(const float* __restrict__ x, const float* __restrict__ w,
                           const float* __restrict__ bias, float* __restrict__ y,
-                          int C, int O, int T) {
+                          int C, int O, int ld, const int* __restrict__ lens, int len_mul) {
     const int b = blockIdx.z;
+    const int T = lens ? lens[b] * len_mul : ld;          // valid length of this utterance (pitch ld)
     const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (t >= T) return;
-    const float* xb = x + (long)b * C * T;
-    const bool full = (t + 3 < T) && ((T & 3) == 0);
+    if (t >= ld) return;
+    if (t >= T) {                                         // ragged batch: the padding of the output is zero
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < 4 && t + i < ld; ++i) y[((long)b * O + o) * ld + t + i] = 0.f;
+        return;
+    }
+    const float* xb = x + (long)b * C * ld;
+    const bool full = (t + 3 < T) && ((ld & 3) == 0);
     for (int o = 0; o < O; ++o) {
         f32x4 acc = f32x4{bias[o], bias[o], bias[o], bias[o]};
         if (full) {
             for (int c = 0; c < C; ++c)
-                acc += *reinterpret_cast<const f32x4*>(xb + (long)c * T + t) * w[o * C + c];
-            *reinterpret_cast<f32x4*>(y + ((long)b * O + o) * T + t) = acc;
+                acc += *reinterpret_cast<const f32x4*>(xb + (long)c * ld + t) * w[o * C + c];
+            *reinterpret_cast<f32x4*>(y + ((long)b * O + o) * ld + t) = acc;
         } else {
-            for (int i = 0; i < 4 && t + i < T; ++i) {
-                float a = bias[o];
-                for (int c = 0; c < C; ++c) a += xb[(long)c * T + t + i] * w[o * C + c];
-                y[((long)b * O + o) * T + t + i] = a;
+            for (int i = 0; i < 4 && t + i < ld; ++i) {
+                float a = 0.f;
+                if (t + i < T) {
+                    a = bias[o];
+                    for (int c = 0; c < C; ++c) a += xb[(long)c * ld + t + i] * w[o * C + c];
+                }
+                y[((long)b * O + o) * ld + t + i] = a;
             }
         }
     }
 }
 
 hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
-                                int B, int C, int O, int T, hipStream_t stream) {
+                                int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream) {
     dim3 grid((T + 1023) / 1024, 1, B);
-    hipLaunchKernelGGL(pointwise_out_kernel, grid, dim3(256), 0, stream, x, w, bias, y, C, O, T);
+    hipLaunchKernelGGL(pointwise_out_kernel, grid, dim3(256), 0, stream, x, w, bias, y, C, O, T, lens, len_mul);
     return hipGetLastError();
 }
 

@@ -658,6 +658,10 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (conv_pipe_supported(q) && tail_fine) { p.mode = MODE_POLY; p.T = p.x_T; p.w = q.w; }
     }
     const bool poly = p.mode == MODE_POLY;
+    // row pitches; with a ragged batch the kernels take each utterance's own lengths from `lens`
+    p.ldx = p.x_T;
+    p.ldy = (int)T_out;
+    if (p.lens) { p.len_mul = p.T / p.frames_ld; p.xlen_mul = p.x_T / p.frames_ld; }
     p.bias = blob + c.b_off; p.bias_sig = pair_b_stride;
     if (c.dec2) { p.bias2 = blob + c.b2_off; p.bias2_sig = c.b2_pair; }
     p.Q = c.Q; p.ngroups = c.ngroups; p.COUT = c.cout;
@@ -954,7 +958,6 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     if (!plan || !dev_blob || !ppg || !sine || !lft || !out || !workspace)
         return fail(FASTSVC_E_INVALID, "null argument");
     if (B < 1 || F < 1) return fail(FASTSVC_E_INVALID, "B and F must be >= 1");
-    if (lengths) return fail(FASTSVC_E_UNSUPPORTED, "per-utterance lengths are not supported yet: bucket by length on the host");
     const fastsvc_plan& P = *plan;
     if (spk_emb && !P.cfg.use_spk_emb)
         return fail(FASTSVC_E_INVALID, "spk_emb given but the generator was built with use_spk_emb=False");
@@ -1044,12 +1047,14 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         ConvParams base;
         std::memset(&base, 0, sizeof(base));
         base.B = B; base.T = (int)Tk; base.s = 1; base.mode = MODE_DIRECT;
+        base.lens = lengths; base.frames_ld = F;
         if (k == 0) {
             if (prof) HIP_TRY(prof->begin(stream, "down.0.c1", "in1_conv", 2.0 * 3 * d.C * (double)Tk * B * 2,
                                           4.0 * (1.0 + d.C) * (double)Tk * B * 2));
             HIP_TRY(launch_in1_conv(sigbuf, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
                                     (long)(d.c1_raw[1].w_off - d.c1_raw[0].w_off),
-                                    (long)(d.c1_raw[1].b_off - d.c1_raw[0].b_off), c1, 2, B, d.C, (int)Tk, stream));
+                                    (long)(d.c1_raw[1].b_off - d.c1_raw[0].b_off), c1, 2, B, d.C, (int)Tk,
+                                    lengths, (int)(Tk / F), stream));
             if (prof) HIP_TRY(prof->end());
         } else {
             float* r = buf("down_r." + s);
@@ -1139,6 +1144,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         ConvParams base;
         std::memset(&base, 0, sizeof(base));
         base.B = B; base.s = 1; base.mode = MODE_DIRECT;
+        base.lens = lengths; base.frames_ld = F;
         // Every tensor that feeds a FiLM-affine is stored already affined (u = scale*t + shift,
         // written by the producing epilogue, which also accumulates its InstanceNorm sums), so the
         // consuming conv stages ONE tensor and applies (u - mean) * rstd + p, LeakyReLU on the fly.
@@ -1191,7 +1197,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     if (prof) HIP_TRY(prof->begin(stream, "conv_last", "pointwise_out", 2.0 * Cx * P.cfg.out_channels * (double)T * B,
                                   4.0 * (Cx + P.cfg.out_channels) * (double)T * B));
     HIP_TRY(launch_pointwise_out(x, blob + P.last.w_off, blob + P.last.b_off, out, B, Cx,
-                                 P.cfg.out_channels, (int)T, stream));
+                                 P.cfg.out_channels, (int)T, lengths, (int)hop, stream));
     if (prof) HIP_TRY(prof->end());
     return FASTSVC_OK;
 }

@@ -7,8 +7,9 @@ row; SURVEY.md §8 e), so the path shards by UTTERANCE with no collective on the
     (`broadcast_packed_weights`, 34.5 MB fp32: every kernel-layout copy of the weights) - the other ranks never touch the checkpoint;
   * work: the utterance list is split by a longest-processing-time greedy so that every rank gets
     the same number of frames (`shard_utterances`); each rank runs the single-GPU path on
-    same-length buckets (padding would change the InstanceNorm statistics, so utterances are
-    bucketed by length, never padded);
+    same-length buckets, or - `ragged=True` - on padded batches of SIMILAR length with per-utterance
+    `lengths` (the kernels then keep every utterance's own zero padding and InstanceNorm length, so
+    padding does not change the result);
   * results: waveforms are all-gathered (`all_gather_waveforms`): one `all_gather_into_tensor`
     when every rank holds the same shape, otherwise lengths first, then padded rows.
 
@@ -44,6 +45,21 @@ def bucket_by_length(indices: Sequence[int], n_frames: Sequence[int]) -> Dict[in
     for i in indices:
         out.setdefault(int(n_frames[i]), []).append(i)
     return out
+
+
+def bucket_ragged(indices: Sequence[int], n_frames: Sequence[int], max_batch: int = 64,
+                  pad_tolerance: float = 0.125) -> List[List[int]]:
+    """Batches for the ragged path: longest first, a batch takes utterances while the shortest is
+    within `pad_tolerance` of the longest (bounded padding waste) and it holds < max_batch."""
+    order = sorted(indices, key=lambda i: (-int(n_frames[i]), i))
+    batches: List[List[int]] = []
+    for i in order:
+        if batches and len(batches[-1]) < max_batch and \
+                int(n_frames[i]) >= (1.0 - pad_tolerance) * int(n_frames[batches[-1][0]]):
+            batches[-1].append(i)
+        else:
+            batches.append([i])
+    return batches
 
 
 def broadcast_packed_weights(generator, device, src: int = 0, group=None) -> torch.Tensor:
@@ -101,17 +117,40 @@ def all_gather_waveforms(local: List[Tuple[int, torch.Tensor]], n_total: int, gr
     return out
 
 
-def run_utterance_parallel(forward_fn: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]], torch.Tensor],
-                           utterances: Sequence[dict], device, max_batch: int = 64, group=None
+def run_utterance_parallel(forward_fn: Callable[..., torch.Tensor],
+                           utterances: Sequence[dict], device, max_batch: int = 64, group=None,
+                           ragged: bool = False, pad_tolerance: float = 0.125
                            ) -> List[Optional[torch.Tensor]]:
     """Shard `utterances` (dicts with 'ppg' (C,F), 'sine' (1,T), 'lft' (1,T), optional 'spk_emb'
-    (E,)) over the ranks, run `forward_fn` on same-length batches, all-gather the waveforms.
-    Every rank passes the same list (only its shard is moved to `device`)."""
+    (E,)) over the ranks, run `forward_fn(ppg, sine, lft, emb)` on same-length batches - or, with
+    `ragged`, `forward_fn(ppg, sine, lft, emb, lengths)` on zero-padded batches of similar length -
+    and all-gather the waveforms.  Every rank passes the same list (only its shard is moved to
+    `device`)."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n_frames = [int(u["ppg"].shape[-1]) for u in utterances]
     mine = shard_utterances(n_frames, world)[rank]
     local: List[Tuple[int, torch.Tensor]] = []
+    if ragged:
+        for chunk in bucket_ragged(mine, n_frames, max_batch, pad_tolerance):
+            fmax = int(n_frames[chunk[0]])
+            hop = int(utterances[chunk[0]]["sine"].shape[-1]) // fmax
+
+            def pad(key, width):
+                rows = []
+                for i in chunk:
+                    t = torch.as_tensor(utterances[i][key])
+                    rows.append(torch.nn.functional.pad(t, (0, width - t.shape[-1])))
+                return torch.stack(rows).to(device)
+
+            emb = None
+            if utterances[chunk[0]].get("spk_emb") is not None:
+                emb = torch.stack([torch.as_tensor(utterances[i]["spk_emb"]) for i in chunk]).to(device)
+            lens = [int(n_frames[i]) for i in chunk]
+            y = forward_fn(pad("ppg", fmax), pad("sine", fmax * hop), pad("lft", fmax * hop), emb, lens)
+            for j, i in enumerate(chunk):
+                local.append((i, y[j][:, : lens[j] * hop]))
+        return all_gather_waveforms(local, len(utterances), group=group)
     for _, idxs in sorted(bucket_by_length(mine, n_frames).items()):
         for k in range(0, len(idxs), max_batch):
             chunk = idxs[k: k + max_batch]

@@ -243,8 +243,12 @@ class Plan:
     def forward(self, blob: torch.Tensor, ppg: torch.Tensor, sine: torch.Tensor, lft: torch.Tensor,
                 spk_emb: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
                 workspace: Optional[torch.Tensor] = None, profile: Optional[list] = None,
-                autotune: bool = False) -> torch.Tensor:
+                autotune: bool = False, lengths=None) -> torch.Tensor:
         """Enqueue one forward on the current HIP stream of ``ppg.device``; returns (B, O, T).
+
+        ``lengths`` (B frame counts, 1 <= n <= F; sequence or int tensor) makes the batch ragged:
+        inputs stay padded to F, utterance b is computed exactly as if run alone with lengths[b]
+        frames and ``out[b, :, lengths[b]*hop:]`` is zero.
 
         With ``profile`` (a list) the launches are bracketed by hipEvents on that stream, the
         stream is synchronised and one dict per kernel launch is appended to the list.
@@ -269,6 +273,14 @@ class Plan:
         ppg, sine, lft = (t.to(torch.float32).contiguous() for t in (ppg, sine, lft))
         if spk_emb is not None:
             spk_emb = spk_emb.to(torch.float32).contiguous()
+        lens_dev = None
+        if lengths is not None:
+            lens_host = torch.as_tensor(lengths, dtype=torch.int64, device="cpu").reshape(-1)
+            if lens_host.numel() != B or int(lens_host.min()) < 1 or int(lens_host.max()) > F:
+                raise ValueError(f"lengths must hold {B} frame counts in [1, {F}]")
+            if autotune:
+                raise ValueError("autotune times full-length batches: call it without lengths")
+            lens_dev = lens_host.to(torch.int32).to(dev)
         need = self.workspace_bytes(B, F)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -281,7 +293,8 @@ class Plan:
                 ctypes.c_void_p(ppg.data_ptr()), ctypes.c_void_p(sine.data_ptr()),
                 ctypes.c_void_p(lft.data_ptr()),
                 ctypes.c_void_p(spk_emb.data_ptr()) if spk_emb is not None else None,
-                ctypes.c_void_p(out.data_ptr()), B, F, None,
+                ctypes.c_void_p(out.data_ptr()), B, F,
+                ctypes.c_void_p(lens_dev.data_ptr()) if lens_dev is not None else None,
                 ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), ctypes.c_void_p(stream))
             if autotune:
                 ntr = ctypes.c_int32(0)
@@ -298,5 +311,5 @@ class Plan:
                         profile.append(dict(layer=recs[i].layer.decode(), kernel=recs[i].kernel.decode(),
                                             flops=recs[i].flops, bytes=recs[i].bytes, ms=recs[i].ms))
         _check(self.lib, rc, "fastsvc_forward")
-        self._last_workspace = workspace      # keep alive until the stream has consumed it
+        self._last_workspace = (workspace, lens_dev)      # keep alive until the stream has consumed them
         return out

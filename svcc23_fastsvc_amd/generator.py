@@ -189,10 +189,14 @@ class FastSVCGenerator(nn.Module):
         return self._plan
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, s, l, spk_emb=None):
+    def forward(self, x, s, l, spk_emb=None, *, lengths=None):
         """x (B, in_channels, F) PPG - s (B, 1, T) sine - l (B, 1, T) loudness -
         spk_emb (B, spk_emb_size) or None  ->  (B, out_channels, T), T = F * prod(scales).
-        Same contract as fastsvc.py:305-332 (raw conv_last output, no tanh)."""
+        Same contract as fastsvc.py:305-332 (raw conv_last output, no tanh).
+
+        Extension (keyword only, not in the reference): ``lengths`` = per-utterance frame counts of
+        a padded ragged batch; utterance b is computed as if run alone with lengths[b] frames and
+        the padding of the output is zero."""
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
                 "the HIP path implements the generator forward only (backward is SURVEY.md §8 f2): "
@@ -213,8 +217,8 @@ class FastSVCGenerator(nn.Module):
         while step > 1 and plan.workspace_bytes(step, F) > self.max_workspace_bytes:
             step = (step + 1) // 2
         if step == B:
-            tune = bool(self.autotune) and (B, F, str(x.device)) not in self._tuned_shapes
-            y = plan.forward(blob, x, s, l, spk_emb, autotune=tune)
+            tune = bool(self.autotune) and lengths is None and (B, F, str(x.device)) not in self._tuned_shapes
+            y = plan.forward(blob, x, s, l, spk_emb, autotune=tune, lengths=lengths)
             if tune:
                 self._tuned_shapes.add((B, F, str(x.device)))
         else:
@@ -223,7 +227,8 @@ class FastSVCGenerator(nn.Module):
             for b0 in range(0, B, step):
                 b1 = min(B, b0 + step)
                 plan.forward(blob, x[b0:b1], s[b0:b1], l[b0:b1],
-                             None if spk_emb is None else spk_emb[b0:b1], out=y[b0:b1], workspace=ws)
+                             None if spk_emb is None else spk_emb[b0:b1], out=y[b0:b1], workspace=ws,
+                             lengths=None if lengths is None else list(lengths)[b0:b1])
         return y.to(x.dtype) if x.dtype != torch.float32 else y
 
     def inference(self, x, f0, l, signal_generator, pad_fn, spk_emb=None):

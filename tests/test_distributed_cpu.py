@@ -29,6 +29,16 @@ def _fake_forward(ppg, sine, lft, emb):
     return base + ppg.sum(dim=(1, 2), keepdim=True) + (0.0 if emb is None else emb.sum(dim=1)[:, None, None])
 
 
+def _fake_forward_ragged(ppg, sine, lft, emb, lengths):
+    """Ragged stand-in: per utterance, the same function of its VALID part only (like the kernels)."""
+    hop = sine.shape[-1] // ppg.shape[-1]
+    out = torch.zeros_like(sine)
+    for j, n in enumerate(lengths):
+        out[j:j + 1, :, : n * hop] = _fake_forward(ppg[j:j + 1, :, :n], sine[j:j + 1, :, : n * hop],
+                                                   lft[j:j + 1, :, : n * hop], None if emb is None else emb[j:j + 1])
+    return out
+
+
 def _utterances():
     cfg = S.TINY_CONFIG
     out = []
@@ -51,7 +61,9 @@ def _worker(rank, world, port, q):
         blob = D.broadcast_packed_weights(g, torch.device("cpu"), src=0)
         utts = _utterances()
         ys = D.run_utterance_parallel(_fake_forward, utts, torch.device("cpu"), max_batch=2)
-        q.put((rank, blob.numpy().copy(), [y.numpy().copy() for y in ys]))
+        yr = D.run_utterance_parallel(_fake_forward_ragged, utts, torch.device("cpu"), max_batch=3,
+                                      ragged=True, pad_tolerance=0.5)
+        q.put((rank, blob.numpy().copy(), [y.numpy().copy() for y in ys], [y.numpy().copy() for y in yr]))
     finally:
         dist.destroy_process_group()
 
@@ -76,8 +88,8 @@ def test_two_ranks_broadcast_shard_gather():
         p.start()
     res = {}
     for _ in range(world):
-        rank, blob, ys = q.get(timeout=120)
-        res[rank] = (blob, ys)
+        rank, blob, ys, yr = q.get(timeout=120)
+        res[rank] = (blob, ys, yr)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -91,6 +103,15 @@ def test_two_ranks_broadcast_shard_gather():
         want = _fake_forward(torch.from_numpy(u["ppg"])[None], torch.from_numpy(u["sine"])[None],
                              torch.from_numpy(u["lft"])[None], torch.from_numpy(u["spk_emb"])[None])[0].numpy()
         for r in range(world):
-            got = res[r][1][i]
-            assert got.shape == want.shape
-            assert np.allclose(got, want, atol=1e-6)
+            for got in (res[r][1][i], res[r][2][i]):      # same-length buckets, and padded ragged batches
+                assert got.shape == want.shape
+                assert np.allclose(got, want, atol=1e-6)
+
+
+def test_ragged_buckets_bound_the_padding():
+    frames = [1500, 1490, 1400, 900, 880, 300, 1300, 1301]
+    batches = D.bucket_ragged(range(len(frames)), frames, max_batch=3, pad_tolerance=0.125)
+    assert sorted(i for b in batches for i in b) == list(range(len(frames)))
+    for b in batches:
+        assert len(b) <= 3
+        assert min(frames[i] for i in b) >= 0.875 * max(frames[i] for i in b)

@@ -194,6 +194,36 @@ def test_frame_counts_not_multiple_of_four_stay_on_the_fast_path(dev, F):
             assert float((got - want).abs().max()) <= TIGHT * max(1.0, float(want.abs().max())), (i, name)
 
 
+@pytest.mark.parametrize("spk", [True, False])
+def test_ragged_batch_equals_each_utterance_alone(dev, spk):
+    """`lengths` (C ABI: device int32 frame counts): a padded batch of utterances of different
+    lengths must give, for every utterance, the result of running it alone (zero padding at its OWN
+    end, InstanceNorm over its OWN length) - checked against the oracle run per utterance - and
+    zeros in the padding of the output.  The padding of the inputs is filled with garbage."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 71)
+    wf = S.fold_weight_norm(sd)
+    lens = [37, 64, 5, 50]
+    B, F = len(lens), max(lens)
+    hop = cfg.hop
+    b = S.synth_batch(cfg, B, F, 72)
+    ppg, sine, lft = b.ppg.copy(), b.sine.copy(), b.lft.copy()
+    for i, n in enumerate(lens):                       # poison the padding
+        ppg[i, :, n:] = 1e3
+        sine[i, :, n * hop:] = -7.0
+        lft[i, :, n * hop:] = 9.0
+    m = _module(cfg, sd, dev)
+    emb = _to(dev, b.spk_emb)[0] if spk else None
+    with torch.no_grad():
+        y = m(*_to(dev, ppg, sine, lft), emb, lengths=lens).cpu()
+    for i, n in enumerate(lens):
+        ref = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[i:i + 1, :, :n], b.sine[i:i + 1, :, :n * hop],
+                              b.lft[i:i + 1, :, :n * hop], b.spk_emb[i:i + 1] if spk else None)
+        assert float((y[i:i + 1, :, :n * hop] - ref).abs().max()) <= TIGHT * max(1.0, float(ref.abs().max())), (i, n)
+        assert float(y[i, :, n * hop:].abs().max()) == 0.0 if n < F else True
+
+
 def test_batch_items_do_not_bleed(dev):
     """Zero padding is per utterance: item b of a batch == the same utterance run alone
     (InstanceNorm statistics and conv halos never cross batch items)."""
