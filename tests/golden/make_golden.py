@@ -17,6 +17,11 @@ Fixtures written:
   full_forward_cfg2.npz yaml-width generator, B=8, F=600 (BASELINE cfg2): 16 slices + checksums
   inference_f40.npz     ``inference()`` call sequence with the reference SignalGenerator, noise_amp=0
   weight_norm_fold.npz  torch ``remove_weight_norm`` result for three layers (g, v -> w)
+  decode_chain.npz      decode_fastsvc.py:160-189 per utterance for three utterances of different
+                        length: F0Statistics.estimate / .convert (features.py:41-108, std forced to 1),
+                        then ``inference()`` with the converted F0 (noise_amp=0)
+
+    python tests/golden/make_golden.py decode_chain     # only that fixture
 """
 import os
 import sys
@@ -138,6 +143,37 @@ def inference(M):
     print("inference", y.shape, sine.shape)
 
 
+def decode_chain(M):
+    """The caller on the other side of the boundary, decode_fastsvc.py:160-189."""
+    from harana.utils.features import F0Statistics
+    SignalGenerator = import_reference_signal_generator()
+    cfg, seed_w = S.FULL_CONFIG, 201
+    g, _ = build_reference(M, cfg, seed_w)
+    g.remove_weight_norm()
+    sg = SignalGenerator(sample_rate=24000, hop_size=cfg.hop, sine_amp=0.1, noise_amp=0.0, signal_types=["sine"])
+    pad_fn = torch.nn.ReplicationPad1d(0)
+    fs = F0Statistics()
+    frames = [37, 64, 50]
+    batches = [S.synth_batch(cfg, 1, F, 400 + i) for i, F in enumerate(frames)]
+    f0s = [b.f0[0, 0].astype(np.float64) for b in batches]               # (F,) Hz, 0 = unvoiced
+    src_stats = fs.estimate(f0s)                                          # [mean, std] of log f0
+    srcstats = np.array([src_stats[0], 1])                                # decode_fastsvc.py:165,176
+    trgstats = np.array([np.log(330.0), 1])
+    emb = torch.from_numpy(batches[0].spk_emb)                            # one target speaker
+    out = {"frames": np.array(frames), "src_stats": src_stats, "srcstats": srcstats, "trgstats": trgstats,
+           "meta": np.array([seed_w, 400])}
+    for i, b in enumerate(batches):
+        cv = fs.convert(f0s[i], srcstats, trgstats)                        # (F,)
+        f0_tm = torch.FloatTensor(np.expand_dims(cv, 1))
+        with torch.no_grad():
+            y = g.inference(torch.from_numpy(b.ppg[0].T.copy()), f0_tm, torch.from_numpy(b.lft[0].T.copy()),
+                            sg, pad_fn, emb).view(-1).numpy()
+        out[f"cvf0.{i}"] = cv
+        out[f"y.{i}"] = y
+    np.savez_compressed(os.path.join(HERE, "decode_chain.npz"), **out)
+    print("decode_chain", [out[f"y.{i}"].shape for i in range(3)], src_stats)
+
+
 def fold(M):
     cfg = S.TINY_CONFIG
     g, sd = build_reference(M, cfg, 101)
@@ -154,10 +190,9 @@ def fold(M):
 
 if __name__ == "__main__":
     M = import_reference()
-    tiny(M)
-    full(M)
-    inference(M)
-    fold(M)
+    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain"]
+    for name in todo:
+        {"tiny": tiny, "full": full, "inference": inference, "fold": fold, "decode_chain": decode_chain}[name](M)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

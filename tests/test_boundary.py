@@ -193,3 +193,36 @@ def test_launch_shape_table_roundtrip_and_shipped_file():
         assert nw in (1, 2, 4) and wm * wn == 4 and 1 <= tpw <= 16 and algo in (0, 1, 2)
     shipped = A.Plan(S.FULL_CONFIG)
     assert shipped.tuned_shapes() == {k: list(v) for k, v in table.items()}
+
+
+def test_decode_harness_f0_statistics_match_reference_golden(tmp_path):
+    """F0Statistics.estimate / .convert vs the live reference (decode_chain.npz), the
+    device variant of convert, PCM-16 writer round trip, feature-container loader."""
+    import wave
+    from conftest import load_golden
+    from svcc23_fastsvc_amd import decode as Dc
+    g = load_golden("decode_chain.npz")
+    cfg = S.FULL_CONFIG
+    frames = [int(v) for v in g["frames"]]
+    batches = [S.synth_batch(cfg, 1, F, 400 + i) for i, F in enumerate(frames)]
+    f0s = [b.f0[0, 0].astype(np.float64) for b in batches]
+    fs = Dc.F0Statistics()
+    assert np.allclose(fs.estimate(f0s), g["src_stats"], rtol=0, atol=1e-12)
+    for i, f0 in enumerate(f0s):
+        cv = fs.convert(f0, g["srcstats"], g["trgstats"])
+        assert np.allclose(cv, g[f"cvf0.{i}"], rtol=1e-12, atol=0)
+        assert np.array_equal(cv == 0, f0 == 0)                       # unvoiced frames stay unvoiced
+        cvd = Dc.convert_f0_device(torch.from_numpy(f0), g["srcstats"], g["trgstats"]).numpy()
+        assert np.allclose(cvd, cv.astype(np.float32), rtol=1e-6)
+    y = np.array([0.0, 0.5, -0.5, 1.0, -1.0, 1.7, -3.0, 1e-5], dtype=np.float32)
+    pcm = Dc.to_pcm16(y)
+    assert pcm.dtype == np.int16 and list(pcm) == [0, 16384, -16384, 32767, -32767, 32767, -32768, 0]
+    path = str(tmp_path / "a.wav")
+    Dc.write_wav(path, y, 24000)
+    with wave.open(path, "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 24000, len(y))
+        assert np.array_equal(np.frombuffer(w.readframes(len(y)), dtype=np.int16), pcm)
+    feat = str(tmp_path / "u.npz")
+    np.savez(feat, f0=batches[0].f0[0].T, ppg=batches[0].ppg[0].T, lft=batches[0].lft[0].T)
+    u = Dc.load_features(feat)
+    assert u["f0"].shape == (frames[0], 1) and u["ppg"].shape == (frames[0], 144) and u["lft"].shape == (frames[0] * 160, 1)

@@ -410,6 +410,31 @@ def test_winograd_time_convs_match_oracle_taps(dev, algo):
         close(plan.tap(f"up.{i}.a", B, F, ws), taps[f"up.{i}.a"], f"up.{i}.a")
 
 
+def test_batched_decode_equals_the_reference_decode_loop(dev):
+    """the decode harness (F0 mean shift -> device excitation -> ONE ragged batch of the
+    three utterances) against tests/golden/decode_chain.npz, which decode_fastsvc.py:160-189's
+    one-utterance-at-a-time loop produced on the live reference (noise_amp = 0)."""
+    from svcc23_fastsvc_amd import decode as Dc
+    g = load_golden("decode_chain.npz")
+    cfg = S.FULL_CONFIG
+    seed_w = int(g["meta"][0])
+    frames = [int(v) for v in g["frames"]]
+    batches = [S.synth_batch(cfg, 1, F, 400 + i) for i, F in enumerate(frames)]
+    feats = [dict(f0=b.f0[0].T.copy(), ppg=b.ppg[0].T.copy(), lft=b.lft[0].T.copy()) for b in batches]
+    m = _module(cfg, S.synth_state_dict(cfg, seed_w), dev, fold=True)
+    sg = A.SignalGenerator(sample_rate=24000, hop_size=cfg.hop, sine_amp=0.1, noise_amp=0.0, signal_types=["sine"])
+    ys = Dc.decode_utterances(m, feats, sg, dev, trg_emb=batches[0].spk_emb,
+                              src_f0_stats=[g["srcstats"]] * 3, trg_f0_stats=g["trgstats"],
+                              max_batch=8, pad_tolerance=0.9)               # all three in one batch
+    for i, y in enumerate(ys):
+        want = g[f"y.{i}"]
+        assert y.shape == want.shape
+        # fp32 phase of the excitation differs from the reference's fp32 cumsum by < 1e-4 cycles here
+        assert float(np.abs(y - want).max()) <= TOL, i
+    pcm = [Dc.to_pcm16(y) for y in ys]
+    assert all(p.dtype == np.int16 and len(p) == f * cfg.hop for p, f in zip(pcm, frames))
+
+
 def test_signal_generator_matches_reference_sine(dev):
     """SignalGenerator on the GPU vs the reference's own output (golden, noise_amp=0):
     the reference accumulates the phase in fp32 (features.py:188-190), ours in f64 mod 1, so the
