@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Randomised parity sweep on the GPU (developer tool): random (B, F), ragged or not, with / without
+speaker embedding, table / cost-model / forced-Winograd launch choices, vs the CPU oracle."""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import svcc23_fastsvc_amd as A
+from svcc23_fastsvc_amd import synth as S
+from oracle import fastsvc_oracle as O
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+rng = random.Random(seed)
+cfg = S.FULL_CONFIG
+dev = torch.device("cuda:0")
+sd = S.synth_state_dict(cfg, 900 + seed)
+wf = S.fold_weight_norm(sd)
+worst = 0.0
+for it in range(n):
+    table = rng.random() < 0.5
+    plan = A.Plan(cfg, load_shipped_table=table)
+    blob = plan.pack(sd).to(dev)
+    B = rng.choice([1, 1, 2, 3, 5, 8])
+    F = rng.choice([1, 2, 3, 4, 6, 9, 17, 32, 45, 63, 64, 100, 131, 150, 257])
+    spk = rng.random() < 0.8
+    ragged = B > 1 and rng.random() < 0.4
+    lens = [rng.randint(1, F) for _ in range(B)] if ragged else None
+    if lens: lens[rng.randrange(B)] = F
+    b = S.synth_batch(cfg, B, F, 5000 + it + 100 * seed)
+    ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft)]
+    emb = torch.from_numpy(b.spk_emb).to(dev) if spk else None
+    y = plan.forward(blob, *ins, emb, lengths=lens).cpu()
+    err = 0.0
+    if lens is None:
+        ref = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb if spk else None)
+        err = float((y - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    else:
+        for i, m in enumerate(lens):
+            ref = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[i:i+1, :, :m], b.sine[i:i+1, :, :m*160],
+                                  b.lft[i:i+1, :, :m*160], b.spk_emb[i:i+1] if spk else None)
+            e = float((y[i:i+1, :, :m*160] - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+            err = max(err, e)
+            assert float(y[i, :, m*160:].abs().max()) == 0.0 if m < F else True
+    worst = max(worst, err)
+    flag = "" if err <= 1e-4 else "   <-- ABOVE 1e-4"
+    print(f"B={B} F={F} spk={spk} lens={lens} table={table}: rel err {err:.2e}{flag}", flush=True)
+print(f"worst {worst:.3e}")
