@@ -750,21 +750,6 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (g_tune.plan) {
             std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
             auto it = g_tune.plan->tuned.find(key);
-            const bool exact = it != g_tune.plan->tuned.end();
-            if (!exact && !g_tune.tuning) {
-                // no entry for this (B, T): take the layer's entry measured at the nearest problem size
-                // (total columns, log scale) - the shapes are generic, only their ranking is size-bound
-                const std::string prefix = std::string(layer) + "|";
-                const double want = std::log((double)p.B * (double)p.T);
-                double best_d = 1e30;
-                for (auto jt = g_tune.plan->tuned.lower_bound(prefix);
-                     jt != g_tune.plan->tuned.end() && jt->first.compare(0, prefix.size(), prefix) == 0; ++jt) {
-                    int kb = 0, kt = 0;
-                    if (std::sscanf(jt->first.c_str() + prefix.size(), "%d|%d", &kb, &kt) != 2 || kb < 1 || kt < 1) continue;
-                    const double d = std::fabs(std::log((double)kb * (double)kt) - want);
-                    if (d < best_d) { best_d = d; it = jt; }
-                }
-            }
             if (it != g_tune.plan->tuned.end()) {
                 // a loaded table may be stale: only shapes this launch is compiled for are taken
                 for (const Cand& cd : cands)
@@ -773,15 +758,6 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                         best = cd; p.tpw = it->second.tpw;
                         have = true;
                     }
-                if (have && !exact) {
-                    // tiles-per-workgroup measured at another size: keep at least two rounds of workgroups
-                    const int NT = (best.algo >= 1 ? 32 : 16) * best.NW * best.WN;
-                    const long ntx = (p.T + NT - 1) / NT;
-                    const int cMW = best.algo == 2 ? 2 : c.MW;
-                    const long gy = ((best.algo == 2 ? c.cout / 32 : c.ngroups) + best.WM - 1) / best.WM;
-                    const long slots = 256L * conv_ws_resident(cMW, best.NW, best.algo >= 1 ? (int)MODE_WINO : p.mode, epi_kind);
-                    while (p.tpw > 1 && ((ntx + p.tpw - 1) / p.tpw) * gy * zb < 2 * slots) --p.tpw;
-                }
             }
         }
         if (!have && g_tune.tuning && g_tune.plan) {
@@ -827,8 +803,14 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         static const double startup_us = std::getenv("FASTSVC_STARTUP_US") ? std::atof(std::getenv("FASTSVC_STARTUP_US")) : 4.0;
         double best_t = 1e30;
         for (const Cand& cd : cands) {
-            if ((cd.algo >= 1) != (wino_ok && wino_env >= 1)) continue;      // Winograd only on request (or by table / tuner)
-            if (wino_env >= 1 && wino_ok && c.wino2 && (cd.algo == 2) != (wino_env == 2)) continue;   // FASTSVC_WINO=2: the MW = 2 variants
+            // Without a table entry the model takes Winograd wherever the layer has it, the 32-channel
+            // grouping (two workgroups per CU) when that exists - measured better than direct on cfg1
+            // and cfg2 (0.56 vs 0.62 ms, 2.24 vs 2.32 ms).  C = 24 layers (MW == 2) stay direct: their
+            // Winograd variant loses to the scalar phase-plane staging.  FASTSVC_WINO = 0 / 1 / 2
+            // forces direct / layer grouping / 32-channel grouping.
+            const int wino_pref = wino_env >= 0 ? wino_env : (c.MW == 2 ? 0 : 2);
+            if ((cd.algo >= 1) != (wino_ok && wino_pref >= 1)) continue;
+            if (wino_pref >= 1 && wino_ok && c.wino2 && (cd.algo == 2) != (wino_pref == 2)) continue;
             const int NT = (cd.algo >= 1 ? 32 : 16) * cd.NW * cd.WN;
             const int cMW = cd.algo == 2 ? 2 : c.MW;
             const long ntx = (p.T + NT - 1) / NT;

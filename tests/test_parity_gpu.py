@@ -388,9 +388,12 @@ def test_winograd_time_convs_match_oracle_taps(dev, algo):
     kern = {r["layer"]: r["kernel"] for r in recs}
     n_wino = sum(1 for k in kern.values() if k.startswith("conv_mfma_ws<") and k.split(",")[4] == "4")
     # eligible: down.k c2/c3 and film.k conv/heads for k = 1..3, film.0.heads, conv_first of blocks
-    # 0..2 = 16 launches; the 48-channel ones (stage 1, film.0.heads, up.2.conv_first) have no
-    # 32-channel grouping, which leaves 11 for algo 2 (those entries are ignored -> cost model)
-    assert n_wino == (16 if algo == 1 else 11), sorted(kern.items())
+    # 0..2 = 16 launches.  The 48-channel ones (stage 1, film.0.heads, up.2.conv_first) have no
+    # 32-channel grouping: for algo 2 their entries are ignored and the cost model picks for them
+    # (Winograd with the layer's own grouping), so 11 launches run with 32-channel groups (MW = 2).
+    assert n_wino == 16, sorted(kern.items())
+    n_mw2 = sum(1 for k in kern.values() if k.startswith("conv_mfma_ws<2,") and k.split(",")[4] == "4")
+    assert n_mw2 == (0 if algo == 1 else 11), sorted(kern.items())
     ref, taps = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft,
                                 b.spk_emb, return_taps=True)
     assert float((y.cpu() - ref).abs().max()) <= TIGHT
