@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3"])
+    ap.add_argument("--storage", default="float32", choices=["float32", "bfloat16"],
+                    help="workspace tensor storage: float32 = the parity path (default, what `value` is quoted "
+                         "on); bfloat16 = BASELINE config 3's dtype (fp32 arithmetic, bf16-activation accuracy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autotune", action="store_true",
                     help="run the untimed device-side autotune pass (cf. cudnn.benchmark) instead of "
@@ -172,7 +175,7 @@ def main():
     wl = S.WORKLOADS[args.workload]
     B, F = wl["B"], wl["F"]
     T = F * cfg.hop
-    plan = A.Plan(cfg, load_shipped_table=not args.no_table)
+    plan = A.Plan(cfg, load_shipped_table=not args.no_table, storage=args.storage)
     n_table = sum(1 for k in plan.tuned_shapes() if k.split("|")[1] == str(B))
 
     # weights: rank 0 folds + packs, everyone receives the kernel-layout blob (RCCL broadcast)
@@ -240,7 +243,8 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.storage == "float32" else "f32 arithmetic, bf16 activation storage",
+            "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']} per GPU, F={F} frames, T={T} samples, "
                                    f"generator fastsvc.yaml (144->[192,96,48,24], x[2,4,4,5]), spk_emb on",
                        "global_batch": world * B, "utterance_samples": T,

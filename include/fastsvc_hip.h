@@ -72,6 +72,15 @@ const char* fastsvc_last_error(void);       /* thread-local text of the last fai
 int fastsvc_plan_create(const fastsvc_config* cfg, fastsvc_plan** out_plan);
 void fastsvc_plan_destroy(fastsvc_plan* plan);
 
+/* Activation storage in the workspace: 0 = float32 (default; the parity path), 1 = bfloat16 - every
+ * intermediate tensor (conv outputs, FiLM-affined tensors, scale / shift) is stored as bfloat16, which
+ * halves the traffic of the HBM-bound layers and the workspace; arithmetic (fp32 MFMA), weights,
+ * InstanceNorm sums, inputs and output stay float32.  Accuracy is that of bf16 activations (about 1e-2
+ * of the output range), so this is the mode for BASELINE config 3, not for the 1e-3 parity bar.
+ * Set it before fastsvc_workspace_bytes / fastsvc_forward; needs F % 4 == 0 and the yaml channel counts. */
+int fastsvc_plan_set_storage(fastsvc_plan* plan, int32_t dtype);
+int fastsvc_plan_get_storage(const fastsvc_plan* plan);
+
 /* Size in bytes of the packed weight blob (device resident; also what rank 0 broadcasts over RCCL). */
 size_t fastsvc_weight_blob_bytes(const fastsvc_plan* plan);
 

@@ -35,19 +35,41 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# (source, extra flags, object name): fastsvc_kernels.hip is compiled twice - float32 and bfloat16
+# activation storage (namespace fastsvc / fastsvc::bf16) - the objects are built in parallel
+UNITS = [
+    ("fastsvc_kernels.hip", [], "kernels_f32.o"),
+    ("fastsvc_kernels.hip", ["-DFASTSVC_ACT_BF16=1"], "kernels_bf16.o"),
+    ("fastsvc_plan.cpp", [], "plan.o"),
+    ("fastsvc_signal.hip", [], "signal.o"),
+]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-munsafe-fp-atomics", "-x", "hip",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    import tempfile
+    hipcc = _hipcc()
+    common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+              "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    with tempfile.TemporaryDirectory(prefix="fastsvc_build_") as tmp:
+        procs = []
+        for src, extra, obj in UNITS:
+            cmd = [hipcc, *common, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", os.path.join(tmp, obj)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for cmd, pr in procs:
+            out, _ = pr.communicate()
+            if pr.returncode != 0:
+                raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
+        link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + [os.path.join(tmp, u[2]) for u in UNITS] + \
+               ["-o", LIB_PATH + ".tmp"]
+        if verbose:
+            print(" ".join(link), file=sys.stderr)
+        res = subprocess.run(link, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

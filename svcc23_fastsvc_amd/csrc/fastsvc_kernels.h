@@ -148,4 +148,16 @@ struct SpkBlock {
 hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks, int B, int E,
                            hipStream_t stream);
 
+// The same launchers compiled with bfloat16 activation storage (fastsvc_kernels.hip built with
+// -DFASTSVC_ACT_BF16): every pointer to an activation tensor then addresses bfloat16 elements (strides
+// stay in elements); weights, biases, the raw signals (r1x), statistics and speaker biases stay float32.
+namespace bf16 {
+hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
+hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, long w_sig, long b_sig,
+                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream);
+hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
+                                int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream);
+hipError_t launch_act_convert(const float* src, float* dst_bf16, long n, hipStream_t stream);
+}  // namespace bf16
+
 }  // namespace fastsvc

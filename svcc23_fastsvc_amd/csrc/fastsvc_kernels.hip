@@ -22,6 +22,9 @@
 #include "fastsvc_kernels.h"
 
 namespace fastsvc {
+#ifdef FASTSVC_ACT_BF16
+namespace bf16 {          // second compilation of this file: bfloat16 activation storage (see act_t below)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -672,9 +675,61 @@ __device__ __forceinline__ f32x4 keep_first(f32x4 v, int nv) {      // zero the 
 __device__ __forceinline__ int row_valid(int t, int T) { return min(4, max(0, T - t)); }
 // The variants that sit at the 128-VGPR limit are compiled WITHOUT the row-end handling (they are the
 // full-rate shapes, whose rows are 160 F long); run_conv only launches them when T % 4 == 0.
+// ---- activation storage type ------------------------------------------------------------------
+// The file is compiled twice: as is (activations float32 in HBM: the parity path) and with
+// -DFASTSVC_ACT_BF16 (namespace fastsvc::bf16: every workspace tensor - conv outputs, FiLM-affined
+// tensors, scale / shift - is stored as bfloat16, halving the traffic of the HBM-bound layers; the
+// arithmetic, the LDS windows, the weights and the InstanceNorm sums stay float32 / float64).
+// All offsets in the kernels are written in "float bytes" (elements * 4); the bf16 helpers halve them.
+#ifdef FASTSVC_ACT_BF16
+typedef unsigned short act_t;
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float x) {            // round to nearest even
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ f32x4 act_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(r, voff >> 1, soff >> 1, 0);
+    return f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                 __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+}
+__device__ __forceinline__ float act_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(r, voff >> 1, soff >> 1, 0);
+    return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+__device__ __forceinline__ void act_store4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
+    u32x2v w;
+    w.x = f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16);
+    w.y = f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, voff >> 1, 0, 0);
+}
+__device__ __forceinline__ void act_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
+    if (nv >= 4) {
+        act_store4(r, voff, v);
+    } else {
+        const float e0 = v[0], e1 = v[1], e2 = v[2];
+        const int far = 0x7ffffff0, o = voff >> 1;
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(e0), r, nv >= 1 ? o : far, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(e1), r, nv >= 2 ? o + 2 : far, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(e2), r, nv >= 3 ? o + 4 : far, 0, 0);
+    }
+}
+#else
+typedef float act_t;
+__device__ __forceinline__ f32x4 act_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return buf_load4(r, voff, soff); }
+__device__ __forceinline__ float act_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return buf_load1(r, voff, soff); }
+__device__ __forceinline__ void act_store4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) { buf_store4(r, voff, v); }
+__device__ __forceinline__ void act_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) { buf_store4_n(r, voff, v, nv); }
+#endif
+// descriptor over `nelems` activation elements starting `elem_off` elements after `base`
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const float* base, long elem_off, long nelems) {
+    const act_t* q = reinterpret_cast<const act_t*>(base) + elem_off;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(q), 0, (int)(nelems * (long)sizeof(act_t)), 0x00020000);
+}
+
 template <bool TAIL>
 __device__ __forceinline__ void store_row4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
-    if constexpr (TAIL) buf_store4_n(r, voff, v, nv); else buf_store4(r, voff, v);
+    if constexpr (TAIL) act_store4_n(r, voff, v, nv); else act_store4(r, voff, v);
 }
 template <bool TAIL>
 __device__ __forceinline__ f32x4 keep_row(f32x4 v, int nv) {
@@ -730,11 +785,11 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
             if (flags & F_POST_LRELU) {
                 v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
             }
-            if (p.res) v += buf_load4(R.res, off, 0);
+            if (p.res) v += act_load4(R.res, off, 0);
             if (p.r1x) v += buf_load4(R.r1x, t * 4, 0) * r1w + r1b;
             if (p.y) store_row4<TAIL>(R.y, off, v, nv);
             if (flags & (F_STATS | F_AFF_OUT)) {
-                const f32x4 u = keep_row<TAIL>(buf_load4(R.ss, off, 0) * v + buf_load4(R.ss, off, shift_soff), nv);
+                const f32x4 u = keep_row<TAIL>(act_load4(R.ss, off, 0) * v + act_load4(R.ss, off, shift_soff), nv);
                 if (flags & F_AFF_OUT) store_row4<TAIL>(R.y2, off, u, nv);
                 s1[m] += (u.x + u.y) + (u.z + u.w);
                 s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
@@ -780,12 +835,12 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
                 const bool ok = cok && t < p.T;
                 nv[g] = TAIL ? (ok ? row_valid(t, p.T) : 0) : 4;
                 off[g] = ok ? (rowoff + t) * 4 : OOB_OFF;
-                if (EPI == EPI_RES) l0[g] = buf_load4(R.res, off[g], 0);
+                if (EPI == EPI_RES) l0[g] = act_load4(R.res, off[g], 0);
                 if (EPI == EPI_RANK1) l0[g] = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
                 if (EPI == EPI_AFF) {
-                    l0[g] = buf_load4(R.res, off[g], 0);              // zero-length descriptor when absent
-                    l1[g] = buf_load4(R.ss, off[g], 0);
-                    l2[g] = buf_load4(R.ss, off[g], shift_soff);
+                    l0[g] = act_load4(R.res, off[g], 0);              // zero-length descriptor when absent
+                    l1[g] = act_load4(R.ss, off[g], 0);
+                    l2[g] = act_load4(R.ss, off[g], shift_soff);
                 }
             }
             #pragma unroll
@@ -850,8 +905,8 @@ __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiR
                     #pragma unroll
                     for (int g = 0; g < G; ++g)
                         if (q0 + g < S) {
-                            l1[g] = buf_load4(R.ss, off0 + (q0 + g) * 16, 0);
-                            l2[g] = buf_load4(R.ss, off0 + (q0 + g) * 16, shift_soff);
+                            l1[g] = act_load4(R.ss, off0 + (q0 + g) * 16, 0);
+                            l2[g] = act_load4(R.ss, off0 + (q0 + g) * 16, shift_soff);
                         }
                 }
                 #pragma unroll
@@ -903,7 +958,7 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
                 const bool ok = cok && t + 4 * h < p.T;
                 nv[h] = cok ? row_valid(t + 4 * h, p.T) : 0;
                 off[h] = ok ? (rowoff + t + 4 * h) * 4 : OOB_OFF;
-                if (EPI == EPI_RES) l0[h] = buf_load4(R.res, off[h], 0);
+                if (EPI == EPI_RES) l0[h] = act_load4(R.res, off[h], 0);
                 if (EPI == EPI_RANK1) l0[h] = buf_load4(R.r1x, ok ? (t + 4 * h) * 4 : OOB_OFF, 0);
             }
             const f32x4 m1 = acc[1][n][m], m2 = acc[2][n][m];
@@ -920,7 +975,7 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
                 w.z = fmaxf(w.z, w.z * slope); w.w = fmaxf(w.w, w.w * slope);
                 if (EPI == EPI_RES) w += l0[h];
                 if (EPI == EPI_RANK1) w += l0[h] * r1w + r1b;
-                buf_store4_n(R.y, off[h], w, nv[h]);
+                act_store4_n(R.y, off[h], w, nv[h]);
             }
         }
     }
@@ -946,8 +1001,8 @@ __device__ __forceinline__ void ws_epilogue_dec2(const ConvParams& p, const EpiR
             const bool ok = cok && t < p.T;
             const int nv = ok ? row_valid(t, p.T) : 0;
             const int off = ok ? (rowoff + t) * 4 : OOB_OFF;
-            buf_store4_n(R.y, off, acc[0][n][m] + bias, nv);
-            buf_store4_n(R.y2, off, acc[1][n][m] + bias2, nv);
+            act_store4_n(R.y, off, acc[0][n][m] + bias, nv);
+            act_store4_n(R.y2, off, acc[1][n][m] + bias2, nv);
         }
     }
 }
@@ -1061,7 +1116,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         // tensor (columns before the first / after the last row, channel padding) read as 0 in
         // hardware, everything else is real memory and is masked by `okmask` where it is padding.
         const __amdgpu_buffer_rsrc_t xr =
-            make_rsrc(p.x + (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
+            act_rsrc(p.x, (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
 
         // unconditional loads of unit `un` into a register set; validity in the mask
         auto pload = [&](int un, f32x4 (&px)[ITEMS], unsigned& okmask) {
@@ -1083,18 +1138,18 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                     const unsigned src0 = udiv_small((unsigned)tc, p.s);
                     const int ph = tc - (int)src0 * p.s;
                     const int o = (ro + (int)src0) * 4;
-                    px[i].x = buf_load1(xr, o, soff);
-                    px[i].y = buf_load1(xr, o + 4 * (int)udiv_small(ph + 1, p.s), soff);
-                    px[i].z = buf_load1(xr, o + 4 * (int)udiv_small(ph + 2, p.s), soff);
-                    px[i].w = buf_load1(xr, o + 4 * (int)udiv_small(ph + 3, p.s), soff);
+                    px[i].x = act_load1(xr, o, soff);
+                    px[i].y = act_load1(xr, o + 4 * (int)udiv_small(ph + 1, p.s), soff);
+                    px[i].z = act_load1(xr, o + 4 * (int)udiv_small(ph + 2, p.s), soff);
+                    px[i].w = act_load1(xr, o + 4 * (int)udiv_small(ph + 3, p.s), soff);
                 } else if (MODE == MODE_DECIMATE || MODE == MODE_DEC2) {
                     const int o = (ro + t * p.s) * 4;           // x[..., ::s]; negative t -> out of range -> 0
-                    px[i].x = buf_load1(xr, o, soff);
-                    px[i].y = buf_load1(xr, o + 4 * p.s, soff);
-                    px[i].z = buf_load1(xr, o + 8 * p.s, soff);
-                    px[i].w = buf_load1(xr, o + 12 * p.s, soff);
+                    px[i].x = act_load1(xr, o, soff);
+                    px[i].y = act_load1(xr, o + 4 * p.s, soff);
+                    px[i].z = act_load1(xr, o + 8 * p.s, soff);
+                    px[i].w = act_load1(xr, o + 12 * p.s, soff);
                 } else {
-                    px[i] = buf_load4(xr, (ro + t) * 4, soff);
+                    px[i] = act_load4(xr, (ro + t) * 4, soff);
                 }
             }
             if (p.dbg & DBG_NO_LOAD) okmask = 0;
@@ -1189,12 +1244,12 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         {
             const long ct = (long)p.COUT * p.ldy;       // rows of y / y2 / res / scale / shift at the output pitch
             const float* nul = p.bias;                  // any valid address for unused descriptors
-            R.y = make_rsrc(p.y ? p.y + (long)sig * p.y_sig + (long)b * p.y_b : nul, p.y ? ct : 0);
+            R.y = act_rsrc(p.y ? p.y : nul, p.y ? (long)sig * p.y_sig + (long)b * p.y_b : 0, p.y ? ct : 0);
             const bool has_y2 = DEC2 || (flags & F_AFF_OUT);
-            R.y2 = make_rsrc(has_y2 ? p.y2 + (long)sig * p.y2_sig + (long)b * p.y2_b : nul, has_y2 ? ct : 0);
-            R.res = make_rsrc(p.res ? p.res + (long)sig * p.res_sig + (long)b * p.res_b : nul, p.res ? ct : 0);
-            R.ss = make_rsrc((flags & (F_STATS | F_AFF_OUT)) ? p.ss_out + (long)b * p.ss_out_b : nul,
-                             (flags & (F_STATS | F_AFF_OUT)) ? 2 * ct : 0);
+            R.y2 = act_rsrc(has_y2 ? p.y2 : nul, has_y2 ? (long)sig * p.y2_sig + (long)b * p.y2_b : 0, has_y2 ? ct : 0);
+            R.res = act_rsrc(p.res ? p.res : nul, p.res ? (long)sig * p.res_sig + (long)b * p.res_b : 0, p.res ? ct : 0);
+            const bool has_ss = (flags & (F_STATS | F_AFF_OUT)) != 0;
+            R.ss = act_rsrc(has_ss ? p.ss_out : nul, has_ss ? (long)b * p.ss_out_b : 0, has_ss ? 2 * ct : 0);
             R.r1x = make_rsrc(p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nul, p.r1x ? p.ldy : 0);
         }
         setup_shared();
@@ -1282,6 +1337,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
     }
 }
 
+#ifndef FASTSVC_ACT_BF16
 template <int MW, int NW>
 static hipError_t launch_conv_generic(const ConvParams& p, int nsig, hipStream_t stream) {
     constexpr int WM = 1, WN = 4;
@@ -1294,10 +1350,13 @@ static hipError_t launch_conv_generic(const ConvParams& p, int nsig, hipStream_t
     return hipGetLastError();
 }
 
+#endif   // generic kernel: float32 storage only
+
 // tile shapes the polyphase variant is compiled for: three accumulator sets, so NW * MW <= 4
 template <int MW, int NW, int WM, int WN>
 constexpr bool poly_shape() { return WM != 4 && ((MW == 3 && NW == 1) || (MW == 2 && NW <= 2)); }
 
+#ifndef FASTSVC_ACT_BF16      // storage-independent host queries: defined once
 int conv_ws_resident(int MW, int NW, int mode, int epi_kind) {
     // workgroups per CU the register budget of the compiled variant allows (see ws_min_waves)
     if (mode == MODE_POLY) return (MW <= 2 && NW == 1) ? 2 : 1;
@@ -1317,6 +1376,8 @@ bool conv_ws_tail_ok(int MW, int NW, int mode, int epi_kind, int S) {
 bool conv_poly_shape(int MW, int NW, int WM, int WN) {
     return WM != 4 && ((MW == 3 && NW == 1) || (MW == 2 && NW <= 2)) && WM * WN == 4;
 }
+
+#endif
 
 template <int MW, int NW, int WM, int WN>
 static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t stream) {
@@ -1406,6 +1467,7 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     return hipGetLastError();
 }
 
+#ifndef FASTSVC_ACT_BF16
 bool conv_pipe_supported(const ConvParams& p) {
     if (p.KC != 24) return false;                              // 6 k-steps per tap per chunk, compiled in
     if (p.flags & F_PRE_AFFINE) return false;                  // only the generic kernel fuses the affine
@@ -1422,6 +1484,8 @@ bool conv_pipe_supported(const ConvParams& p) {
     return p.mode == MODE_STRETCH || p.mode == MODE_DECIMATE;
 }
 
+#endif
+
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream) {
     if (cfg.pipe) {
 #define FASTSVC_PIPE(mw, nw, wm, wn) \
@@ -1434,12 +1498,14 @@ hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t s
 #undef FASTSVC_PIPE
         return hipErrorInvalidValue;
     }
+#ifndef FASTSVC_ACT_BF16
 #define FASTSVC_CASE(mw, nw) if (cfg.MW == mw && cfg.NW == nw) return launch_conv_generic<mw, nw>(p, cfg.nsig, stream);
     FASTSVC_CASE(1, 1) FASTSVC_CASE(1, 2) FASTSVC_CASE(1, 4)
     FASTSVC_CASE(2, 1) FASTSVC_CASE(2, 2) FASTSVC_CASE(2, 4)
     FASTSVC_CASE(3, 1) FASTSVC_CASE(3, 2) FASTSVC_CASE(3, 4)
 #undef FASTSVC_CASE
-    return hipErrorInvalidValue;
+#endif
+    return hipErrorInvalidValue;      // (the generic kernel exists for float32 storage only)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1465,19 +1531,30 @@ void in1_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
     }
     const float* ws = w + sig * w_sig;
     const float* bs = bias + sig * b_sig;
-    float* yb = y + (long)z * C * ld;
+    act_t* yb = reinterpret_cast<act_t*>(y) + (long)z * C * ld;
     const bool full = (t + 3 < T) && ((ld & 3) == 0);
     for (int co = 0; co < C; ++co) {
         const float w0 = ws[co * 3 + 0], w1 = ws[co * 3 + 1], w2 = ws[co * 3 + 2], bb = bs[co];
         float o[4];
         #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = bb + (w0 * xv[i] + w1 * xv[i + 1]) + w2 * xv[i + 2];
-        float* yr = yb + (long)co * ld + t;
+        act_t* yr = yb + (long)co * ld + t;
+#ifdef FASTSVC_ACT_BF16
+        if (full) {
+            u32x2v w;
+            w.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
+            w.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+            *reinterpret_cast<u32x2v*>(yr) = w;
+        } else {
+            for (int i = 0; i < 4 && t + i < T; ++i) yr[i] = (act_t)f32_to_bf16_bits(o[i]);
+        }
+#else
         if (full) {
             *reinterpret_cast<f32x4*>(yr) = f32x4{o[0], o[1], o[2], o[3]};
         } else {
             for (int i = 0; i < 4 && t + i < T; ++i) yr[i] = o[i];
         }
+#endif
     }
 }
 
@@ -1504,20 +1581,36 @@ void pointwise_out_kernel(const float* __restrict__ x, const float* __restrict__
             for (int i = 0; i < 4 && t + i < ld; ++i) y[((long)b * O + o) * ld + t + i] = 0.f;
         return;
     }
-    const float* xb = x + (long)b * C * ld;
+    const act_t* xb = reinterpret_cast<const act_t*>(x) + (long)b * C * ld;
     const bool full = (t + 3 < T) && ((ld & 3) == 0);
+    auto ld1 = [&](long idx) -> float {
+#ifdef FASTSVC_ACT_BF16
+        return __builtin_bit_cast(float, (unsigned)xb[idx] << 16);
+#else
+        return xb[idx];
+#endif
+    };
+    auto ld4 = [&](long idx) -> f32x4 {
+#ifdef FASTSVC_ACT_BF16
+        const u32x2v v = *reinterpret_cast<const u32x2v*>(xb + idx);
+        return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                     __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
+#else
+        return *reinterpret_cast<const f32x4*>(xb + idx);
+#endif
+    };
     for (int o = 0; o < O; ++o) {
         f32x4 acc = f32x4{bias[o], bias[o], bias[o], bias[o]};
         if (full) {
             for (int c = 0; c < C; ++c)
-                acc += *reinterpret_cast<const f32x4*>(xb + (long)c * ld + t) * w[o * C + c];
+                acc += ld4((long)c * ld + t) * w[o * C + c];
             *reinterpret_cast<f32x4*>(y + ((long)b * O + o) * ld + t) = acc;
         } else {
             for (int i = 0; i < 4 && t + i < ld; ++i) {
                 float a = 0.f;
                 if (t + i < T) {
                     a = bias[o];
-                    for (int c = 0; c < C; ++c) a += xb[(long)c * ld + t + i] * w[o * C + c];
+                    for (int c = 0; c < C; ++c) a += ld1((long)c * ld + t + i) * w[o * C + c];
                 }
                 y[((long)b * O + o) * ld + t + i] = a;
             }
@@ -1532,6 +1625,20 @@ hipError_t launch_pointwise_out(const float* x, const float* w, const float* bia
     return hipGetLastError();
 }
 
+#ifdef FASTSVC_ACT_BF16
+// float32 -> bfloat16 copy of an external input (the PPG) into the workspace
+__global__ __launch_bounds__(256)
+void act_convert_kernel(const float* __restrict__ src, act_t* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (act_t)f32_to_bf16_bits(src[i]);
+}
+
+hipError_t launch_act_convert(const float* src, float* dst, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(act_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       src, reinterpret_cast<act_t*>(dst), n);
+    return hipGetLastError();
+}
+#else
 // ---------------------------------------------------------------------------------------------
 // Speaker bias p = Linear(F.normalize(spk_emb)) for every up block (fastsvc.py:135-137).
 // grid = (B, nblocks); one wave per output channel, lanes stride over the embedding.
@@ -1588,4 +1695,9 @@ hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks
     return hipGetLastError();
 }
 
+#endif   // speaker projection: storage independent, defined once
+
+#ifdef FASTSVC_ACT_BF16
+}  // namespace bf16
+#endif
 }  // namespace fastsvc

@@ -116,6 +116,7 @@ struct fastsvc_plan {
     std::vector<std::pair<PackedConv*, PackSource>> pack_jobs;
     std::vector<RawParam*> raw_jobs;
     double flops_per_sample = 0.0;
+    int storage = 0;                    // activation storage in the workspace: 0 float32, 1 bfloat16
     // autotuned launch choices (fastsvc_autotune), keyed by "layer|B|T"; guarded by tune_mu
     struct Choice { int NW, WM, WN, tpw, algo; };    // algo: 0 direct / as launched, 1 Winograd F(2,3)
     mutable std::mutex tune_mu;
@@ -532,31 +533,33 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
     int64_t hop = 1;
     for (int i = 0; i < n; ++i) hop *= P.cfg.upsampling_scales[i];
     const int64_t T = hop * F;
-    ws.add("sig", 2, B, T);                                   // [lft ; sine] raw signals
+    const size_t ae = P.storage == 1 ? 2 : sizeof(float);      // activation element size
+    ws.add("sig", 2, B, T);                                   // [lft ; sine] raw signals (always float32)
+    if (P.storage == 1) ws.add("ppg_act", B, P.cfg.in_channels, F, ae);
     int64_t Tk = T;
     for (int k = 0; k < n; ++k) {
         const DownStage& d = P.down[k];
         Tk = Tk / d.scale;
         const std::string s = std::to_string(k);
-        if (k > 0) ws.add("down_r." + s, 2 * B, d.C, Tk);
-        ws.add("down_c1." + s, 2 * B, d.C, Tk);
-        ws.add("down_c2." + s, 2 * B, d.C, Tk);
-        ws.add("down_h." + s, 2 * B, d.C, Tk);               // [lft batch ; sine batch]
-        ws.add("film_u." + s, B, 2 * d.C, Tk);               // channels [lft ; sine]
-        ws.add("ss." + s, B, 2 * d.C, Tk);                   // channels [scale ; shift]
+        if (k > 0) ws.add("down_r." + s, 2 * B, d.C, Tk, ae);
+        ws.add("down_c1." + s, 2 * B, d.C, Tk, ae);
+        ws.add("down_c2." + s, 2 * B, d.C, Tk, ae);
+        ws.add("down_h." + s, 2 * B, d.C, Tk, ae);               // [lft batch ; sine batch]
+        ws.add("film_u." + s, B, 2 * d.C, Tk, ae);               // channels [lft ; sine]
+        ws.add("ss." + s, B, 2 * d.C, Tk, ae);                   // channels [scale ; shift]
     }
     int64_t Tin = F;
     for (int i = 0; i < n; ++i) {
         const UpStage& u = P.up[i];
         const int64_t Tout = Tin * u.scale;
         const std::string s = std::to_string(i);
-        ws.add("up." + s + ".a", B, u.C, Tin);
-        ws.add("up." + s + ".xr", B, u.C, Tout);
-        ws.add("up." + s + ".u1", B, u.C, Tout);      // scale * t0 + shift      (fastsvc.py:131-132)
-        ws.add("up." + s + ".xmid", B, u.C, Tout);
-        ws.add("up." + s + ".u2", B, u.C, Tout);      // scale * xmid + shift
-        ws.add("up." + s + ".u3", B, u.C, Tout);      // scale * t2 + shift
-        ws.add("up." + s + ".out", B, u.C, Tout);
+        ws.add("up." + s + ".a", B, u.C, Tin, ae);
+        ws.add("up." + s + ".xr", B, u.C, Tout, ae);
+        ws.add("up." + s + ".u1", B, u.C, Tout, ae);      // scale * t0 + shift      (fastsvc.py:131-132)
+        ws.add("up." + s + ".xmid", B, u.C, Tout, ae);
+        ws.add("up." + s + ".u2", B, u.C, Tout, ae);      // scale * xmid + shift
+        ws.add("up." + s + ".u3", B, u.C, Tout, ae);      // scale * t2 + shift
+        ws.add("up." + s + ".out", B, u.C, Tout, ae);
         ws.add("up." + s + ".spk", B, u.C, 1);
         ws.add("up." + s + ".stats", 3 * B, u.C, 2, sizeof(double));
         Tin = Tout;
@@ -646,6 +649,10 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                     const char* layer = "") {
     p.CIN = c.cin; p.KC = c.KC; p.nchunks = c.nchunks;
     p.w = blob + c.w_off; p.w_sig = pair_w_stride;
+    const bool act_bf16 = g_tune.plan && g_tune.plan->storage == 1;
+    auto launch = [&](const ConvParams& q, const ConvLaunch& Lq, hipStream_t st) {
+        return act_bf16 ? bf16::launch_conv(q, Lq, st) : launch_conv(q, Lq, st);
+    };
     static const bool no_poly = std::getenv("FASTSVC_NO_POLY") != nullptr;   // A/B switch
     const long T_out = p.T;                                  // output columns (accounting below)
     if (p.mode == MODE_STRETCH && c.poly && !no_poly && c.dil == 1 && (long)p.x_T * p.s == p.T) {
@@ -777,10 +784,10 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 for (int tpw : tpws) {
                     q.tpw = tpw;
                     ConvLaunch Lq{cd.algo == 2 ? 2 : c.MW, cd.NW, cd.WM, cd.WN, nsig, 1};
-                    hipError_t e = launch_conv(q, Lq, stream);            // warm
+                    hipError_t e = launch(q, Lq, stream);                 // warm
                     if (e != hipSuccess) return e;
                     hipEventRecord(e0, stream);
-                    for (int r = 0; r < 3; ++r) { e = launch_conv(q, Lq, stream); if (e != hipSuccess) return e; }
+                    for (int r = 0; r < 3; ++r) { e = launch(q, Lq, stream); if (e != hipSuccess) return e; }
                     hipEventRecord(e1, stream);
                     if (hipEventSynchronize(e1) != hipSuccess) return hipErrorUnknown;
                     float ms = 0.f;
@@ -869,7 +876,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (p.res) el += (double)c.cout * T_out;
         if (p.r1x) el += (double)T_out;
         if (p.flags & (F_STATS | F_AFF_OUT)) el += 2.0 * c.cout * T_out;
-        const double bytes = 4.0 * (el * p.B * nsig + (double)(c.w_floats + c.b_floats) * nsig);
+        const double bytes = (act_bf16 ? 2.0 : 4.0) * el * p.B * nsig + 4.0 * (double)(c.w_floats + c.b_floats) * nsig;
         char kname[40];
         if (L.pipe)
         {
@@ -887,11 +894,12 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d,1,4>", L.MW, L.NW);
         hipError_t e = prof->begin(stream, layer, kname, flops, bytes);
         if (e != hipSuccess) return e;
-        e = launch_conv(p, L, stream);
+        e = launch(p, L, stream);
         if (e != hipSuccess) return e;
         return prof->end();
     }
-    return launch_conv(p, L, stream);
+    if (act_bf16 && !L.pipe) return hipErrorNotSupported;   // the scalar kernel exists for float32 storage only
+    return launch(p, L, stream);
 }
 
 }  // namespace
@@ -941,6 +949,13 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         return fail(FASTSVC_E_INVALID, "null argument");
     if (B < 1 || F < 1) return fail(FASTSVC_E_INVALID, "B and F must be >= 1");
     const fastsvc_plan& P = *plan;
+    if (P.storage == 1) {
+        if (F % 4 != 0) return fail(FASTSVC_E_UNSUPPORTED, "bfloat16 storage needs a frame count that is a multiple of 4");
+        for (int k = 0; k < P.n; ++k)
+            if (P.down[k].c2[0].KC != 24 || P.up[k].d3.KC != 24 || P.up[k].first.KC != 24)
+                return fail(FASTSVC_E_UNSUPPORTED, "bfloat16 storage needs the pipelined kernels (24-channel K chunks)");
+        if (P.n > 1 && !P.down[1].rc1[0].dec2) return fail(FASTSVC_E_UNSUPPORTED, "bfloat16 storage needs the fused decimating pair");
+    }
     if (spk_emb && !P.cfg.use_spk_emb)
         return fail(FASTSVC_E_INVALID, "spk_emb given but the generator was built with use_spk_emb=False");
     const Workspace ws = layout_workspace(P, B, F);
@@ -1033,7 +1048,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         if (k == 0) {
             if (prof) HIP_TRY(prof->begin(stream, "down.0.c1", "in1_conv", 2.0 * 3 * d.C * (double)Tk * B * 2,
                                           4.0 * (1.0 + d.C) * (double)Tk * B * 2));
-            HIP_TRY(launch_in1_conv(sigbuf, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
+            HIP_TRY((P.storage == 1 ? bf16::launch_in1_conv : launch_in1_conv)(sigbuf, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
                                     (long)(d.c1_raw[1].w_off - d.c1_raw[0].w_off),
                                     (long)(d.c1_raw[1].b_off - d.c1_raw[0].b_off), c1, 2, B, d.C, (int)Tk,
                                     lengths, (int)(Tk / F), stream));
@@ -1104,6 +1119,11 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
 
     // ---- up blocks ----
     const float* x = ppg;
+    if (P.storage == 1) {                                          // external float32 input -> workspace bf16
+        float* pa = buf("ppg_act");
+        HIP_TRY(bf16::launch_act_convert(ppg, pa, (long)B * P.cfg.in_channels * F, stream));
+        x = pa;
+    }
     int Cx = P.cfg.in_channels;
     long Tin = F;
     for (int i = 0; i < n; ++i) {
@@ -1178,11 +1198,19 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     // ---- conv_last ----
     if (prof) HIP_TRY(prof->begin(stream, "conv_last", "pointwise_out", 2.0 * Cx * P.cfg.out_channels * (double)T * B,
                                   4.0 * (Cx + P.cfg.out_channels) * (double)T * B));
-    HIP_TRY(launch_pointwise_out(x, blob + P.last.w_off, blob + P.last.b_off, out, B, Cx,
+    HIP_TRY((P.storage == 1 ? bf16::launch_pointwise_out : launch_pointwise_out)(x, blob + P.last.w_off, blob + P.last.b_off, out, B, Cx,
                                  P.cfg.out_channels, (int)T, lengths, (int)hop, stream));
     if (prof) HIP_TRY(prof->end());
     return FASTSVC_OK;
 }
+
+int fastsvc_plan_set_storage(fastsvc_plan* plan, int32_t dtype) {
+    if (!plan || (dtype != 0 && dtype != 1)) return fail(FASTSVC_E_INVALID, "storage dtype must be 0 (float32) or 1 (bfloat16)");
+    plan->storage = dtype;
+    return FASTSVC_OK;
+}
+
+int fastsvc_plan_get_storage(const fastsvc_plan* plan) { return plan ? plan->storage : 0; }
 
 int fastsvc_tuned_count(const fastsvc_plan* plan) {
     if (!plan) return 0;

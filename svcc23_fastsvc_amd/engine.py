@@ -26,6 +26,7 @@ TUNED_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tun
 # every symbol include/fastsvc_hip.h declares (checked by tests/test_boundary.py)
 ABI_SYMBOLS = (
     "fastsvc_abi_version", "fastsvc_last_error", "fastsvc_plan_create", "fastsvc_plan_destroy",
+    "fastsvc_plan_set_storage", "fastsvc_plan_get_storage",
     "fastsvc_weight_blob_bytes", "fastsvc_pack_weights", "fastsvc_workspace_bytes",
     "fastsvc_forward", "fastsvc_autotune", "fastsvc_tuned_count", "fastsvc_tuned_get", "fastsvc_tuned_set",
     "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
@@ -79,6 +80,10 @@ def load_library():
     lib.fastsvc_plan_create.restype = ctypes.c_int
     lib.fastsvc_plan_destroy.argtypes = [vp]
     lib.fastsvc_plan_destroy.restype = None
+    lib.fastsvc_plan_set_storage.argtypes = [vp, i32]
+    lib.fastsvc_plan_set_storage.restype = ctypes.c_int
+    lib.fastsvc_plan_get_storage.argtypes = [vp]
+    lib.fastsvc_plan_get_storage.restype = ctypes.c_int
     lib.fastsvc_weight_blob_bytes.argtypes = [vp]
     lib.fastsvc_weight_blob_bytes.restype = sz
     lib.fastsvc_pack_weights.argtypes = [vp, ctypes.POINTER(_Tensor), i32, vp]
@@ -127,7 +132,13 @@ def _check(lib, rc: int, what: str):
 class Plan:
     """Host-only plan (layer table + blob / workspace layout) for one generator configuration."""
 
-    def __init__(self, cfg: GeneratorConfig, load_shipped_table: bool = True):
+    def __init__(self, cfg: GeneratorConfig, load_shipped_table: bool = True, storage: str = "float32"):
+        """``storage``: "float32" (default, the parity path) or "bfloat16" - every workspace tensor is
+        stored as bf16 (half the HBM traffic of the narrow layers, half the workspace; fp32 arithmetic;
+        bf16-activation accuracy, frame counts must be multiples of 4)."""
+        if storage not in ("float32", "bfloat16"):
+            raise ValueError("storage must be 'float32' or 'bfloat16'")
+        self.storage = storage
         self.cfg = cfg
         self.lib = load_library()
         if cfg.n_stages > MAX_STAGES or len(cfg.upsampling_scales) != cfg.n_stages:
@@ -144,6 +155,9 @@ class Plan:
         handle = ctypes.c_void_p()
         _check(self.lib, self.lib.fastsvc_plan_create(ctypes.byref(c), ctypes.byref(handle)), "fastsvc_plan_create")
         self._h = handle
+        if storage == "bfloat16":
+            _check(self.lib, self.lib.fastsvc_plan_set_storage(handle, 1), "fastsvc_plan_set_storage")
+            load_shipped_table = False           # the shipped table was measured with float32 storage
         self.last_autotune_trials = 0
         if load_shipped_table:
             self.load_tuned_file(TUNED_TABLE_PATH, missing_ok=True)
@@ -238,6 +252,8 @@ class Plan:
         off, numel, shape = self.tap_info(name, B, F)
         if name.endswith(".stats"):
             return workspace[off: off + numel * 8].view(torch.float64).view(shape)
+        if self.storage == "bfloat16" and name != "sig" and not name.endswith(".spk"):
+            return workspace[off: off + numel * 2].view(torch.bfloat16).view(shape)
         return workspace[off: off + numel * 4].view(torch.float32).view(shape)
 
     def forward(self, blob: torch.Tensor, ppg: torch.Tensor, sine: torch.Tensor, lft: torch.Tensor,

@@ -103,6 +103,9 @@ class FastSVCGenerator(nn.Module):
     # of each layer on the device and keeps the fastest (the role cudnn.benchmark plays for the
     # reference, train_fastsvc.py:617).  False: static cost model.
     autotune = False
+    # "float32" (the parity path) or "bfloat16": workspace tensors stored as bf16 (BASELINE config 3:
+    # half the HBM traffic of the narrow layers, bf16-activation accuracy).  Set before the first forward.
+    activation_storage = "float32"
 
     def __init__(self, in_channels: int = 144, mid_channels: Sequence[int] = (192, 96, 48, 24),
                  upsampling_scales: Sequence[int] = (2, 4, 4, 5), out_channels: int = 1,
@@ -165,7 +168,7 @@ class FastSVCGenerator(nn.Module):
     def packed_weights(self, device) -> torch.Tensor:
         """Device-resident kernel-layout weight blob; rebuilt when any parameter changed."""
         if self._plan is None:
-            self._plan = Plan(self._cfg)
+            self._plan = Plan(self._cfg, storage=self.activation_storage)
         key = self._weights_key(device)
         if self._blob is None or self._blob_key != key:
             host = self._plan.pack(self.state_dict())
@@ -176,7 +179,7 @@ class FastSVCGenerator(nn.Module):
     def load_packed_weights(self, blob: torch.Tensor):
         """Adopt an already packed device blob (e.g. received by RCCL broadcast)."""
         if self._plan is None:
-            self._plan = Plan(self._cfg)
+            self._plan = Plan(self._cfg, storage=self.activation_storage)
         if blob.numel() * blob.element_size() != self._plan.blob_bytes:
             raise ValueError("packed blob has the wrong size for this configuration")
         self._blob = blob
@@ -185,7 +188,7 @@ class FastSVCGenerator(nn.Module):
     @property
     def plan(self) -> Plan:
         if self._plan is None:
-            self._plan = Plan(self._cfg)
+            self._plan = Plan(self._cfg, storage=self.activation_storage)
         return self._plan
 
     # ------------------------------------------------------------------ forward
