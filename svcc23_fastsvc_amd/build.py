@@ -45,13 +45,17 @@ UNITS = [
 ]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, timeline: bool = False) -> str:
+    """timeline=True: diagnostic build with per-wave cycle stamps in the pipelined kernel
+    (-DFASTSVC_TIMELINE, tools/timeline.py); never used for measurements of record."""
+    if not force and not timeline and not needs_build():
         return LIB_PATH
     import tempfile
     hipcc = _hipcc()
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
               "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    if timeline:
+        common.append("-DFASTSVC_TIMELINE=1")
     with tempfile.TemporaryDirectory(prefix="fastsvc_build_") as tmp:
         procs = []
         for src, extra, obj in UNITS:
@@ -75,4 +79,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timeline="--timeline" in sys.argv))

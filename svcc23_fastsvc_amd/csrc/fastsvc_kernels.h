@@ -100,6 +100,9 @@ struct ConvParams {
     const int* lens;
     int len_mul, xlen_mul;
     int frames_ld;               // host side only: padded frame count F (run_conv derives len_mul = T / F)
+    // FASTSVC_TIMELINE builds only (tools/timeline.py): per-wave cycle stamps, [workgroup][wave][64]
+    unsigned long long* tl;
+    int tl_wgs;                  // workgroups (linear id < tl_wgs) that record
     int vec;                     // 1: T % 4 == 0 and all row bases 16-byte aligned -> float4 epilogue
     int tpw;                     // pipelined kernel: consecutive time tiles walked by one workgroup
     int dbg;                     // ablation switches for profiling (FASTSVC_DBG env var); 0 in production

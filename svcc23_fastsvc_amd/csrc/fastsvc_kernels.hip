@@ -223,6 +223,7 @@ __device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0
             const int tap = (s + LA) / 6, j = (s + LA) % 6;
             #pragma unroll
             for (int n = 0; n < NW; ++n) av[(s + LA) % (LA + 1)][n] = xa0[tap * dil + j * 4 * XS + n * 16];
+            __builtin_amdgcn_sched_barrier(0);         // ... and stay before them (hipcc sinks them behind otherwise)
         }
         #pragma unroll
         for (int n = 0; n < NW; ++n)
@@ -747,6 +748,29 @@ constexpr bool ws_tail_ok() {
 struct EpiRsrc {
     __amdgpu_buffer_rsrc_t y, y2, res, ss, r1x;
 };
+// Per-lane epilogue constants of the wave's MW channel tiles, loaded ONCE per workgroup: fetched inside
+// the epilogue each costs an L2 round trip and a vmcnt(0) that also drains the previous item's stores.
+// HOISTED false (variants already at their register budget): fetched per item as before.
+template <int MW, bool HOISTED>
+struct EpiConst {
+    const float (&k_bias)[MW];
+    const float (&k_bias2)[MW];
+    const float (&k_r1w)[MW];
+    const float (&k_r1b)[MW];
+    // cot: channel of this lane in tile m (bias arrays are padded to the tiles), co: the same clamped to COUT
+    __device__ __forceinline__ float bias(const ConvParams& p, int sig, int m, int cot) const {
+        if constexpr (HOISTED) return k_bias[m]; else return p.bias[(long)sig * p.bias_sig + cot];
+    }
+    __device__ __forceinline__ float bias2(const ConvParams& p, int sig, int m, int cot) const {
+        if constexpr (HOISTED) return k_bias2[m]; else return p.bias2[(long)sig * p.bias2_sig + cot];
+    }
+    __device__ __forceinline__ float r1w(const ConvParams& p, int sig, int m, int co) const {
+        if constexpr (HOISTED) return k_r1w[m]; else return p.r1w[(long)sig * p.r1_sig + co];
+    }
+    __device__ __forceinline__ float r1b(const ConvParams& p, int sig, int m, int co) const {
+        if constexpr (HOISTED) return k_r1b[m]; else return p.r1b[(long)sig * p.r1_sig + co];
+    }
+};
 
 template <int MW, int NW>
 __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[NW][MW],
@@ -805,14 +829,61 @@ __device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiR
 // descriptor (loads return 0, stores are dropped) and the loads of G items are issued together.
 constexpr int OOB_OFF = 0x7ffffff0;
 
+// Epilogue operands staged in LDS by the consumer wave itself (see ws_estage): fetched inside the epilogue
+// they cost MW*NW serialised memory round trips after the MFMA loop (timeline of a C = 24 unit: 16.8k of
+// 23.6k cycles), and the 128-register budget has no room to prefetch them into VGPRs.  One LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPRs) per operand and
+// 16x16 item, issued before the MFMA loop of the tile's last K chunk.  A piece lands lane-linear
+// (wave base + lane * 16), so in the epilogue every lane reads back exactly the float4 it requested:
+// a private, conflict-free extension of the register file; no cross-wave synchronisation.
+// Wave region: [operand: scale, shift, residual][m][n][64 lanes] float4.
+// The DMA is inline assembly on purpose: behind the builtin hipcc drains vmcnt(0) before every LDS read
+// that follows (and again after each item's stores); hidden from it, its own counted waits on the
+// weight ring stay valid (loads return in order, the extra pieces only make them conservative) and
+// the epilogue waits with ws_epilogue_stage_wait.  M0 (LDS base of the piece) has no other user here.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsigned lds_byte, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_byte), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+// all pieces landed: they are older than the NEWER weight-ring loads of at least one unit
+template <int NEWER>
+__device__ __forceinline__ void ws_epilogue_stage_wait(bool counted) {
+    if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NEWER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int MW, int NW, int EPI>
+__device__ __forceinline__ void ws_epilogue_stage(const ConvParams& p, const EpiRsrc& R, const float* Ew,
+                                                  int mg, int tcol0, int lane, bool live) {
+    const int shift_soff = p.COUT * p.ldy * 4;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)Ew;
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const bool cok = live && cot < p.COUT;
+        const int rowoff = (cok ? cot : 0) * p.ldy;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int t = tcol0 + n * 16 + (lane >> 4) * 4;
+            const int off = (cok && t < p.T) ? (rowoff + t) * 4 : OOB_OFF;
+            const unsigned slot = base + (m * NW + n) * 1024;
+            if (EPI == EPI_RES) lds_dma16(R.res, slot, off, 0);
+            if (EPI == EPI_AFF) {
+                lds_dma16(R.ss, slot, off, 0);
+                lds_dma16(R.ss, slot + MW * NW * 1024, off, shift_soff);
+                if (p.res) lds_dma16(R.res, slot + 2 * MW * NW * 1024, off, 0);
+            }
+        }
+    }
+}
+
+template <int MW, int NW, int EPI, bool EST = false, class KT>
 __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[NW][MW],
                                                  float (&s1)[MW], float (&s2)[MW],
-                                                 int sig, int mg, int tcol0, bool active, int lane) {
+                                                 int sig, int mg, int tcol0, bool active, int lane,
+                                                 const KT& K, const float* Ew = nullptr) {
     if (p.dbg & DBG_NO_EPILOGUE) { ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg, tcol0, active, lane); return; }
     if (!active) return;                                   // whole wave (uniform)
     const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;     // max(v, slope*v): identity for 1
-    const float* biasp = p.bias + (long)sig * p.bias_sig;                  // padded to the channel tiles
     const int shift_soff = p.COUT * p.ldy * 4;
     constexpr int G = (EPI == EPI_AFF) ? (NW == 2 ? 2 : 1) : NW;           // items whose loads fly together (register budget)
     constexpr bool TAIL = ws_tail_ok<MW, NW, MODE_DIRECT, EPI, 1>();
@@ -821,9 +892,9 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
         const int cot = (mg * MW + m) * 16 + (lane & 15);
         const bool cok = cot < p.COUT;
         const int co = cok ? cot : 0;
-        const float bias = biasp[cot];                     // padded array: always in bounds
+        const float bias = K.bias(p, sig, m, cot);
         float r1w = 0.f, r1b = 0.f;
-        if (EPI == EPI_RANK1) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
+        if (EPI == EPI_RANK1) { r1w = K.r1w(p, sig, m, co); r1b = K.r1b(p, sig, m, co); }
         const int rowoff = co * p.ldy;
         #pragma unroll
         for (int n0 = 0; n0 < NW; n0 += G) {
@@ -835,12 +906,22 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
                 const bool ok = cok && t < p.T;
                 nv[g] = TAIL ? (ok ? row_valid(t, p.T) : 0) : 4;
                 off[g] = ok ? (rowoff + t) * 4 : OOB_OFF;
-                if (EPI == EPI_RES) l0[g] = act_load4(R.res, off[g], 0);
-                if (EPI == EPI_RANK1) l0[g] = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
-                if (EPI == EPI_AFF) {
-                    l0[g] = act_load4(R.res, off[g], 0);              // zero-length descriptor when absent
-                    l1[g] = act_load4(R.ss, off[g], 0);
-                    l2[g] = act_load4(R.ss, off[g], shift_soff);
+                if constexpr (EST) {
+                    const f32x4* slot = reinterpret_cast<const f32x4*>(Ew + (m * NW + n0 + g) * 256) + lane;
+                    if (EPI == EPI_RES) l0[g] = slot[0];
+                    if (EPI == EPI_AFF) {
+                        l1[g] = slot[0];
+                        l2[g] = slot[MW * NW * 64];
+                        l0[g] = p.res ? slot[2 * MW * NW * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                } else {
+                    if (EPI == EPI_RES) l0[g] = act_load4(R.res, off[g], 0);
+                    if (EPI == EPI_RANK1) l0[g] = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
+                    if (EPI == EPI_AFF) {
+                        l0[g] = act_load4(R.res, off[g], 0);              // zero-length descriptor when absent
+                        l1[g] = act_load4(R.ss, off[g], 0);
+                        l2[g] = act_load4(R.ss, off[g], shift_soff);
+                    }
                 }
             }
             #pragma unroll
@@ -867,10 +948,10 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
 // output channel, i.e. 4*S consecutive output samples = S float4 stores.  EPI_PLAIN: y = o + bias
 // (the stretched residual conv, fastsvc.py:72-75,94); EPI_AFF: t = lrelu(o + bias),
 // u = scale * t + shift -> y2, InstanceNorm partial sums (fastsvc.py:57-62,97 + 115-140).
-template <int MW, int NW, int EPI, int S>
+template <int MW, int NW, int EPI, int S, class KT>
 __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[3][NW][MW],
                                                  float (&s1)[MW], float (&s2)[MW],
-                                                 int mg, int tcol0, bool active, int lane) {
+                                                 int mg, int tcol0, bool active, int lane, const KT& K) {
     if (!active) return;                                   // whole wave (uniform)
     const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
     const int T_out = p.ldy;                               // output row pitch
@@ -881,7 +962,7 @@ __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiR
         const int cot = (mg * MW + m) * 16 + (lane & 15);
         const bool cok = cot < p.COUT;
         const int co = cok ? cot : 0;
-        const float bias = p.bias[cot];                    // padded array: always in bounds
+        const float bias = K.bias(p, 0, m, cot);
         const int rowoff = co * T_out;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
@@ -933,20 +1014,19 @@ __device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiR
 // Winograd epilogue: a lane holds m0..m3 of FOUR consecutive pairs of one output channel = the 8
 // consecutive outputs starting at tcol0 + 32 n + 8 (lane >> 4).  The even/odd interleave depends on
 // the dilation: D=1 e0 o0 e1 o1 | e2 o2 e3 o3;  D=2 e0 e1 o0 o1 | e2 e3 o2 o3;  D=4 e0..e3 | o0..o3.
-template <int MW, int NW, int EPI, int D>
+template <int MW, int NW, int EPI, int D, class KT>
 __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[4][NW][MW],
-                                                 int sig, int mg, int tcol0, bool active, int lane) {
+                                                 int sig, int mg, int tcol0, bool active, int lane, const KT& K) {
     if (!active) return;                                   // whole wave (uniform)
     const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
-    const float* biasp = p.bias + (long)sig * p.bias_sig;
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int cot = (mg * MW + m) * 16 + (lane & 15);
         const bool cok = cot < p.COUT;
         const int co = cok ? cot : 0;
-        const float bias = biasp[cot];                     // padded array: always in bounds
+        const float bias = K.bias(p, sig, m, cot);
         float r1w = 0.f, r1b = 0.f;
-        if (EPI == EPI_RANK1) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
+        if (EPI == EPI_RANK1) { r1w = K.r1w(p, sig, m, co); r1b = K.r1b(p, sig, m, co); }
         const int rowoff = co * p.ldy;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
@@ -982,18 +1062,16 @@ __device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiR
 }
 
 // MODE_DEC2 epilogue: two plain outputs, y = acc[0] + bias, y2 = acc[1] + bias2.
-template <int MW, int NW>
+template <int MW, int NW, class KT>
 __device__ __forceinline__ void ws_epilogue_dec2(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[2][NW][MW],
-                                                 int sig, int mg, int tcol0, bool active, int lane) {
+                                                 int sig, int mg, int tcol0, bool active, int lane, const KT& K) {
     if (!active) return;
-    const float* biasp = p.bias + (long)sig * p.bias_sig;
-    const float* bias2p = p.bias2 + (long)sig * p.bias2_sig;
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int cot = (mg * MW + m) * 16 + (lane & 15);
         const bool cok = cot < p.COUT;
         const int co = cok ? cot : 0;
-        const float bias = biasp[cot], bias2 = bias2p[cot];          // padded arrays
+        const float bias = K.bias(p, sig, m, cot), bias2 = K.bias2(p, sig, m, cot);
         const int rowoff = co * p.ldy;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
@@ -1012,6 +1090,16 @@ __device__ __forceinline__ void ws_epilogue_dec2(const ConvParams& p, const EpiR
 // a 2*S-load epilogue: 256 (those layers launch about one workgroup per CU anyway).
 // MW == 3, NW == 2 fits 128 only with the plain / residual epilogues (no extra epilogue operands).
 constexpr bool NTAPS_IS_3_DIRECT(int mode) { return mode == MODE_DIRECT; }
+// variants that stage their epilogue operands in LDS (ws_epilogue_stage); float32 storage only
+template <int MW, int NW, int MODE, int EPI>
+constexpr bool ws_estage() {
+#ifdef FASTSVC_ACT_BF16
+    return false;
+#else
+    return MODE == MODE_DIRECT &&
+           ((EPI == EPI_AFF && MW * NW <= 4) || (EPI == EPI_RES && MW * NW <= 6));
+#endif
+}
 template <int MW, int NW, int MODE, int EPI>
 constexpr int ws_min_waves() {
     if (MODE == MODE_POLY) return (MW <= 2 && NW == 1) ? 4 : 2;
@@ -1064,6 +1152,22 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
     const int ntiles = min(p.tpw, ntx - tile0);
     if (ntiles <= 0) return;                                           // ragged batch: nothing of this utterance here
     const int nunits = ntiles * p.nchunks;
+#ifdef FASTSVC_TIMELINE
+    // diagnostic build: lane 0 of every wave stamps s_memtime at its phase boundaries
+    const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned long long* tlw = (p.tl && wg_lin < p.tl_wgs) ? p.tl + ((long)wg_lin * 8 + wave) * 64 : nullptr;
+    int tli = 0;
+    auto stamp = [&](int tag) {
+        if (tlw && lane == 0 && tli < 62) { tlw[tli++] = ((unsigned long long)tag << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); }
+    };
+    stamp(1);                                               // kernel entry
+    if (tlw && lane == 0) {
+        tlw[62] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID: wave / simd / cu / sh / se
+        tlw[63] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));     // XCC_ID
+    }
+#else
+    auto stamp = [](int) {};
+#endif
 
     double* sstat = reinterpret_cast<double*>(smem_raw);                       // [WM*MW*16][2]
     float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);  // [CINp]
@@ -1205,23 +1309,30 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         unsigned oka = 0, okb = 0;
         pload(0, pa, oka);
         if (nunits > 1) pload(1, pb, okb);
+        stamp(2);                                      // first loads issued
         setup_shared();
         pcommit(0, pa, oka, Xs0);
+        stamp(3);                                      // unit 0 committed
         __syncthreads();                               // unit 0 staged
+        stamp(4);
         for (int u = 0; u < nunits; u += 2) {
             // consumers multiply unit u (buffer 0): stage unit u+1 into buffer 1, fetch unit u+2
             if (u + 1 < nunits) {
                 if (u + 2 < nunits) pload(u + 2, pa, oka);
                 pcommit(u + 1, pb, okb, Xs0 + bufsz);
             }
+            stamp(5);                                  // producer: staged the next unit
             __syncthreads();                           // end of unit u
+            stamp(6);
             if (u + 1 >= nunits) break;
             // consumers multiply unit u+1 (buffer 1): stage unit u+2 into buffer 0, fetch unit u+3
             if (u + 2 < nunits) {
                 if (u + 3 < nunits) pload(u + 3, pb, okb);
                 pcommit(u + 2, pa, oka, Xs0);
             }
+            stamp(5);
             __syncthreads();                           // end of unit u+1
+            stamp(6);
         }
     } else {
         // ================================ CONSUMER WAVES ================================
@@ -1240,6 +1351,10 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         const int wq = (lane >> 4) * XS + wpair / S + 4 / S;
         const int colr = wq + (wpair % S) * p.ps;
         const int colrd = wq + (wpair % S + S) * p.ps;
+        constexpr bool EST = ws_estage<MW, NW, MODE, EPI>();
+        // this wave's epilogue-operand slots, behind the window buffers (launch_conv_pipe sizes them)
+        float* Ew = Xs0 + ((p.nchunks > 1 || p.tpw > 1) ? 2 : 1) * bufsz
+                        + cw * ((EPI == EPI_RES ? 1 : p.res ? 3 : 2) * MW * NW * 256);
         EpiRsrc R;
         {
             const long ct = (long)p.COUT * p.ldy;       // rows of y / y2 / res / scale / shift at the output pitch
@@ -1252,8 +1367,32 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
             R.ss = act_rsrc(has_ss ? p.ss_out : nul, has_ss ? (long)b * p.ss_out_b : 0, has_ss ? 2 * ct : 0);
             R.r1x = make_rsrc(p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nul, p.r1x ? p.ldy : 0);
         }
+        // (variants already at their register budget fetch them per tile instead)
+        constexpr bool HOIST = !(WINO && ((MW == 3 && NW == 2) || EPI == EPI_RANK1)) &&
+                               !(MODE == MODE_STRETCH && NW == 4) && !(MW == 3 && EPI == EPI_RANK1) &&
+                               !(POLY && S == 5 && EPI == EPI_AFF);
+        float k_bias[MW], k_bias2[MW], k_r1w[MW], k_r1b[MW];
+        auto load_consts = [&]() {
+        #pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int cot = (mg * MW + m) * 16 + (lane & 15);
+            const int co = cot < p.COUT ? cot : 0;
+            const bool cok = active && cot < p.COUT;
+            k_bias[m] = cok ? p.bias[(long)sig * p.bias_sig + co] : 0.f;
+            k_bias2[m] = 0.f; k_r1w[m] = 0.f; k_r1b[m] = 0.f;
+            if constexpr (DEC2) k_bias2[m] = cok ? p.bias2[(long)sig * p.bias2_sig + co] : 0.f;
+            if constexpr (EPI == EPI_RANK1) {
+                k_r1w[m] = cok ? p.r1w[(long)sig * p.r1_sig + co] : 0.f;
+                k_r1b[m] = cok ? p.r1b[(long)sig * p.r1_sig + co] : 0.f;
+            }
+        }
+        };
+        if constexpr (HOIST) load_consts();
+        const EpiConst<MW, HOIST> K{k_bias, k_bias2, k_r1w, k_r1b};
+        stamp(2);                                      // weight stream issued
         setup_shared();
         __syncthreads();                               // unit 0 staged
+        stamp(4);
         int u = 0;
         for (int tl = 0; tl < ntiles; ++tl) {
             if constexpr (DEC2) {
@@ -1284,30 +1423,38 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                     for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
+                if constexpr (EST) {
+                    // one unit earlier when the tile has several K chunks: more time to land
+                    if (active && ch == max(p.nchunks - 2, 0) && !(p.dbg & DBG_NO_EPILOGUE))
+                        ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane, true);
+                }
                 if (active && !(p.dbg & DBG_NO_MFMA)) {
                     if constexpr (DEC2) mfma_unit_dec2<MW, NW>(acc2, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
                     else if constexpr (WINO) mfma_unit_wino<MW, NW, S, NSTEPS>(acc4, Xs0 + (u & 1) * bufsz + colr, Xs0 + (u & 1) * bufsz + colrd, XS, wst);
                     else if constexpr (POLY) mfma_unit_poly<MW, NW>(acc3, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
                     else mfma_unit<MW, NW, NSTEPS>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
                 }
+                stamp(7);                              // consumer: MFMAs of the unit issued
                 if (ch + 1 == p.nchunks) {
                     #pragma unroll
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
                     if constexpr (DEC2)
                         ws_epilogue_dec2<MW, NW>(p, R, acc2, sig, mg,
-                                                 (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
+                                                 (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
                     else if constexpr (WINO)
                         ws_epilogue_wino<MW, NW, EPI, S>(p, R, acc4, sig, mg,
-                                                         (tile0 + tl) * NT + wave_n * (NW * 32), active, lane);
+                                                         (tile0 + tl) * NT + wave_n * (NW * 32), active, lane, K);
                     else if constexpr (POLY)
                         ws_epilogue_poly<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg,
-                                                         (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
+                                                         (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
                     else if constexpr (EPI == EPI_GENERIC)
                         ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg,
                                                  (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
-                    else
-                        ws_epilogue_kind<MW, NW, EPI>(p, R, acc, s1, s2, sig, mg,
-                                                      (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
+                    else {
+                        if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSTEPS>(!(p.dbg & DBG_NO_MFMA)); }
+                        ws_epilogue_kind<MW, NW, EPI, EST>(p, R, acc, s1, s2, sig, mg,
+                                                           (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
+                    }
                     if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
                         // fp32 partials stay short (this tile only); the running sums are f64 in LDS
                         #pragma unroll
@@ -1323,7 +1470,9 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                         }
                     }
                 }
+                stamp(8);                              // consumer: epilogue (if any) issued
                 __syncthreads();                       // end of unit u
+                stamp(6);
             }
         }
     }
@@ -1391,6 +1540,9 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM
                       + sizeof(float) * (2 * (size_t)CINp + (size_t)nbuf * p.KC * p.xs);
     block = dim3(512);                                  // 4 consumer + 4 producer waves
+    // epilogue-operand slots of the four consumer waves (ws_estage variants)
+    const bool aff_epi = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+    const size_t smem_est = smem + sizeof(float) * 4 * (size_t)(aff_epi ? (p.res ? 3 : 2) : 1) * MW * NW * 256;
     if (p.mode == MODE_WINO) {
         if constexpr ((MW == 3 && NW <= 2) || (MW == 2 && NW == 1)) {
             const bool res = p.res != nullptr;
@@ -1446,7 +1598,13 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
         const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
         const int kind = aff ? EPI_AFF : p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
         {
-#define FASTSVC_EPI(mode, k) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), grid, block, smem, stream, p)
+#define FASTSVC_EPI(mode, k) do { \
+                if constexpr (ws_estage<MW, NW, mode, k>()) { \
+                    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), \
+                                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    if (attr != hipSuccess) return attr; \
+                    hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), grid, block, smem_est, stream, p); \
+                } else hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), grid, block, smem, stream, p); } while (0)
             if (p.mode == MODE_STRETCH) {
                 if (kind == EPI_AFF) FASTSVC_EPI(MODE_STRETCH, EPI_AFF); else FASTSVC_EPI(MODE_STRETCH, EPI_PLAIN);
             } else {

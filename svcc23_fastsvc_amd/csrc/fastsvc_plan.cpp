@@ -899,6 +899,38 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         return prof->end();
     }
     if (act_bf16 && !L.pipe) return hipErrorNotSupported;   // the scalar kernel exists for float32 storage only
+#ifdef FASTSVC_TIMELINE
+    {
+        // diagnostic build (python -m svcc23_fastsvc_amd.build --timeline; tools/timeline.py): per-wave
+        // cycle stamps of the launch named by FASTSVC_TIMELINE_LAYER, dumped to FASTSVC_TIMELINE_OUT
+        const char* want = std::getenv("FASTSVC_TIMELINE_LAYER");
+        const char* out = std::getenv("FASTSVC_TIMELINE_OUT");
+        if (want && out && L.pipe && std::strcmp(want, layer) == 0) {
+            const int NT = (p.mode == MODE_WINO ? 32 : 16) * L.NW * L.WN;
+            const long ntx = (p.T + NT - 1) / NT;
+            const long wgs = ((ntx + p.tpw - 1) / p.tpw) * ((p.ngroups + L.WM - 1) / L.WM) * zb;
+            const long cap = wgs < 8192 ? wgs : 8192;
+            unsigned long long* dbuf = nullptr;
+            const size_t bytes = (size_t)cap * 8 * 64 * sizeof(unsigned long long);
+            if (hipMalloc(&dbuf, bytes) != hipSuccess) return hipErrorOutOfMemory;
+            hipMemsetAsync(dbuf, 0, bytes, stream);
+            p.tl = dbuf; p.tl_wgs = (int)cap;
+            hipError_t e = launch(p, L, stream);
+            if (e != hipSuccess) return e;
+            hipStreamSynchronize(stream);
+            std::vector<unsigned long long> host((size_t)cap * 8 * 64);
+            hipMemcpy(host.data(), dbuf, bytes, hipMemcpyDeviceToHost);
+            hipFree(dbuf);
+            if (FILE* f = std::fopen(out, "wb")) {
+                const long hdr[8] = {cap, wgs, p.tpw, p.nchunks, L.MW, L.NW, L.WM, L.WN};
+                std::fwrite(hdr, sizeof(long), 8, f);
+                std::fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+                std::fclose(f);
+            }
+            return hipSuccess;
+        }
+    }
+#endif
     return launch(p, L, stream);
 }
 
