@@ -201,7 +201,11 @@ struct UnitWeightStream {
     }
 };
 
-template <int MW, int NW, int NSTEPS>
+// RELOAD false: the whole layer is ONE unit of weights (C_in <= 24), the ring just stays resident.  Apart
+// from the L2 traffic saved, the consumer's MFMA loop then has no vmcnt wait at all: on gfx9 loads
+// and stores share that counter in order, so every wait on a re-requested slot also drained the
+// previous tile's epilogue stores (and the LDS-DMA pieces of this one) in the middle of the loop.
+template <int MW, int NW, int NSTEPS, bool RELOAD = true>
 __device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0, int XS,
                                           UnitWeightStream<MW, NSTEPS>& ws, int dil) {
     // The LDS reads of step s+LA are issued BEFORE the MFMAs of step s (register ring by full
@@ -230,20 +234,23 @@ __device__ __forceinline__ void mfma_unit(f32x4 (&acc)[NW][MW], const float* xa0
             #pragma unroll
             for (int m = 0; m < MW; ++m)
                 acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s % (LA + 1)][n], wfrag_get<MW>(ws.wr[s], m), acc[n][m], 0, 0, 0);
-        ws.wr[s] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + s * UnitWeightStream<MW, NSTEPS>::STEP_BYTES);
+        if constexpr (RELOAD)
+            ws.wr[s] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + s * UnitWeightStream<MW, NSTEPS>::STEP_BYTES);
         // pin the re-request right behind its step (hipcc otherwise sinks the loads to the end
         // of the unit and waits for all of them at the top of the next one)
         __builtin_amdgcn_sched_barrier(0);
     }
-    ws.next += UnitWeightStream<MW, NSTEPS>::UNIT_BYTES;
-    if (ws.next >= ws.total) ws.next = 0;
+    if constexpr (RELOAD) {
+        ws.next += UnitWeightStream<MW, NSTEPS>::UNIT_BYTES;
+        if (ws.next >= ws.total) ws.next = 0;
+    }
 }
 
 // Polyphase unit (MODE_POLY): per 4-channel k-group read x[j-1], x[j], x[j+1] from the window
 // (the same three LDS reads a 3-tap conv makes), form the two differences on the VALU and feed three
 // accumulator sets: acc[0] += (x[j-1]-x[j]) W0,  acc[1] += x[j] (W0+W1+W2),  acc[2] += (x[j+1]-x[j]) W2.
 // Weight slots: tap-major like every unit (slot = tap * 6 + k-group), so the stream is unchanged.
-template <int MW, int NW>
+template <int MW, int NW, bool RELOAD = true>
 __device__ __forceinline__ void mfma_unit_poly(f32x4 (&acc)[3][NW][MW], const float* xa0, int XS,
                                                UnitWeightStream<MW, UNIT_STEPS>& ws) {
     float av[2][3][NW];                                     // k-group ring, one group of look-ahead
@@ -268,12 +275,15 @@ __device__ __forceinline__ void mfma_unit_poly(f32x4 (&acc)[3][NW][MW], const fl
                 for (int m = 0; m < MW; ++m)
                     acc[tap][n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wfrag_get<MW>(ws.wr[tap * 6 + j], m), acc[tap][n][m], 0, 0, 0);
             }
-            ws.wr[tap * 6 + j] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + (tap * 6 + j) * UnitWeightStream<MW, UNIT_STEPS>::STEP_BYTES);
+            if constexpr (RELOAD)
+                ws.wr[tap * 6 + j] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + (tap * 6 + j) * UnitWeightStream<MW, UNIT_STEPS>::STEP_BYTES);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    ws.next += UnitWeightStream<MW, UNIT_STEPS>::UNIT_BYTES;
-    if (ws.next >= ws.total) ws.next = 0;
+    if constexpr (RELOAD) {
+        ws.next += UnitWeightStream<MW, UNIT_STEPS>::UNIT_BYTES;
+        if (ws.next >= ws.total) ws.next = 0;
+    }
 }
 
 // Winograd F(2,3) unit (MODE_WINO).  Weight steps of a unit are packed HALF-major:
@@ -283,7 +293,7 @@ __device__ __forceinline__ void mfma_unit_poly(f32x4 (&acc)[3][NW][MW], const fl
 // xr / xrd: this lane's LDS addresses of d1 = x[t] (plane r) and d2 = x[t+d] (plane r+d) for
 // k-group 0 of M-tile 0; d3 = x[t+2d] is the next entry of plane r, d0 = x[t-d] the previous entry
 // of plane r+d.  M-tile n starts 16 pairs = 16/D plane positions further on.
-template <int MW, int NW, int D, int RING>
+template <int MW, int NW, int D, int RING, bool RELOAD = true>
 __device__ __forceinline__ void mfma_unit_wino(f32x4 (&acc)[4][NW][MW], const float* xr, const float* xrd, int XS,
                                                UnitWeightStream<MW, RING>& ws) {
     constexpr int TSTEP = 16 / D;
@@ -316,7 +326,8 @@ __device__ __forceinline__ void mfma_unit_wino(f32x4 (&acc)[4][NW][MW], const fl
                     for (int m = 0; m < MW; ++m)
                         acc[c][n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wfrag_get<MW>(ws.wr[slot], m), acc[c][n][m], 0, 0, 0);
                 }
-                ws.wr[slot] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + slot * STEP_BYTES);
+                if constexpr (RELOAD || RING == 12)
+                    ws.wr[slot] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + slot * STEP_BYTES);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -325,7 +336,7 @@ __device__ __forceinline__ void mfma_unit_wino(f32x4 (&acc)[4][NW][MW], const fl
             if (ws.next >= ws.total) ws.next = 0;
         }
     }
-    if (RING == 24) {
+    if (RING == 24 && RELOAD) {
         ws.next += UnitWeightStream<MW, RING>::UNIT_BYTES;
         if (ws.next >= ws.total) ws.next = 0;
     }
@@ -333,7 +344,7 @@ __device__ __forceinline__ void mfma_unit_wino(f32x4 (&acc)[4][NW][MW], const fl
 
 // MODE_DEC2 unit: acc[0] += lrelu(x[t-1]) w0 + lrelu(x[t]) w1 + lrelu(x[t+1]) w2,  acc[1] += x[t] w1x1.
 // Weight steps are packed half-major like the Winograd ones (component 3 = the 1x1 weights).
-template <int MW, int NW>
+template <int MW, int NW, bool RELOAD = true>
 __device__ __forceinline__ void mfma_unit_dec2(f32x4 (&acc)[2][NW][MW], const float* xa0, int XS,
                                                UnitWeightStream<MW, 24>& ws) {
     constexpr int STEP_BYTES = UnitWeightStream<MW, 24>::STEP_BYTES;
@@ -362,13 +373,16 @@ __device__ __forceinline__ void mfma_unit_dec2(f32x4 (&acc)[2][NW][MW], const fl
                     for (int m = 0; m < MW; ++m)
                         acc[c == 3][n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wfrag_get<MW>(ws.wr[slot], m), acc[c == 3][n][m], 0, 0, 0);
                 }
-                ws.wr[slot] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + slot * STEP_BYTES);
+                if constexpr (RELOAD)
+                    ws.wr[slot] = load_wfrag_buf<MW>(ws.rsrc, ws.voff, ws.next + slot * STEP_BYTES);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    ws.next += UnitWeightStream<MW, 24>::UNIT_BYTES;
-    if (ws.next >= ws.total) ws.next = 0;
+    if constexpr (RELOAD) {
+        ws.next += UnitWeightStream<MW, 24>::UNIT_BYTES;
+        if (ws.next >= ws.total) ws.next = 0;
+    }
 }
 
 // Epilogue of one time tile.  D layout (16x16x4 f32): lane holds column j = lane & 15 (output
@@ -1110,7 +1124,9 @@ constexpr int ws_min_waves() {
     return 2;
 }
 
-template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC, int S = 1>
+// WSTATIC (MW == 2 instances only, chosen by launch_ws): the layer has a single unit of weights per
+// channel group (Q == NSTEPS), see mfma_unit's RELOAD.
+template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC, int S = 1, bool WSTATIC = false>
 __global__ __launch_bounds__(512, (ws_min_waves<MW, NW, MODE, EPI>()))
 void conv_mfma_ws_kernel(const ConvParams p0) {
     constexpr bool WINO = (MODE == MODE_WINO);                         // S carries the dilation D
@@ -1370,7 +1386,8 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         // (variants already at their register budget fetch them per tile instead)
         constexpr bool HOIST = !(WINO && ((MW == 3 && NW == 2) || EPI == EPI_RANK1)) &&
                                !(MODE == MODE_STRETCH && NW == 4) && !(MW == 3 && EPI == EPI_RANK1) &&
-                               !(POLY && S == 5 && EPI == EPI_AFF);
+                               !(POLY && S == 5 && EPI == EPI_AFF) &&
+                               !(MW == 2 && NW == 4 && (EPI == EPI_RANK1 || EPI == EPI_AFF)) && !(DEC2 && MW == 2 && NW == 2);
         float k_bias[MW], k_bias2[MW], k_r1w[MW], k_r1b[MW];
         auto load_consts = [&]() {
         #pragma unroll
@@ -1429,10 +1446,11 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                         ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane, true);
                 }
                 if (active && !(p.dbg & DBG_NO_MFMA)) {
-                    if constexpr (DEC2) mfma_unit_dec2<MW, NW>(acc2, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
-                    else if constexpr (WINO) mfma_unit_wino<MW, NW, S, NSTEPS>(acc4, Xs0 + (u & 1) * bufsz + colr, Xs0 + (u & 1) * bufsz + colrd, XS, wst);
-                    else if constexpr (POLY) mfma_unit_poly<MW, NW>(acc3, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
-                    else mfma_unit<MW, NW, NSTEPS>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
+                    constexpr bool RL = !WSTATIC;      // WSTATIC: the ring holds the whole layer, nothing to re-request
+                    if constexpr (DEC2) mfma_unit_dec2<MW, NW, RL>(acc2, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
+                    else if constexpr (WINO) mfma_unit_wino<MW, NW, S, NSTEPS, RL>(acc4, Xs0 + (u & 1) * bufsz + colr, Xs0 + (u & 1) * bufsz + colrd, XS, wst);
+                    else if constexpr (POLY) mfma_unit_poly<MW, NW, RL>(acc3, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
+                    else mfma_unit<MW, NW, NSTEPS, RL>(acc, Xs0 + (u & 1) * bufsz + colbase, XS, wst, p.dil);
                 }
                 stamp(7);                              // consumer: MFMAs of the unit issued
                 if (ch + 1 == p.nchunks) {
@@ -1451,7 +1469,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                         ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg,
                                                  (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
                     else {
-                        if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSTEPS>(!(p.dbg & DBG_NO_MFMA)); }
+                        if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSTEPS>(!WSTATIC && !(p.dbg & DBG_NO_MFMA)); }
                         ws_epilogue_kind<MW, NW, EPI, EST>(p, R, acc, s1, s2, sig, mg,
                                                            (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
                     }
@@ -1528,6 +1546,33 @@ bool conv_poly_shape(int MW, int NW, int WM, int WN) {
 
 #endif
 
+template <auto KERNEL>
+static hipError_t launch_instance(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const ConvParams& p) {
+    if (smem > 64 * 1024) {                                 // above the default dynamic-LDS limit: once per instance
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL(KERNEL, grid, block, smem, stream, p);
+    return hipGetLastError();
+}
+
+// One launch of the pipelined kernel: picks the resident-weights instance (MW == 2 and a single unit of
+// weights per channel group) and adds the epilogue-operand slots of the ws_estage variants to the LDS size.
+template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GENERIC, int S = 1>
+static hipError_t launch_ws(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const ConvParams& p) {
+    if constexpr (ws_estage<MW, NW, MODE, EPI>()) {
+        const bool aff_epi = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+        smem += sizeof(float) * 4 * (size_t)(aff_epi ? (p.res ? 3 : 2) : 1) * MW * NW * 256;
+    }
+    constexpr int NSTEPS = (MODE == MODE_WINO || MODE == MODE_DEC2) ? 24 : 6 * NTAPS;
+    if constexpr (MW == 2) {
+        if (p.Q == NSTEPS && !(p.dbg & DBG_NO_WEIGHTS))
+            return launch_instance<&conv_mfma_ws_kernel<MW, NW, WM, WN, MODE, NTAPS, EPI, S, true>>(grid, block, smem, stream, p);
+    }
+    return launch_instance<&conv_mfma_ws_kernel<MW, NW, WM, WN, MODE, NTAPS, EPI, S, false>>(grid, block, smem, stream, p);
+}
+
 template <int MW, int NW, int WM, int WN>
 static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t stream) {
     const int NT = (p.mode == MODE_WINO ? 32 : 16) * NW * WN;
@@ -1540,17 +1585,14 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM
                       + sizeof(float) * (2 * (size_t)CINp + (size_t)nbuf * p.KC * p.xs);
     block = dim3(512);                                  // 4 consumer + 4 producer waves
-    // epilogue-operand slots of the four consumer waves (ws_estage variants)
-    const bool aff_epi = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
-    const size_t smem_est = smem + sizeof(float) * 4 * (size_t)(aff_epi ? (p.res ? 3 : 2) : 1) * MW * NW * 256;
     if (p.mode == MODE_WINO) {
         if constexpr ((MW == 3 && NW <= 2) || (MW == 2 && NW == 1)) {
             const bool res = p.res != nullptr;
             if constexpr (MW == 2) {                        // rank-1 residual: the stage-0 chain (C_in = 1 residual path)
                 if (p.r1x) {
-                    if (p.dil == 4) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 4>), grid, block, smem, stream, p);
-                    else if (p.dil == 2) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 2>), grid, block, smem, stream, p);
-                    else if (p.dil == 1) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 1>), grid, block, smem, stream, p);
+                    if (p.dil == 4) return launch_ws<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 4>(grid, block, smem, stream, p);
+                    else if (p.dil == 2) return launch_ws<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 2>(grid, block, smem, stream, p);
+                    else if (p.dil == 1) return launch_ws<MW, NW, WM, WN, MODE_WINO, 3, EPI_RANK1, 1>(grid, block, smem, stream, p);
                     else return hipErrorInvalidValue;
                     return hipGetLastError();
                 }
@@ -1559,8 +1601,8 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
             }
 #define FASTSVC_WINO(dv) \
             if (p.dil == dv) { \
-                if (res) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_RES, dv>), grid, block, smem, stream, p); \
-                else hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_WINO, 3, EPI_PLAIN, dv>), grid, block, smem, stream, p); \
+                if (res) return launch_ws<MW, NW, WM, WN, MODE_WINO, 3, EPI_RES, dv>(grid, block, smem, stream, p); \
+                else return launch_ws<MW, NW, WM, WN, MODE_WINO, 3, EPI_PLAIN, dv>(grid, block, smem, stream, p); \
                 return hipGetLastError(); \
             }
             FASTSVC_WINO(1) FASTSVC_WINO(2) FASTSVC_WINO(4)
@@ -1573,7 +1615,7 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
     } else
     if (p.mode == MODE_DEC2) {
         if constexpr (NW <= 2) {
-            hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DEC2, 3>), grid, block, smem, stream, p);
+            return launch_ws<MW, NW, WM, WN, MODE_DEC2, 3>(grid, block, smem, stream, p);
             return hipGetLastError();
         }
         return hipErrorInvalidValue;
@@ -1583,8 +1625,8 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
             const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
 #define FASTSVC_POLY(sv) \
             if (p.s == sv) { \
-                if (aff) hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_POLY, 3, EPI_AFF, sv>), grid, block, smem, stream, p); \
-                else hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_POLY, 3, EPI_PLAIN, sv>), grid, block, smem, stream, p); \
+                if (aff) return launch_ws<MW, NW, WM, WN, MODE_POLY, 3, EPI_AFF, sv>(grid, block, smem, stream, p); \
+                else return launch_ws<MW, NW, WM, WN, MODE_POLY, 3, EPI_PLAIN, sv>(grid, block, smem, stream, p); \
                 return hipGetLastError(); \
             }
             FASTSVC_POLY(2) FASTSVC_POLY(4) FASTSVC_POLY(5)
@@ -1592,19 +1634,13 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
         }
         return hipErrorInvalidValue;
     } else if (p.ntaps == 1) {
-        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DECIMATE, 1>), grid, block, smem, stream, p);
+        return launch_ws<MW, NW, WM, WN, MODE_DECIMATE, 1>(grid, block, smem, stream, p);
     } else if (p.ntaps == 3 && (p.mode == MODE_STRETCH || p.mode == MODE_DIRECT)) {
         // compile-time specialised epilogue
         const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
         const int kind = aff ? EPI_AFF : p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
         {
-#define FASTSVC_EPI(mode, k) do { \
-                if constexpr (ws_estage<MW, NW, mode, k>()) { \
-                    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), \
-                                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                    if (attr != hipSuccess) return attr; \
-                    hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), grid, block, smem_est, stream, p); \
-                } else hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, mode, 3, k>), grid, block, smem, stream, p); } while (0)
+#define FASTSVC_EPI(mode, k) return launch_ws<MW, NW, WM, WN, mode, 3, k>(grid, block, smem, stream, p)
             if (p.mode == MODE_STRETCH) {
                 if (kind == EPI_AFF) FASTSVC_EPI(MODE_STRETCH, EPI_AFF); else FASTSVC_EPI(MODE_STRETCH, EPI_PLAIN);
             } else {
@@ -1616,11 +1652,11 @@ static hipError_t launch_conv_pipe(const ConvParams& p, int nsig, hipStream_t st
 #undef FASTSVC_EPI
         }
     } else if (p.mode == MODE_STRETCH) {
-        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_STRETCH, 3>), grid, block, smem, stream, p);
+        return launch_ws<MW, NW, WM, WN, MODE_STRETCH, 3>(grid, block, smem, stream, p);
     } else if (p.mode == MODE_DECIMATE) {
-        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DECIMATE, 3>), grid, block, smem, stream, p);
+        return launch_ws<MW, NW, WM, WN, MODE_DECIMATE, 3>(grid, block, smem, stream, p);
     } else {
-        hipLaunchKernelGGL((conv_mfma_ws_kernel<MW, NW, WM, WN, MODE_DIRECT, 3>), grid, block, smem, stream, p);
+        return launch_ws<MW, NW, WM, WN, MODE_DIRECT, 3>(grid, block, smem, stream, p);
     }
     return hipGetLastError();
 }
