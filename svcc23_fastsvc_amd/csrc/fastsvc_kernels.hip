@@ -668,7 +668,12 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, int voff, f
 // only dword-aligned then, and the float4 that straddles the end of a row is handled by element:
 // nv = number of its elements that belong to the row (4 everywhere else, 0 for lanes off the tile).
 __device__ __forceinline__ void buf_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
-    if (nv >= 4) {
+    // wave-uniform fast path: no lane of the wave is a partial float4 (rows that are a multiple of 4 long,
+    // i.e. nearly always) -> ONE store instead of four; vmcnt counts every one of them, and the weight
+    // ring's counted waits drain whatever stores are ahead of them
+    if (__builtin_amdgcn_ballot_w64(nv > 0 && nv < 4) == 0) {
+        buf_store4(r, nv > 0 ? voff : 0x7ffffff0, v);
+    } else if (nv >= 4) {
         buf_store4(r, voff, v);
     } else {
         // element stores with the offset pushed out of range for the elements past the row end
@@ -719,7 +724,9 @@ __device__ __forceinline__ void act_store4(__amdgpu_buffer_rsrc_t r, int voff, f
     __builtin_amdgcn_raw_buffer_store_b64(w, r, voff >> 1, 0, 0);
 }
 __device__ __forceinline__ void act_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
-    if (nv >= 4) {
+    if (__builtin_amdgcn_ballot_w64(nv > 0 && nv < 4) == 0) {      // see buf_store4_n
+        act_store4(r, nv > 0 ? voff : 0x7ffffff0, v);
+    } else if (nv >= 4) {
         act_store4(r, voff, v);
     } else {
         const float e0 = v[0], e1 = v[1], e2 = v[2];
