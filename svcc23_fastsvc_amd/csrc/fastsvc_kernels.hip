@@ -265,6 +265,7 @@ __device__ __forceinline__ void mfma_unit_poly(f32x4 (&acc)[3][NW][MW], const fl
             for (int tap = 0; tap < 3; ++tap)
                 #pragma unroll
                 for (int n = 0; n < NW; ++n) av[(j + 1) & 1][tap][n] = xa0[tap + (j + 1) * 4 * XS + n * 16];
+            __builtin_amdgcn_sched_barrier(0);
         }
         #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
@@ -314,7 +315,7 @@ __device__ __forceinline__ void mfma_unit_wino(f32x4 (&acc)[4][NW][MW], const fl
         #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
             const int j = 3 * h + jj;
-            if (j + 1 < 6) fetch((j + 1) & 1, j + 1);
+            if (j + 1 < 6) { fetch((j + 1) & 1, j + 1); __builtin_amdgcn_sched_barrier(0); }   // reads stay ahead of the MFMAs
             #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int slot = (RING == 24 ? h * 12 : 0) + c * 3 + jj;
@@ -361,7 +362,7 @@ __device__ __forceinline__ void mfma_unit_dec2(f32x4 (&acc)[2][NW][MW], const fl
         #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
             const int j = 3 * h + jj;
-            if (j + 1 < 6) fetch((j + 1) & 1, j + 1);
+            if (j + 1 < 6) { fetch((j + 1) & 1, j + 1); __builtin_amdgcn_sched_barrier(0); }
             #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int slot = h * 12 + c * 3 + jj;
