@@ -30,7 +30,7 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
 write = per_kernel(os.path.join(src, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE")
-rows, js = [], {}
+rows, js, merged = [], {}, {}
 for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     if "fastsvc" not in k:
         continue
@@ -40,9 +40,13 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     rows.append((k, fetch[k][1], f_kib, w_kib, hbm))
     # template arguments: MW, NW, WM, WN, mode, ntaps, epilogue kind, S (polyphase stretch / Winograd
     # dilation, else 1) - bench.py names the kernels by the same eight numbers
-    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", k)
+    # (a ninth argument, resident weights true / false, does not change the traffic model: merged)
+    m = re.search(r"conv_mfma_ws_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", k)
     if m:
-        js["conv_mfma_ws<%s,%s,%s,%s,%s,%s,%s,%s>" % m.groups()] = hbm
+        key = "conv_mfma_ws<%s,%s,%s,%s,%s,%s,%s,%s>" % m.groups()
+        n0 = merged.get(key, 0)
+        js[key] = (js.get(key, 0.0) * n0 + hbm * fetch[k][1]) / (n0 + fetch[k][1])
+        merged[key] = n0 + fetch[k][1]
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
     if m:
         js["conv_mfma<%s,%s,%s,%s>" % m.groups()] = hbm
