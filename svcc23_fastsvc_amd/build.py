@@ -15,6 +15,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip.so")
+# the stamped diagnostic build (--timeline) is a separate file: loaded only when FASTSVC_HIP_LIB names it
+TIMELINE_LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip_timeline.so")
 SOURCES = ["fastsvc_kernels.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip"]
 HEADERS = [os.path.join(CSRC, "fastsvc_kernels.h"), os.path.join(ROOT, "include", "fastsvc_hip.h")]
 ARCH = "gfx950"
@@ -47,7 +49,8 @@ UNITS = [
 
 def build(force: bool = False, verbose: bool = False, timeline: bool = False) -> str:
     """timeline=True: diagnostic build with per-wave cycle stamps in the pipelined kernel
-    (-DFASTSVC_TIMELINE, tools/timeline.py); never used for measurements of record."""
+    (-DFASTSVC_TIMELINE, tools/timeline.py) written to libfastsvc_hip_timeline.so, which only
+    tools/timeline.py loads (FASTSVC_HIP_LIB); the product library is left untouched."""
     if not force and not timeline and not needs_build():
         return LIB_PATH
     import tempfile
@@ -67,15 +70,16 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
             out, _ = pr.communicate()
             if pr.returncode != 0:
                 raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
+        out_path = TIMELINE_LIB_PATH if timeline else LIB_PATH
         link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + [os.path.join(tmp, u[2]) for u in UNITS] + \
-               ["-o", LIB_PATH + ".tmp"]
+               ["-o", out_path + ".tmp"]
         if verbose:
             print(" ".join(link), file=sys.stderr)
         res = subprocess.run(link, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out_path + ".tmp", out_path)
+    return out_path
 
 
 if __name__ == "__main__":

@@ -17,7 +17,10 @@ import torch
 from .synth import GeneratorConfig
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfastsvc_hip.so")
+# FASTSVC_HIP_LIB: load another build of the same ABI (tools/timeline.py points it at the stamped
+# diagnostic library); there is no fallback of any kind - a missing library is an error
+_LIB_PATH = os.environ.get("FASTSVC_HIP_LIB") or \
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfastsvc_hip.so")
 MAX_STAGES = 8
 # launch shapes measured once on an MI355X by tools/tune_shapes.py (fastsvc_autotune winners for
 # the BASELINE.json workloads); other (B, F) fall back to the static cost model or model.autotune

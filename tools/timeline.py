@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Per-wave phase timeline of ONE launch of the pipelined convolution kernel (diagnostic).
 
-Needs the stamped build:  python -m svcc23_fastsvc_amd.build --force --timeline
-(rebuild without --timeline afterwards; stamped binaries are never used for numbers of record).
+Needs the stamped build:  python -m svcc23_fastsvc_amd.build --timeline   (-> libfastsvc_hip_timeline.so,
+a separate file that only this tool loads; the product library is never stamped).
 
     python tools/timeline.py cfg2 up.3.d9 [more layers ...]
 
@@ -19,7 +19,9 @@ from collections import defaultdict
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("FASTSVC_HIP_LIB", os.path.join(ROOT, "svcc23_fastsvc_amd", "libfastsvc_hip_timeline.so"))
 
 TAGS = {1: "entry", 2: "issued", 3: "commit0", 4: "bar0", 5: "staged", 6: "bar", 7: "mfma", 8: "epi"}
 
@@ -44,14 +46,11 @@ def analyse(path, layer):
         m = tag[w, :, :62] > 0
         last[w] = cyc[w, :, :62][m].max() if m.any() else 0
     ok = last > 0
-    t0 = t_in[ok].min()
+    # (s_memtime is per XCD and the eight counters are not synchronised: only differences inside one
+    # workgroup are meaningful, so there is no kernel-wide span here)
     span = (last - t_in)[ok]
-    print(f"kernel span {last[ok].max() - t0} cyc; workgroup life: median {int(np.median(span))}, "
-          f"p10 {int(np.percentile(span, 10))}, p90 {int(np.percentile(span, 90))} cyc")
-    # start waves: how many distinct start times
-    starts = np.sort(t_in[ok] - t0)
-    late = (starts > np.median(span) * 0.5).sum()
-    print(f"workgroups starting after half a median life: {late} of {ok.sum()} (second wave of the launch)")
+    print(f"workgroup life: median {int(np.median(span))}, p10 {int(np.percentile(span, 10))}, "
+          f"p90 {int(np.percentile(span, 90))} cyc")
     cus = set(zip(xcc[ok, 0], se[ok, 0], sh[ok, 0], cu[ok, 0]))
     print(f"distinct (xcc, se, sh, cu) seen: {len(cus)}; simd of wave 0..7 in wg 0: {simd[0].tolist()}")
     # phase durations per role
