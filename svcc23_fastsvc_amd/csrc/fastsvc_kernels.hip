@@ -725,9 +725,7 @@ __device__ __forceinline__ void act_store4(__amdgpu_buffer_rsrc_t r, int voff, f
     __builtin_amdgcn_raw_buffer_store_b64(w, r, voff >> 1, 0, 0);
 }
 __device__ __forceinline__ void act_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
-    if (__builtin_amdgcn_ballot_w64(nv > 0 && nv < 4) == 0) {      // see buf_store4_n
-        act_store4(r, nv > 0 ? voff : 0x7ffffff0, v);
-    } else if (nv >= 4) {
+    if (nv >= 4) {
         act_store4(r, voff, v);
     } else {
         const float e0 = v[0], e1 = v[1], e2 = v[2];
@@ -866,6 +864,33 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsigned lds
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_byte), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
+__device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t r, unsigned lds_byte, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_byte), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+// One 16 x 16 item of an activation tensor (this lane's four consecutive elements) into the wave's slot.
+// float32: one 16-byte piece per lane (1 KB slot).  bfloat16 storage: the lane's 8 bytes go as two
+// dword pieces (LDS-DMA has no 8-byte form): elements 0-1 in the first 256 B of the slot, 2-3 in the second.
+#ifdef FASTSVC_ACT_BF16
+constexpr int EST_ITEM_FLOATS = 128;
+__device__ __forceinline__ void est_fetch(__amdgpu_buffer_rsrc_t r, unsigned slot_byte, int off, int soff) {
+    lds_dma4(r, slot_byte, off >> 1, soff >> 1);
+    lds_dma4(r, slot_byte + 256, (off >> 1) + 4, soff >> 1);
+}
+__device__ __forceinline__ f32x4 est_read(const float* slot, int lane) {
+    const unsigned w0 = __builtin_bit_cast(unsigned, slot[lane]), w1 = __builtin_bit_cast(unsigned, slot[64 + lane]);
+    return f32x4{__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                 __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+}
+#else
+constexpr int EST_ITEM_FLOATS = 256;
+__device__ __forceinline__ void est_fetch(__amdgpu_buffer_rsrc_t r, unsigned slot_byte, int off, int soff) {
+    lds_dma16(r, slot_byte, off, soff);
+}
+__device__ __forceinline__ f32x4 est_read(const float* slot, int lane) {
+    return reinterpret_cast<const f32x4*>(slot)[lane];
+}
+#endif
 // all pieces landed: they are older than the NEWER weight-ring loads of at least one unit
 template <int NEWER>
 __device__ __forceinline__ void ws_epilogue_stage_wait(bool counted) {
@@ -887,12 +912,13 @@ __device__ __forceinline__ void ws_epilogue_stage(const ConvParams& p, const Epi
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 16 + (lane >> 4) * 4;
             const int off = (cok && t < p.T) ? (rowoff + t) * 4 : OOB_OFF;
-            const unsigned slot = base + (m * NW + n) * 1024;
-            if (EPI == EPI_RES) lds_dma16(R.res, slot, off, 0);
+            constexpr int IB = EST_ITEM_FLOATS * 4;            // bytes of one item slot
+            const unsigned slot = base + (m * NW + n) * IB;
+            if (EPI == EPI_RES) est_fetch(R.res, slot, off, 0);
             if (EPI == EPI_AFF) {
-                lds_dma16(R.ss, slot, off, 0);
-                lds_dma16(R.ss, slot + MW * NW * 1024, off, shift_soff);
-                if (p.res) lds_dma16(R.res, slot + 2 * MW * NW * 1024, off, 0);
+                est_fetch(R.ss, slot, off, 0);
+                est_fetch(R.ss, slot + MW * NW * IB, off, shift_soff);
+                if (p.res) est_fetch(R.res, slot + 2 * MW * NW * IB, off, 0);
             }
         }
     }
@@ -929,12 +955,12 @@ __device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiR
                 nv[g] = TAIL ? (ok ? row_valid(t, p.T) : 0) : 4;
                 off[g] = ok ? (rowoff + t) * 4 : OOB_OFF;
                 if constexpr (EST) {
-                    const f32x4* slot = reinterpret_cast<const f32x4*>(Ew + (m * NW + n0 + g) * 256) + lane;
-                    if (EPI == EPI_RES) l0[g] = slot[0];
+                    const float* slot = Ew + (m * NW + n0 + g) * EST_ITEM_FLOATS;
+                    if (EPI == EPI_RES) l0[g] = est_read(slot, lane);
                     if (EPI == EPI_AFF) {
-                        l1[g] = slot[0];
-                        l2[g] = slot[MW * NW * 64];
-                        l0[g] = p.res ? slot[2 * MW * NW * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        l1[g] = est_read(slot, lane);
+                        l2[g] = est_read(slot + MW * NW * EST_ITEM_FLOATS, lane);
+                        l0[g] = p.res ? est_read(slot + 2 * MW * NW * EST_ITEM_FLOATS, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 } else {
                     if (EPI == EPI_RES) l0[g] = act_load4(R.res, off[g], 0);
@@ -1112,18 +1138,21 @@ __device__ __forceinline__ void ws_epilogue_dec2(const ConvParams& p, const EpiR
 // a 2*S-load epilogue: 256 (those layers launch about one workgroup per CU anyway).
 // MW == 3, NW == 2 fits 128 only with the plain / residual epilogues (no extra epilogue operands).
 constexpr bool NTAPS_IS_3_DIRECT(int mode) { return mode == MODE_DIRECT; }
-// variants that stage their epilogue operands in LDS (ws_epilogue_stage); float32 storage only
+// variants that stage their epilogue operands in LDS (ws_epilogue_stage)
 template <int MW, int NW, int MODE, int EPI>
 constexpr bool ws_estage() {
-#ifdef FASTSVC_ACT_BF16
-    return false;
-#else
     return MODE == MODE_DIRECT &&
            ((EPI == EPI_AFF && MW * NW <= 4) || (EPI == EPI_RES && MW * NW <= 6));
-#endif
 }
 template <int MW, int NW, int MODE, int EPI>
 constexpr int ws_min_waves() {
+#ifdef FASTSVC_ACT_BF16
+    // bfloat16 storage: the pack / unpack temporaries push these variants over 128 registers
+    if (MODE == MODE_POLY && EPI == EPI_AFF) return 2;
+    if (MODE == MODE_DEC2 && NW == 2) return 2;
+    if (MW == 2 && NW == 4 && (EPI == EPI_AFF || EPI == EPI_RANK1)) return 2;
+    if (MW == 3 && NW == 2) return 2;
+#endif
     if (MODE == MODE_POLY) return (MW <= 2 && NW == 1) ? 4 : 2;
     if (MODE == MODE_WINO) return (MW == 2 && NW == 1) ? 4 : 2;   // four accumulator sets + a 24-slot weight ring
     if (MODE == MODE_DEC2) return MW <= 2 ? 4 : 2;                // two accumulator sets + a 24-slot weight ring
@@ -1378,7 +1407,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         constexpr bool EST = ws_estage<MW, NW, MODE, EPI>();
         // this wave's epilogue-operand slots, behind the window buffers (launch_conv_pipe sizes them)
         float* Ew = Xs0 + ((p.nchunks > 1 || p.tpw > 1) ? 2 : 1) * bufsz
-                        + cw * ((EPI == EPI_RES ? 1 : p.res ? 3 : 2) * MW * NW * 256);
+                        + cw * ((EPI == EPI_RES ? 1 : p.res ? 3 : 2) * MW * NW * EST_ITEM_FLOATS);
         EpiRsrc R;
         {
             const long ct = (long)p.COUT * p.ldy;       // rows of y / y2 / res / scale / shift at the output pitch
@@ -1392,7 +1421,12 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
             R.r1x = make_rsrc(p.r1x ? p.r1x + (long)sig * p.r1x_sig + (long)b * p.r1x_b : nul, p.r1x ? p.ldy : 0);
         }
         // (variants already at their register budget fetch them per tile instead)
-        constexpr bool HOIST = !(WINO && ((MW == 3 && NW == 2) || EPI == EPI_RANK1)) &&
+#ifdef FASTSVC_ACT_BF16
+        constexpr bool HOIST_OK = false;        // the bf16 pack / unpack temporaries take those registers
+#else
+        constexpr bool HOIST_OK = true;
+#endif
+        constexpr bool HOIST = HOIST_OK && !(WINO && ((MW == 3 && NW == 2) || EPI == EPI_RANK1)) &&
                                !(MODE == MODE_STRETCH && NW == 4) && !(MW == 3 && EPI == EPI_RANK1) &&
                                !(POLY && S == 5 && EPI == EPI_AFF) &&
                                !(MW == 2 && NW == 4 && (EPI == EPI_RANK1 || EPI == EPI_AFF)) && !(DEC2 && MW == 2 && NW == 2);
@@ -1571,7 +1605,7 @@ template <int MW, int NW, int WM, int WN, int MODE, int NTAPS, int EPI = EPI_GEN
 static hipError_t launch_ws(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const ConvParams& p) {
     if constexpr (ws_estage<MW, NW, MODE, EPI>()) {
         const bool aff_epi = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
-        smem += sizeof(float) * 4 * (size_t)(aff_epi ? (p.res ? 3 : 2) : 1) * MW * NW * 256;
+        smem += sizeof(float) * 4 * (size_t)(aff_epi ? (p.res ? 3 : 2) : 1) * MW * NW * EST_ITEM_FLOATS;
     }
     constexpr int NSTEPS = (MODE == MODE_WINO || MODE == MODE_DEC2) ? 24 : 6 * NTAPS;
     if constexpr (MW == 2) {

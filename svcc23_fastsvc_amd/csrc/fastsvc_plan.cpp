@@ -751,7 +751,8 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             }
         };
         char key[96];
-        std::snprintf(key, sizeof(key), "%s|%d|%d", layer, p.B, p.T);
+        // bfloat16 storage compiles some variants under a different register budget: its own entries ("|b")
+        std::snprintf(key, sizeof(key), act_bf16 ? "%s|%d|%d|b" : "%s|%d|%d", layer, p.B, p.T);
         bool have = false;
         Cand best = cands[0];
         if (g_tune.plan) {

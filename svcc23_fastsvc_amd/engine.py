@@ -160,7 +160,7 @@ class Plan:
         self._h = handle
         if storage == "bfloat16":
             _check(self.lib, self.lib.fastsvc_plan_set_storage(handle, 1), "fastsvc_plan_set_storage")
-            load_shipped_table = False           # the shipped table was measured with float32 storage
+            # (bfloat16 launches look their shapes up under "<layer>|<B>|<T>|b": separate entries of the same table)
         self.last_autotune_trials = 0
         if load_shipped_table:
             self.load_tuned_file(TUNED_TABLE_PATH, missing_ok=True)

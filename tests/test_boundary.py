@@ -188,8 +188,8 @@ def test_launch_shape_table_roundtrip_and_shipped_file():
     table = doc["tables"][plan.config_signature()]
     assert len(table) > 40
     for key, (nw, wm, wn, tpw, algo) in table.items():
-        layer, b, t = key.split("|")
-        assert int(b) >= 1 and int(t) >= 1 and layer
+        layer, b, t, *storage = key.split("|")                      # "...|b": entries of the bfloat16-storage mode
+        assert int(b) >= 1 and int(t) >= 1 and layer and storage in ([], ["b"])
         assert nw in (1, 2, 4) and wm * wn == 4 and 1 <= tpw <= 16 and algo in (0, 1, 2)
     shipped = A.Plan(S.FULL_CONFIG)
     assert shipped.tuned_shapes() == {k: list(v) for k, v in table.items()}

@@ -15,17 +15,19 @@ from svcc23_fastsvc_amd import synth as S
 from svcc23_fastsvc_amd.engine import TUNED_TABLE_PATH
 
 REPS = 3
-names = sys.argv[1:] or ["cfg1", "cfg2"]
+names = sys.argv[1:] or ["cfg1", "cfg2"]          # "cfg3:bf16" tunes the bfloat16-storage entries (keys end in "|b")
 cfg = S.FULL_CONFIG
 dev = torch.device("cuda:0")
 votes = collections.defaultdict(collections.Counter)
 sig = None
 for name in names:
+    name, _, st = name.partition(":")
+    storage = "bfloat16" if st == "bf16" else "float32"
     wl = S.WORKLOADS[name]
     b = S.synth_batch(cfg, wl["B"], wl["F"], wl["seed"])
     ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
     for rep in range(REPS):
-        plan = A.Plan(cfg, load_shipped_table=False)
+        plan = A.Plan(cfg, load_shipped_table=False, storage=storage)
         sig = plan.config_signature()
         blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
         ws = torch.empty(plan.workspace_bytes(wl["B"], wl["F"]), dtype=torch.uint8, device=dev)
@@ -33,7 +35,7 @@ for name in names:
         plan.forward(blob, *ins, workspace=ws, autotune=True)
         for k, v in plan.tuned_shapes().items():
             votes[k][tuple(v)] += 1
-        print(f"{name} rep {rep}: {plan.last_autotune_trials} trials", file=sys.stderr)
+        print(f"{name} ({storage}) rep {rep}: {plan.last_autotune_trials} trials", file=sys.stderr)
 table = {k: list(c.most_common(1)[0][0]) for k, c in sorted(votes.items())}
 doc = {"tables": {}}
 if os.path.exists(TUNED_TABLE_PATH):
