@@ -135,7 +135,8 @@ int fastsvc_autotune(const fastsvc_plan* plan, const void* dev_blob,
                      void* workspace, size_t workspace_bytes, void* stream, int32_t* n_trials);
 
 /* Launch-shape table.  fastsvc_autotune stores its winners in the plan under keys
- * "<layer>|<B>|<T>"; these entry points export them and load them back (a table measured once on an
+ * "<layer>|<B>|<T>" ("<layer>|<B>|<T>|b" while the plan uses bfloat16 activation storage, whose variants
+ * compile under different register budgets); these entry points export them and load them back (a table measured once on an
  * MI355X ships as svcc23_fastsvc_amd/tuned_mi355x.json, so production runs need no trial launches).
  * An entry whose shape is not compiled for that layer is ignored at launch time (cost model instead).
  *   fastsvc_tuned_count: number of entries;
