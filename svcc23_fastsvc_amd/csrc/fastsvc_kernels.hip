@@ -900,13 +900,13 @@ __device__ __forceinline__ void ws_epilogue_stage_wait(bool counted) {
 
 template <int MW, int NW, int EPI>
 __device__ __forceinline__ void ws_epilogue_stage(const ConvParams& p, const EpiRsrc& R, const float* Ew,
-                                                  int mg, int tcol0, int lane, bool live) {
+                                                  int mg, int tcol0, int lane) {
     const int shift_soff = p.COUT * p.ldy * 4;
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)Ew;
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int cot = (mg * MW + m) * 16 + (lane & 15);
-        const bool cok = live && cot < p.COUT;
+        const bool cok = cot < p.COUT;
         const int rowoff = (cok ? cot : 0) * p.ldy;
         #pragma unroll
         for (int n = 0; n < NW; ++n) {
@@ -1485,7 +1485,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                 if constexpr (EST) {
                     // one unit earlier when the tile has several K chunks: more time to land
                     if (active && ch == max(p.nchunks - 2, 0) && !(p.dbg & DBG_NO_EPILOGUE))
-                        ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane, true);
+                        ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                 }
                 if (active && !(p.dbg & DBG_NO_MFMA)) {
                     constexpr bool RL = !WSTATIC;      // WSTATIC: the ring holds the whole layer, nothing to re-request
