@@ -193,6 +193,9 @@ def test_launch_shape_table_roundtrip_and_shipped_file():
         assert nw in (1, 2, 4) and wm * wn == 4 and 1 <= tpw <= 16 and algo in (0, 1, 2)
     shipped = A.Plan(S.FULL_CONFIG)
     assert shipped.tuned_shapes() == {k: list(v) for k, v in table.items()}
+    # the bfloat16-storage plan holds the same table; its launches look up the "|b" keys
+    assert any(k.endswith("|b") for k in table) and any(not k.endswith("|b") for k in table)
+    assert A.Plan(S.FULL_CONFIG, storage="bfloat16").tuned_shapes() == shipped.tuned_shapes()
 
 
 def test_decode_harness_f0_statistics_match_reference_golden(tmp_path):
