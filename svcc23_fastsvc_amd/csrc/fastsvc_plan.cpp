@@ -771,7 +771,8 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (!have && g_tune.tuning && g_tune.plan) {
             // time every (shape, tiles-per-workgroup) on the device; InstanceNorm sums are not
             // accumulated by the trial launches (the real launch below does that once)
-            static const int tpws[] = {1, 2, 3, 4, 6, 8, 12, 16};
+            // (fine steps matter: the winner is often the count that fills the last round of workgroups best)
+            static const int tpws[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24};
             hipEvent_t e0, e1;
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return hipErrorUnknown;
             float best_ms = 1e30f;

@@ -190,7 +190,7 @@ def test_launch_shape_table_roundtrip_and_shipped_file():
     for key, (nw, wm, wn, tpw, algo) in table.items():
         layer, b, t, *storage = key.split("|")                      # "...|b": entries of the bfloat16-storage mode
         assert int(b) >= 1 and int(t) >= 1 and layer and storage in ([], ["b"])
-        assert nw in (1, 2, 4) and wm * wn == 4 and 1 <= tpw <= 16 and algo in (0, 1, 2)
+        assert nw in (1, 2, 4) and wm * wn == 4 and 1 <= tpw <= 24 and algo in (0, 1, 2)
     shipped = A.Plan(S.FULL_CONFIG)
     assert shipped.tuned_shapes() == {k: list(v) for k, v in table.items()}
     # the bfloat16-storage plan holds the same table; its launches look up the "|b" keys

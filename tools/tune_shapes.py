@@ -6,7 +6,8 @@
 
 For every workload it runs fastsvc_autotune (each pipelined conv times all its candidate tile shapes
 and tiles-per-workgroup on the device) REPS times and keeps, per layer, the shape that won most
-often.  Keys are "<layer>|<B>|<T>", so entries of different workloads do not collide."""
+often; that is done ROUNDS times and the table whose whole forward is fastest is kept (single-launch
+timings of close candidates are noisy at the 1-2 % level).  Keys are "<layer>|<B>|<T>", so entries of different workloads do not collide."""
 import collections, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,25 +19,49 @@ REPS = 3
 names = sys.argv[1:] or ["cfg1", "cfg2"]          # "cfg3:bf16" tunes the bfloat16-storage entries (keys end in "|b")
 cfg = S.FULL_CONFIG
 dev = torch.device("cuda:0")
-votes = collections.defaultdict(collections.Counter)
+ROUNDS = 3          # independent tunings per workload; the table that runs the whole forward fastest is kept
 sig = None
+table = {}
+
+
+def time_forward(plan, blob, ins, ws, n=30):
+    for _ in range(5):
+        plan.forward(blob, *ins, workspace=ws)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        plan.forward(blob, *ins, workspace=ws)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
 for name in names:
     name, _, st = name.partition(":")
     storage = "bfloat16" if st == "bf16" else "float32"
     wl = S.WORKLOADS[name]
     b = S.synth_batch(cfg, wl["B"], wl["F"], wl["seed"])
     ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
-    for rep in range(REPS):
+    best = (1e30, None)
+    for rnd in range(ROUNDS):
+        votes = collections.defaultdict(collections.Counter)
+        for rep in range(REPS):
+            plan = A.Plan(cfg, load_shipped_table=False, storage=storage)
+            sig = plan.config_signature()
+            blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
+            ws = torch.empty(plan.workspace_bytes(wl["B"], wl["F"]), dtype=torch.uint8, device=dev)
+            plan.forward(blob, *ins, workspace=ws)
+            plan.forward(blob, *ins, workspace=ws, autotune=True)
+            for k, v in plan.tuned_shapes().items():
+                votes[k][tuple(v)] += 1
+        cand = {k: list(c.most_common(1)[0][0]) for k, c in sorted(votes.items())}
         plan = A.Plan(cfg, load_shipped_table=False, storage=storage)
-        sig = plan.config_signature()
-        blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
-        ws = torch.empty(plan.workspace_bytes(wl["B"], wl["F"]), dtype=torch.uint8, device=dev)
-        plan.forward(blob, *ins, workspace=ws)
-        plan.forward(blob, *ins, workspace=ws, autotune=True)
-        for k, v in plan.tuned_shapes().items():
-            votes[k][tuple(v)] += 1
-        print(f"{name} ({storage}) rep {rep}: {plan.last_autotune_trials} trials", file=sys.stderr)
-table = {k: list(c.most_common(1)[0][0]) for k, c in sorted(votes.items())}
+        plan.load_tuned(cand)
+        ms = time_forward(plan, blob, ins, ws)
+        print(f"{name} ({storage}) tuning {rnd}: {plan.last_autotune_trials or ''} forward {ms:.4f} ms", file=sys.stderr)
+        if ms < best[0]:
+            best = (ms, cand)
+    table.update(best[1])
 doc = {"tables": {}}
 if os.path.exists(TUNED_TABLE_PATH):
     doc = json.load(open(TUNED_TABLE_PATH))
