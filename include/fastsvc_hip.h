@@ -17,8 +17,12 @@
  *   - device memory is owned by the caller (PyTorch's caching allocator in the shipped host
  *     code): the packed weight blob, the workspace, the inputs and the output.  The plan object
  *     is host-only and immutable after creation, so one plan may serve several devices/streams.
- *   - every launch goes to the hipStream_t passed in; no hidden synchronisation, no allocation
- *     inside fastsvc_forward (hipGraph-capturable).
+ *   - every launch is ordered with respect to the hipStream_t passed in (kernels off the critical
+ *     path run on helper streams forked from and joined back into it with events); no hidden
+ *     synchronisation.  The helper streams / events of a (device, stream) pair are created by the
+ *     FIRST forward on that pair, or ahead of time by fastsvc_stream_prepare(); after that a forward
+ *     allocates nothing.  Concurrent forwards on DIFFERENT streams are independent; forwards issued
+ *     from several host threads on the SAME stream are serialised while they enqueue.
  *   - return value 0 = success; negative = FASTSVC_E_*; fastsvc_last_error() gives the text.
  */
 #ifndef FASTSVC_HIP_H
@@ -115,6 +119,11 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
                     const float* ppg, const float* sine, const float* lft, const float* spk_emb,
                     float* out, int32_t B, int32_t F, const int32_t* lengths,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Creates the helper streams / events fastsvc_forward uses for `stream` on the current device, so
+ * that the forward itself allocates nothing (call once per stream, e.g. before graph capture or
+ * a latency-critical first call).  Idempotent. */
+int fastsvc_stream_prepare(void* stream);
 
 /* Test / profiling support: location of a named intermediate tensor inside the workspace after a
  * forward (names as in oracle/fastsvc_oracle.py taps: "down_lft.0", "scale.2", "up.1.xmid", ...).

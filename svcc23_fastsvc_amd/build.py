@@ -33,7 +33,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -53,31 +53,46 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
     tools/timeline.py loads (FASTSVC_HIP_LIB); the product library is left untouched."""
     if not force and not timeline and not needs_build():
         return LIB_PATH
-    import tempfile
+    import hashlib
     hipcc = _hipcc()
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
               "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     if timeline:
         common.append("-DFASTSVC_TIMELINE=1")
-    with tempfile.TemporaryDirectory(prefix="fastsvc_build_") as tmp:
-        procs = []
-        for src, extra, obj in UNITS:
-            cmd = [hipcc, *common, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", os.path.join(tmp, obj)]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        for cmd, pr in procs:
-            out, _ = pr.communicate()
-            if pr.returncode != 0:
-                raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
-        out_path = TIMELINE_LIB_PATH if timeline else LIB_PATH
-        link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + [os.path.join(tmp, u[2]) for u in UNITS] + \
-               ["-o", out_path + ".tmp"]
+    # object cache (git-ignored build/ directory): a unit is recompiled only when its source, any header
+    # under csrc/ or include/, or its flags changed - one kernel file takes minutes, the host file seconds
+    cache = os.path.join(PKG_DIR, "build")
+    os.makedirs(cache, exist_ok=True)
+    hdr_hash = hashlib.sha1()
+    for h in sorted(HEADERS + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]):
+        hdr_hash.update(open(h, "rb").read())
+    procs, objs = [], []
+    for src, extra, obj in UNITS:
+        key = hashlib.sha1(open(os.path.join(CSRC, src), "rb").read() + hdr_hash.digest() +
+                           " ".join(common + extra).encode()).hexdigest()[:16]
+        path = os.path.join(cache, f"{os.path.splitext(obj)[0]}_{key}.o")
+        objs.append(path)
+        if os.path.exists(path) and not force:
+            continue
+        for stale in os.listdir(cache):
+            if stale.startswith(os.path.splitext(obj)[0] + "_") and stale.endswith(".o"):
+                os.remove(os.path.join(cache, stale))
+        cmd = [hipcc, *common, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", path + ".tmp"]
         if verbose:
-            print(" ".join(link), file=sys.stderr)
-        res = subprocess.run(link, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, path, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, path, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
+        os.replace(path + ".tmp", path)
+    out_path = TIMELINE_LIB_PATH if timeline else LIB_PATH
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", out_path + ".tmp"]
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    res = subprocess.run(link, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     os.replace(out_path + ".tmp", out_path)
     return out_path
 

@@ -9,6 +9,7 @@
 // InstanceNorm statistics are produced by the epilogue of the kernel that writes the tensor.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -609,17 +610,25 @@ struct Profiler {
 // asynchronous with respect to the host and ordered with respect to the caller's stream.
 struct ExecCtx {
     hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev[48];
-    int nev = 0;
+    std::vector<hipEvent_t> ev;
+    std::mutex busy;                   // one forward at a time enqueues through a context
 };
 
-ExecCtx* exec_ctx_for_current_device() {
+// One context per (device, caller stream): two host threads driving different streams of one device
+// get their own helper streams and event rings, so a wait can never bind to the other thread's
+// record; two threads sharing ONE stream serialise on `busy` for the duration of the enqueue.
+// `nev` events cover every fork/join of a forward with FASTSVC_MAX_STAGES stages and all helper
+// streams enabled (2 per down stage + 2 per up block + 1 ss_ready per stage, with slack), so the
+// ring never wraps inside one call.  Created on first use: the call that creates it allocates
+// streams/events and is therefore not graph-capturable - fastsvc_forward_prepare() does it ahead.
+ExecCtx* exec_ctx_for(hipStream_t stream) {
     static std::mutex mu;
-    static std::map<int, ExecCtx*> ctxs;
+    static std::map<std::pair<int, hipStream_t>, ExecCtx*> ctxs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = ctxs.find(dev);
+    const auto key = std::make_pair(dev, stream);
+    auto it = ctxs.find(key);
     if (it != ctxs.end()) return it->second;
     ExecCtx* c = new ExecCtx();
     // the FiLM helper stream runs at the LOWEST priority: its kernels only fill the CUs the
@@ -628,10 +637,11 @@ ExecCtx* exec_ctx_for_current_device() {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = numerically largest
     if (hipStreamCreateWithPriority(&c->aux[0], hipStreamNonBlocking, prio_lo) != hipSuccess) { delete c; return nullptr; }
     if (hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-    for (int i = 0; i < 48; ++i)
+    const int nev = 8 * FASTSVC_MAX_STAGES + 16;
+    c->ev.resize(nev);
+    for (int i = 0; i < nev; ++i)
         if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
-    c->nev = 48;
-    ctxs[dev] = c;
+    ctxs[key] = c;
     return c;
 }
 
@@ -723,8 +733,9 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 if (ng2 % 4 == 0) cands.push_back(Cand{1, 4, 1, 2});
             }
         }
-        if ((p.T & 3) != 0) {
-            // rows that are not a multiple of 4 long: only the variants compiled with the row-end handling
+        if ((p.T & 3) != 0 || (p.lens && (p.len_mul & 3) != 0)) {
+            // rows that are not a multiple of 4 long (with a ragged batch: ANY utterance's own length,
+            // whatever the padded maximum is): only the variants compiled with the row-end handling
             std::vector<Cand> keep;
             for (const Cand& cd : cands)
                 if (conv_ws_tail_ok(cd.algo == 2 ? 2 : c.MW, cd.NW, cd.algo >= 1 ? (int)MODE_WINO : p.mode, epi_kind,
@@ -998,7 +1009,9 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     static const bool serial = std::getenv("FASTSVC_SERIAL") != nullptr;   // debugging: one stream
     g_tune.plan = plan;
     // per-launch profiling and autotuning run on ONE stream so that every kernel is timed alone
-    ExecCtx* ctx = (serial || g_tune.tuning || prof) ? nullptr : exec_ctx_for_current_device();
+    ExecCtx* ctx = (serial || g_tune.tuning || prof) ? nullptr : exec_ctx_for(stream);
+    std::unique_lock<std::mutex> ctx_lock;
+    if (ctx) ctx_lock = std::unique_lock<std::mutex>(ctx->busy);
     // FASTSVC_STREAMS: bit 0 = residual-conv helper stream, bit 1 = FiLM helper stream (experiments)
     // Measured with tuned launch shapes: the FiLM stream pays from ~10^5 samples per call (cfg2 -2 %),
     // below that the fork/join events cost more than the overlap (cfg1 +4 %); the residual-conv
@@ -1013,7 +1026,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     // `to` waits for everything enqueued on `from` so far
     auto order_after = [&](hipStream_t from, hipStream_t to) -> hipError_t {
         if (from == to || !ctx) return hipSuccess;
-        hipEvent_t e = ctx->ev[evi++ % ctx->nev];
+        hipEvent_t e = ctx->ev[evi++ % ctx->ev.size()];
         hipError_t r = hipEventRecord(e, from);
         if (r != hipSuccess) return r;
         return hipStreamWaitEvent(to, e, 0);
@@ -1028,7 +1041,20 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     int64_t hop = 1;
     for (int i = 0; i < n; ++i) hop *= P.cfg.upsampling_scales[i];
     const long T = (long)hop * F;
-    if (T > 0x7fffffffL / 4) return fail(FASTSVC_E_INVALID, "utterance too long");
+    {
+        // The kernels address every tensor of ONE utterance through a 32-bit buffer descriptor and
+        // 32-bit byte offsets ((row * pitch + t) * 4, 2*C rows for scale/shift): the largest of those
+        // spans must stay below 2 GiB.  (C = 24 at the full rate: ~11 M samples = 7.7 min at 24 kHz.)
+        long worst = 4L * T;
+        long Tk = T;
+        for (int k = 0; k < P.n; ++k) { Tk /= P.down[k].scale; worst = std::max(worst, 2L * P.down[k].C * Tk * 4); }   // film_u / ss: 2C rows
+        long Ti = F;
+        for (int i = 0; i < P.n; ++i) { Ti *= P.up[i].scale; worst = std::max(worst, 2L * P.up[i].C * Ti * 4); }
+        worst = std::max(worst, (long)P.cfg.in_channels * F * 4);
+        if (worst >= 0x7fffffffL)
+            return fail(FASTSVC_E_UNSUPPORTED, "utterance too long for the 32-bit tensor descriptors of the kernels "
+                                                "(largest per-utterance tensor must stay below 2 GiB): split it");
+    }
     const bool spk = spk_emb != nullptr;
 
     // ---- raw signals side by side: sig 0 = lft, sig 1 = sine ----
@@ -1144,7 +1170,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             q.y = buf("ss." + s); q.y_sig = 0; q.y_b = 2 * tb;
             HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, sf, prof, ("film." + s + ".heads").c_str()));
             if (sf != stream && ctx) {
-                ss_ready[k] = ctx->ev[evi++ % ctx->nev];
+                ss_ready[k] = ctx->ev[evi++ % ctx->ev.size()];
                 HIP_TRY(hipEventRecord(ss_ready[k], sf));
             }
         }
@@ -1236,6 +1262,11 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                                  P.cfg.out_channels, (int)T, lengths, (int)hop, stream));
     if (prof) HIP_TRY(prof->end());
     return FASTSVC_OK;
+}
+
+int fastsvc_stream_prepare(void* stream) {
+    return exec_ctx_for(static_cast<hipStream_t>(stream)) ? FASTSVC_OK
+                                                          : fail(FASTSVC_E_HIP, "could not create the helper streams / events");
 }
 
 int fastsvc_plan_set_storage(fastsvc_plan* plan, int32_t dtype) {

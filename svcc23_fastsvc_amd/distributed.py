@@ -4,18 +4,27 @@ The generator forward has no cross-utterance coupling (InstanceNorm is per (b, c
 row; SURVEY.md §8 e), so the path shards by UTTERANCE with no collective on the data path:
 
   * weights: rank 0 folds weight-norm and packs the kernel-layout blob once, then broadcasts it
-    (`broadcast_packed_weights`, 34.5 MB fp32: every kernel-layout copy of the weights) - the other ranks never touch the checkpoint;
+    (`broadcast_packed_weights`: every kernel-layout copy of the weights) - the other ranks never
+    touch the checkpoint;
   * work: the utterance list is split by a longest-processing-time greedy so that every rank gets
     the same number of frames (`shard_utterances`); each rank runs the single-GPU path on
     same-length buckets, or - `ragged=True` - on padded batches of SIMILAR length with per-utterance
     `lengths` (the kernels then keep every utterance's own zero padding and InstanceNorm length, so
     padding does not change the result);
-  * results: waveforms are all-gathered (`all_gather_waveforms`): one `all_gather_into_tensor`
-    when every rank holds the same shape, otherwise lengths first, then padded rows.
+  * results: waveforms are all-gathered in ROUNDS (`GatherSchedule`): the shard of every rank and
+    its batches are a deterministic function of the frame counts, which every rank knows, so the
+    shape of every round's buffer is computed locally - no metadata collective, no host
+    synchronisation; round r's `all_gather_into_tensor` is issued asynchronously right after the
+    rank's r-th batch and overlaps the next batch's kernels.  A rank with fewer batches (or none at
+    all: fewer utterances than ranks) contributes zero rows, on ITS device.
+  * staging: host-resident inputs go through two pinned staging buffers and a copy stream, so
+    batch k+1 is uploaded while batch k computes (`_Stager`); device-resident inputs are stacked in
+    place.
 
-The reference has no distributed code at all; this module is new, and is
-exercised on CPU with the gloo backend in tests/test_distributed_cpu.py (world_size 2) using an
-injected forward function, and on GPUs by bench.py (`--gpus N`).
+The reference has no distributed code at all; this module is new.  It is exercised
+on CPU with the gloo backend in tests/test_distributed_cpu.py (world_size 2, including a rank with
+an empty shard) using an injected forward function, on one GPU with the nccl backend in
+tests/test_parity_gpu.py, and on N GPUs by `bench.py --workload cfg4`.
 """
 from __future__ import annotations
 
@@ -62,6 +71,18 @@ def bucket_ragged(indices: Sequence[int], n_frames: Sequence[int], max_batch: in
     return batches
 
 
+def plan_batches(indices: Sequence[int], n_frames: Sequence[int], max_batch: int, ragged: bool,
+                 pad_tolerance: float) -> List[List[int]]:
+    """The batches one rank runs, in order (deterministic: every rank can compute every rank's)."""
+    if ragged:
+        return bucket_ragged(indices, n_frames, max_batch, pad_tolerance)
+    out: List[List[int]] = []
+    for _, idxs in sorted(bucket_by_length(indices, n_frames).items()):
+        for k in range(0, len(idxs), max_batch):
+            out.append(idxs[k: k + max_batch])
+    return out
+
+
 def broadcast_packed_weights(generator, device, src: int = 0, group=None) -> torch.Tensor:
     """Rank `src` packs its (already loaded) parameters; every rank ends up with the device blob
     installed in `generator` (RCCL broadcast when `device` is a GPU)."""
@@ -76,91 +97,214 @@ def broadcast_packed_weights(generator, device, src: int = 0, group=None) -> tor
     return blob
 
 
-def all_gather_waveforms(local: List[Tuple[int, torch.Tensor]], n_total: int, group=None
-                         ) -> List[Optional[torch.Tensor]]:
-    """Collect (utterance index, waveform (C, T)) pairs from every rank; returns the list indexed by
-    utterance.  Equal shapes everywhere -> one all_gather_into_tensor; else lengths, then rows
-    padded to the longest."""
+class GatherSchedule:
+    """Round-by-round layout of the waveform all-gather, computed identically on every rank from
+    the frame counts alone.  Round r carries the r-th batch of every rank: a (rows_r, C, T_r) buffer
+    per rank with rows_r / T_r the largest batch / longest utterance of that round over all ranks."""
+
+    def __init__(self, n_frames: Sequence[int], hop: int, world: int, max_batch: int, ragged: bool,
+                 pad_tolerance: float):
+        self.world = world
+        self.hop = hop
+        self.n_frames = [int(f) for f in n_frames]
+        self.shards = shard_utterances(self.n_frames, world)
+        self.batches = [plan_batches(s, self.n_frames, max_batch, ragged, pad_tolerance) for s in self.shards]
+        self.n_rounds = max((len(b) for b in self.batches), default=0)
+        self.rows: List[int] = []
+        self.cols: List[int] = []
+        for r in range(self.n_rounds):
+            live = [b[r] for b in self.batches if r < len(b)]
+            self.rows.append(max(len(c) for c in live))
+            self.cols.append(max(self.n_frames[i] for c in live for i in c) * hop)
+
+    def batch(self, rank: int, r: int) -> List[int]:
+        return self.batches[rank][r] if r < len(self.batches[rank]) else []
+
+
+def all_gather_waveforms(local: List[Tuple[int, torch.Tensor]], n_total: int, group=None,
+                         device=None, channels: int = 1) -> List[Optional[torch.Tensor]]:
+    """Collect (utterance index, waveform (C, T)) pairs from every rank when the ranks do NOT share
+    a schedule (ad-hoc use; `run_utterance_parallel` needs no metadata exchange).  `device` /
+    `channels` say where and how wide this rank's buffers are even when it holds nothing - a rank
+    with an empty list must still join the collectives with tensors of the backend's device.
+    ONE packed metadata gather (count, then (index, T) pairs), one host read of it, one payload
+    gather padded to the longest row."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    dev = local[0][1].device if local else torch.device("cpu")
-    n_local = torch.tensor([len(local)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
+    if device is None:
+        if not local:
+            raise ValueError("all_gather_waveforms: pass `device` (this rank holds no waveform to infer it from)")
+        device = local[0][1].device
+    device = torch.device(device)
+    if local:
+        channels = int(local[0][1].shape[0])
+    cap = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    caps = [torch.zeros_like(cap) for _ in range(world)]
+    dist.all_gather(caps, cap, group=group)
+    counts = torch.stack(caps).flatten().tolist()                # the one unavoidable host read #1
     nmax = max(counts) if counts else 0
     if nmax == 0:
         return [None] * n_total
-    chans = local[0][1].shape[0] if local else 1
-    meta = torch.full((nmax, 2), -1, dtype=torch.int64, device=dev)       # (index, T)
+    meta = torch.full((nmax, 2), -1, dtype=torch.int64)
     for k, (i, y) in enumerate(local):
         meta[k, 0] = i
         meta[k, 1] = y.shape[-1]
+    meta = meta.to(device)
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
-    tmax = max(int(m[:, 1].max().item()) for m in metas)
-    rows = torch.zeros((nmax, chans, tmax), dtype=torch.float32, device=dev)
+    table = torch.stack(metas).tolist()                          # host read #2: every (index, T)
+    tmax = max(t for m in table for _, t in m)
+    rows = torch.zeros((nmax, channels, tmax), dtype=torch.float32, device=device)
     for k, (_, y) in enumerate(local):
         rows[k, :, : y.shape[-1]] = y
-    gathered = torch.empty((world * nmax, chans, tmax), dtype=torch.float32, device=dev)
-    if dev.type == "cuda":
-        dist.all_gather_into_tensor(gathered, rows, group=group)
-    else:                                                 # gloo: list form
-        parts = [torch.empty_like(rows) for _ in range(world)]
-        dist.all_gather(parts, rows, group=group)
-        gathered = torch.cat(parts, dim=0)
+    gathered = _gather_rows(rows, world, group)
     out: List[Optional[torch.Tensor]] = [None] * n_total
     for r in range(world):
         for k in range(counts[r]):
-            i, t = int(metas[r][k, 0].item()), int(metas[r][k, 1].item())
+            i, t = table[r][k]
             out[i] = gathered[r * nmax + k, :, :t]
     return out
 
 
+def _gather_rows(rows: torch.Tensor, world: int, group, async_op: bool = False):
+    """(n, C, T) per rank -> (world * n, C, T) on every rank; returns the tensor, or (tensor, work)."""
+    import torch.distributed as dist
+    if rows.is_cuda:
+        gathered = torch.empty((world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        work = dist.all_gather_into_tensor(gathered, rows, group=group, async_op=async_op)
+        return (gathered, work) if async_op else gathered
+    parts = [torch.empty_like(rows) for _ in range(world)]      # gloo: list form
+    dist.all_gather(parts, rows, group=group)
+    gathered = torch.cat(parts, dim=0)
+    return (gathered, None) if async_op else gathered
+
+
+class _Stager:
+    """Device batches one step ahead of the compute stream.
+
+    Host-resident utterances: rows are written into one of TWO pinned staging sets and copied on a
+    side stream (`non_blocking`), so the upload of batch k+1 overlaps the kernels of batch k; a
+    staging set is reused only after the copy that last read it has completed (event).  Utterances
+    already on the device are stacked / padded there.  On CPU (tests) everything is plain tensors."""
+
+    def __init__(self, utterances, device, hop: int):
+        self.utts = utterances
+        self.device = torch.device(device)
+        self.hop = hop
+        self.cuda = self.device.type == "cuda"
+        self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.pinned: List[Dict[str, torch.Tensor]] = [{}, {}]
+        self.pin_free: List[Optional[torch.cuda.Event]] = [None, None]
+        self.turn = 0
+
+    def _host_buffer(self, slot: int, key: str, shape, dtype) -> torch.Tensor:
+        need = 1
+        for s in shape:
+            need *= int(s)
+        buf = self.pinned[slot].get(key)
+        if buf is None or buf.numel() < need or buf.dtype != dtype:
+            buf = torch.empty(need, dtype=dtype, pin_memory=True)
+            self.pinned[slot][key] = buf
+        return buf[:need].view(*shape)
+
+    def stage(self, chunk: Sequence[int], fmax: int):
+        """-> (ppg (b, C, fmax), sine (b, 1, fmax*hop), lft, emb or None, ready event or None); rows
+        shorter than fmax are zero padded."""
+        first = self.utts[chunk[0]]
+        has_emb = first.get("spk_emb") is not None
+        keys = [("ppg", fmax), ("sine", fmax * self.hop), ("lft", fmax * self.hop)]
+        on_device = torch.as_tensor(first["ppg"]).device == self.device and self.cuda
+        if not self.cuda or on_device:
+            out = []
+            for key, width in keys:
+                rows = []
+                for i in chunk:
+                    t = torch.as_tensor(self.utts[i][key])
+                    if t.shape[-1] != width:
+                        t = torch.nn.functional.pad(t, (0, width - t.shape[-1]))
+                    rows.append(t)
+                out.append(torch.stack(rows).to(self.device))
+            emb = torch.stack([torch.as_tensor(self.utts[i]["spk_emb"]) for i in chunk]).to(self.device) if has_emb else None
+            return out[0], out[1], out[2], emb, None
+        slot = self.turn & 1
+        self.turn += 1
+        if self.pin_free[slot] is not None:
+            self.pin_free[slot].synchronize()                      # the copy that last read this set is done
+        host = {}
+        for key, width in keys:
+            t0 = torch.as_tensor(first[key])
+            hb = self._host_buffer(slot, key, (len(chunk), t0.shape[0], width), t0.dtype)
+            for j, i in enumerate(chunk):
+                t = torch.as_tensor(self.utts[i][key])
+                hb[j, :, : t.shape[-1]] = t
+                if t.shape[-1] < width:
+                    hb[j, :, t.shape[-1]:] = 0
+            host[key] = hb
+        if has_emb:
+            e0 = torch.as_tensor(first["spk_emb"])
+            hb = self._host_buffer(slot, "spk_emb", (len(chunk), e0.shape[0]), e0.dtype)
+            for j, i in enumerate(chunk):
+                hb[j] = torch.as_tensor(self.utts[i]["spk_emb"])
+            host["spk_emb"] = hb
+        with torch.cuda.stream(self.copy_stream):
+            dev = {k: v.to(self.device, non_blocking=True) for k, v in host.items()}
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        self.pin_free[slot] = ready
+        return dev["ppg"], dev["sine"], dev["lft"], dev.get("spk_emb"), ready
+
+
 def run_utterance_parallel(forward_fn: Callable[..., torch.Tensor],
-                           utterances: Sequence[dict], device, max_batch: int = 64, group=None,
-                           ragged: bool = False, pad_tolerance: float = 0.125
-                           ) -> List[Optional[torch.Tensor]]:
+                           utterances: Sequence[Optional[dict]], device, max_batch: int = 64, group=None,
+                           ragged: bool = False, pad_tolerance: float = 0.125,
+                           out_channels: int = 1, n_frames: Optional[Sequence[int]] = None,
+                           hop: Optional[int] = None) -> List[Optional[torch.Tensor]]:
     """Shard `utterances` (dicts with 'ppg' (C,F), 'sine' (1,T), 'lft' (1,T), optional 'spk_emb'
     (E,)) over the ranks, run `forward_fn(ppg, sine, lft, emb)` on same-length batches - or, with
     `ragged`, `forward_fn(ppg, sine, lft, emb, lengths)` on zero-padded batches of similar length -
-    and all-gather the waveforms.  Every rank passes the same list (only its shard is moved to
-    `device`)."""
+    and all-gather the waveforms ((out_channels, T) each, indexed like `utterances`).
+
+    Every rank passes the same list; only its own shard is touched, so entries of other ranks'
+    utterances may be None when `n_frames` (frame count of every utterance) and `hop` are given."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n_frames = [int(u["ppg"].shape[-1]) for u in utterances]
-    mine = shard_utterances(n_frames, world)[rank]
-    local: List[Tuple[int, torch.Tensor]] = []
-    if ragged:
-        for chunk in bucket_ragged(mine, n_frames, max_batch, pad_tolerance):
-            fmax = int(n_frames[chunk[0]])
-            hop = int(utterances[chunk[0]]["sine"].shape[-1]) // fmax
-
-            def pad(key, width):
-                rows = []
-                for i in chunk:
-                    t = torch.as_tensor(utterances[i][key])
-                    rows.append(torch.nn.functional.pad(t, (0, width - t.shape[-1])))
-                return torch.stack(rows).to(device)
-
-            emb = None
-            if utterances[chunk[0]].get("spk_emb") is not None:
-                emb = torch.stack([torch.as_tensor(utterances[i]["spk_emb"]) for i in chunk]).to(device)
-            lens = [int(n_frames[i]) for i in chunk]
-            y = forward_fn(pad("ppg", fmax), pad("sine", fmax * hop), pad("lft", fmax * hop), emb, lens)
-            for j, i in enumerate(chunk):
-                local.append((i, y[j][:, : lens[j] * hop]))
-        return all_gather_waveforms(local, len(utterances), group=group)
-    for _, idxs in sorted(bucket_by_length(mine, n_frames).items()):
-        for k in range(0, len(idxs), max_batch):
-            chunk = idxs[k: k + max_batch]
-            ppg = torch.stack([torch.as_tensor(utterances[i]["ppg"]) for i in chunk]).to(device)
-            sine = torch.stack([torch.as_tensor(utterances[i]["sine"]) for i in chunk]).to(device)
-            lft = torch.stack([torch.as_tensor(utterances[i]["lft"]) for i in chunk]).to(device)
-            emb = None
-            if utterances[chunk[0]].get("spk_emb") is not None:
-                emb = torch.stack([torch.as_tensor(utterances[i]["spk_emb"]) for i in chunk]).to(device)
-            y = forward_fn(ppg, sine, lft, emb)
-            for j, i in enumerate(chunk):
-                local.append((i, y[j]))
-    return all_gather_waveforms(local, len(utterances), group=group)
+    device = torch.device(device)
+    if n_frames is None:
+        n_frames = [int(u["ppg"].shape[-1]) for u in utterances]
+    n_total = len(n_frames)
+    if n_total == 0:
+        return []
+    if hop is None:
+        u0 = next(u for u in utterances if u is not None)
+        hop = int(u0["sine"].shape[-1]) // int(u0["ppg"].shape[-1])
+    sched = GatherSchedule(n_frames, hop, world, max_batch, ragged, pad_tolerance)
+    mine = sched.batches[rank]
+    stager = _Stager(utterances, device, hop)
+    staged = stager.stage(mine[0], max(sched.n_frames[i] for i in mine[0])) if mine else None
+    rounds: List[Tuple[torch.Tensor, object]] = []
+    for r in range(sched.n_rounds):
+        rows = torch.zeros((sched.rows[r], out_channels, sched.cols[r]), dtype=torch.float32, device=device)
+        if r < len(mine):
+            chunk = mine[r]
+            ppg, sine, lft, emb, ready = staged
+            if r + 1 < len(mine):                                  # upload the next batch meanwhile
+                staged = stager.stage(mine[r + 1], max(sched.n_frames[i] for i in mine[r + 1]))
+            if ready is not None:
+                torch.cuda.current_stream(device).wait_event(ready)
+            if ragged:
+                lens = [sched.n_frames[i] for i in chunk]
+                y = forward_fn(ppg, sine, lft, emb, lens)
+            else:
+                y = forward_fn(ppg, sine, lft, emb)
+            if y.shape[1] != out_channels:
+                raise ValueError(f"forward_fn returned {y.shape[1]} channels, out_channels={out_channels}")
+            rows[: y.shape[0], :, : y.shape[-1]] = y
+        rounds.append(_gather_rows(rows, world, group, async_op=True))
+    out: List[Optional[torch.Tensor]] = [None] * n_total
+    for r, (gathered, work) in enumerate(rounds):
+        if work is not None:
+            work.wait()
+        for rk in range(world):
+            for k, i in enumerate(sched.batch(rk, r)):
+                out[i] = gathered[rk * sched.rows[r] + k, :, : sched.n_frames[i] * hop]
+    return out

@@ -34,6 +34,7 @@ ABI_SYMBOLS = (
     "fastsvc_forward", "fastsvc_autotune", "fastsvc_tuned_count", "fastsvc_tuned_get", "fastsvc_tuned_set",
     "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
     "fastsvc_flops_per_sample", "fastsvc_signal_scratch_bytes", "fastsvc_signal_generate",
+    "fastsvc_stream_prepare",
 )
 
 
@@ -95,6 +96,8 @@ def load_library():
     lib.fastsvc_workspace_bytes.restype = sz
     lib.fastsvc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.fastsvc_forward.restype = ctypes.c_int
+    lib.fastsvc_stream_prepare.argtypes = [vp]
+    lib.fastsvc_stream_prepare.restype = ctypes.c_int
     lib.fastsvc_autotune.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, ctypes.POINTER(i32)]
     lib.fastsvc_autotune.restype = ctypes.c_int
     lib.fastsvc_tuned_count.argtypes = [vp]
@@ -206,6 +209,11 @@ class Plan:
             self._h = None
 
     @property
+    def arithmetic(self) -> str:
+        """The type the path computes in, for bench.py's `dtype`."""
+        return "f32" if self.storage == "float32" else "f32 arithmetic, bf16 activation storage"
+
+    @property
     def blob_bytes(self) -> int:
         return int(self.lib.fastsvc_weight_blob_bytes(self._h))
 
@@ -215,6 +223,13 @@ class Plan:
 
     def launch_count(self, with_spk: bool = True) -> int:
         return int(self.lib.fastsvc_forward_launch_count(self._h, 1 if with_spk else 0))
+
+    def prepare_stream(self, device=None) -> None:
+        """Create the helper streams / events of the current HIP stream of `device` ahead of the first
+        forward on it (so that forward allocates nothing)."""
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _check(self.lib, self.lib.fastsvc_stream_prepare(ctypes.c_void_p(stream)), "fastsvc_stream_prepare")
 
     def workspace_bytes(self, B: int, F: int) -> int:
         return int(self.lib.fastsvc_workspace_bytes(self._h, B, F))

@@ -151,6 +151,8 @@ class FastSVCGenerator(nn.Module):
             if isinstance(m, (nn.Conv1d, nn.Conv2d)) and not hasattr(m, "weight_g"):
                 torch.nn.utils.weight_norm(m)
         self.apply(_apply)
+        if getattr(self, "_blob", None) is not None:
+            self.invalidate_packed_weights()
 
     def remove_weight_norm(self):
         """Fold g * v / ||v|| back into ``.weight`` (fastsvc.py:342-352)."""
@@ -160,10 +162,67 @@ class FastSVCGenerator(nn.Module):
             except ValueError:
                 return
         self.apply(_remove)
+        self.invalidate_packed_weights()
 
     # ------------------------------------------------------------------ packed-weight cache
+    # The kernels read a device-resident, kernel-layout copy of the parameters.  It is rebuilt when a
+    # parameter object or its autograd version counter changes (optimizer steps, `p.copy_()`,
+    # `load_state_dict`, weight-norm removal), and dropped explicitly by everything that re-homes or
+    # replaces parameters (`_apply`: .to()/.half()/.cuda(); `load_state_dict`; weight-norm changes).
+    # LIMITATION: writes through `p.data` (`p.data.copy_()`, `p.data.mul_()`, EMA swaps done that
+    # way) bump no version counter; call `invalidate_packed_weights()` after them, or set
+    # `FastSVCGenerator.checksum_weights = True` to fingerprint the parameter storage on every
+    # forward (one device reduction per parameter: safe, slower).
+    checksum_weights = False
+
+    def invalidate_packed_weights(self):
+        """Forget the packed device blob; the next forward folds and packs the parameters again."""
+        self._blob = None
+        self._blob_key = None
+
     def _weights_key(self, device):
-        return (str(device),) + tuple((id(p), p._version) for p in self.parameters())
+        key = (str(device),) + tuple((id(p), p._version) for p in self.parameters())
+        if self.checksum_weights:
+            with torch.no_grad():
+                key += tuple(float(p.detach().double().sum()) + float(p.detach().double().abs().sum())
+                             for p in self.parameters())
+        return key
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_blob", None) is not None:
+            self.invalidate_packed_weights()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed_weights()
+        return out
+
+    # the plan / blob hold a ctypes handle and a device cache: never copied or pickled, always rebuilt
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_plan"] = None
+        state["_blob"] = None
+        state["_blob_key"] = None
+        state["_tuned_shapes"] = set()
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        # legacy weight-norm leaves a NON-LEAF `weight` attribute (g * v / ||v||, recomputed by its
+        # pre-forward hook) on every conv, which torch refuses to deep-copy: detach it first - the HIP
+        # path folds weight_g / weight_v itself and never reads that attribute
+        for m in self.modules():
+            w = m.__dict__.get("weight")
+            if isinstance(w, torch.Tensor) and w.grad_fn is not None:
+                m.__dict__["weight"] = w.detach()
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def packed_weights(self, device) -> torch.Tensor:
         """Device-resident kernel-layout weight blob; rebuilt when any parameter changed."""

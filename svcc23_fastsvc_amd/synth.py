@@ -318,3 +318,34 @@ WORKLOADS = {
     "cfg3": dict(B=64, F=1500, seed=1237, desc="64 x 10 s utterances"),
     "cfg4": dict(B=512, F=1500, seed=1238, desc="512 x 10 s utterances (sharded)"),
 }
+
+
+def device_batch(cfg: GeneratorConfig, B: int, F: int, seed: int, device, sample_rate: int = 24000):
+    """The same kind of synthetic utterances as `synth_batch` (SURVEY.md §8 d), generated with torch
+    ops ON `device` - for the large workloads (cfg3 / cfg4: tens of GB of features) where the
+    integer-hash host generator would take minutes.  Not bit-identical to `synth_batch` (torch's
+    generator, not the hash streams): use it for timing and for self-consistency properties only;
+    parity fixtures always come from `synth_batch`.  Returns (ppg, sine, lft, spk_emb) tensors."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    hop = cfg.hop
+    T = hop * F
+    ppg = torch.randn((B, cfg.in_channels, F), generator=g, device=device, dtype=torch.float32)
+    step = torch.randn((B, F), generator=g, device=device, dtype=torch.float64) * 0.02
+    start = (torch.rand((B, 1), generator=g, device=device, dtype=torch.float64) - 0.5) * 0.6
+    f0 = torch.exp(np.log(220.0) + start + torch.cumsum(step, dim=1)).clamp(80.0, 600.0)
+    nrun = (F + 9) // 10
+    uv = torch.rand((B, nrun), generator=g, device=device) < 0.3
+    f0 = torch.where(uv.repeat_interleave(10, dim=1)[:, :F], torch.zeros_like(f0), f0)
+    f0u = f0.repeat_interleave(hop, dim=1)
+    vuv = (f0u > 0).to(torch.float64)
+    phase = torch.cumsum((f0u / float(sample_rate)) % 1.0, dim=1)
+    sine = vuv * torch.sin(phase * (2.0 * np.pi)) * 0.1
+    noise = torch.randn((B, T), generator=g, device=device, dtype=torch.float32)
+    sine = (sine + noise.to(torch.float64) * (vuv * 0.003 + (1.0 - vuv) * 0.001)).to(torch.float32).unsqueeze(1)
+    nblk = (T + 63) // 64
+    lft = (torch.rand((B, 1, nblk), generator=g, device=device, dtype=torch.float32) * 10.0 - 9.0)
+    lft = lft.repeat_interleave(64, dim=2)[:, :, :T].contiguous()
+    emb = torch.randn((B, cfg.spk_emb_size), generator=g, device=device, dtype=torch.float32) * 5.0
+    return ppg.contiguous(), sine.contiguous(), lft, emb

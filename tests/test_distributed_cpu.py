@@ -63,7 +63,13 @@ def _worker(rank, world, port, q):
         ys = D.run_utterance_parallel(_fake_forward, utts, torch.device("cpu"), max_batch=2)
         yr = D.run_utterance_parallel(_fake_forward_ragged, utts, torch.device("cpu"), max_batch=3,
                                       ragged=True, pad_tolerance=0.5)
-        q.put((rank, blob.numpy().copy(), [y.numpy().copy() for y in ys], [y.numpy().copy() for y in yr]))
+        # fewer utterances than ranks: rank 1's shard is EMPTY, it must still join every collective
+        # (the gather used to fall back to a CPU tensor / 1 channel on such a rank)
+        y1 = D.run_utterance_parallel(_fake_forward, utts[:1], torch.device("cpu"), max_batch=2)
+        # ad-hoc gather without a shared schedule: rank 1 passes nothing, device and channels explicit
+        adhoc = D.all_gather_waveforms([(0, ys[3].clone())] if rank == 0 else [], 2, device=torch.device("cpu"), channels=1)
+        q.put((rank, blob.numpy().copy(), [y.numpy().copy() for y in ys], [y.numpy().copy() for y in yr],
+               [y.numpy().copy() for y in y1], [None if y is None else y.numpy().copy() for y in adhoc]))
     finally:
         dist.destroy_process_group()
 
@@ -88,8 +94,8 @@ def test_two_ranks_broadcast_shard_gather():
         p.start()
     res = {}
     for _ in range(world):
-        rank, blob, ys, yr = q.get(timeout=120)
-        res[rank] = (blob, ys, yr)
+        rank, blob, ys, yr, y1, adhoc = q.get(timeout=120)
+        res[rank] = (blob, ys, yr, y1, adhoc)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -106,6 +112,25 @@ def test_two_ranks_broadcast_shard_gather():
             for got in (res[r][1][i], res[r][2][i]):      # same-length buckets, and padded ragged batches
                 assert got.shape == want.shape
                 assert np.allclose(got, want, atol=1e-6)
+    # the one-utterance set (empty shard on rank 1) and the schedule-free gather
+    for r in range(world):
+        assert len(res[r][3]) == 1 and np.allclose(res[r][3][0], res[0][1][0], atol=1e-6)
+        assert res[r][4][1] is None and np.allclose(res[r][4][0], res[0][1][3], atol=1e-6)
+
+
+def test_gather_schedule_is_rank_independent_and_covers_everything():
+    frames = [5, 9, 5, 3, 9, 7, 5]
+    for ragged in (False, True):
+        s = D.GatherSchedule(frames, 160, 3, max_batch=2, ragged=ragged, pad_tolerance=0.5)
+        seen = sorted(i for rk in range(3) for r in range(s.n_rounds) for i in s.batch(rk, r))
+        assert seen == list(range(len(frames)))
+        for r in range(s.n_rounds):
+            for rk in range(3):
+                b = s.batch(rk, r)
+                assert len(b) <= s.rows[r]
+                assert all(frames[i] * 160 <= s.cols[r] for i in b)
+    empty = D.GatherSchedule([4], 160, 8, max_batch=64, ragged=False, pad_tolerance=0.125)
+    assert empty.n_rounds == 1 and sum(len(empty.batch(rk, 0)) for rk in range(8)) == 1
 
 
 def test_ragged_buckets_bound_the_padding():

@@ -238,8 +238,8 @@ def test_batch_items_do_not_bleed(dev):
             assert float((yb[i:i + 1] - yi).abs().max()) <= 2e-5
 
 
-def test_linearity_of_conv_last_residual_path(dev):
-    """Size-independent property at cfg2's utterance length: determinism run-to-run within fp64
+def test_determinism_and_batch_permutation_equivariance(dev):
+    """Size-independent properties at cfg2's utterance length: determinism run-to-run within fp64
     atomics jitter, and permutation equivariance over the batch axis."""
     cfg = S.FULL_CONFIG
     m = _module(cfg, S.synth_state_dict(cfg, 9), dev)
@@ -252,6 +252,38 @@ def test_linearity_of_conv_last_residual_path(dev):
         yp = m(*[t[perm] for t in ins])
     assert float((y1 - y2).abs().max()) <= 1e-5
     assert float((y1[perm] - yp).abs().max()) <= 2e-5
+
+
+def test_output_is_affine_in_conv_last(dev):
+    """The one exactly linear stage (fastsvc.py:301,330, no output non-linearity): scaling conv_last's
+    weight and bias by a power of two scales the waveform by exactly that factor."""
+    cfg = S.FULL_CONFIG
+    sd = S.fold_weight_norm(S.synth_state_dict(cfg, 9))
+    b = S.synth_batch(cfg, 2, 64, 11)
+    plan = A.Plan(cfg)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    y = plan.forward(plan.pack(sd).to(dev), *ins)
+    sd2 = dict(sd)
+    sd2["conv_last.weight"] = sd["conv_last.weight"] * 4.0
+    sd2["conv_last.bias"] = sd["conv_last.bias"] * 4.0
+    y4 = plan.forward(plan.pack(sd2).to(dev), *ins)
+    assert float((y4 - 4.0 * y).abs().max()) <= 4e-5     # exact up to the f64-atomics jitter of the norms upstream
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_single_frame_utterances_over_several_seeds(dev, seed):
+    """F = 1: the first up block normalises over TWO samples per channel, so (x - mean) * rstd amplifies
+    fp32 rounding by up to 1/sqrt(eps) ~ 316 and single inputs reach 1e-4..3e-4 against the oracle
+    (conditioning of the input, the same with every kernel variant): held to the north-star 1e-3."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 400 + seed)
+    b = S.synth_batch(cfg, 2, 1, 500 + seed)
+    m = _module(cfg, sd, dev)
+    with torch.no_grad():
+        y = m(*_to(dev, b.ppg, b.sine, b.lft, b.spk_emb)).cpu()
+    ref = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)
+    assert float((y - ref).abs().max()) <= TOL * max(1.0, float(ref.abs().max()))
 
 
 def test_errors_mirror_reference(dev):
@@ -441,7 +473,8 @@ def test_batched_decode_equals_the_reference_decode_loop(dev):
 def test_bfloat16_activation_storage_mode(dev):
     """BASELINE config 3's dtype: workspace tensors stored as bfloat16 (fp32 MFMA arithmetic, fp32
     weights / statistics).  Not the 1e-3 parity path: tolerance is that of bf16 activations, the
-    bound SURVEY 8(c) proposes (mean-abs <= 2e-2, max-abs <= 0.3 on an output of rms 0.66), and the
+    bound is ~2x what is observed (mean-abs 7e-3, max-abs 0.08 on an output of rms 0.66; SURVEY 8(c)'s
+    proposed ceiling is 2e-2 / 0.3), and the
     float32 path must stay an order of magnitude closer.  Also: half the workspace, bf16 taps,
     ragged batches work, frame counts that are not multiples of 4 are refused (not silently slow)."""
     O = _oracle()
@@ -460,7 +493,7 @@ def test_bfloat16_activation_storage_mode(dev):
     y16 = p16.forward(blob, *ins, workspace=ws).cpu()
     y32 = p32.forward(blob, *ins).cpu()
     e16, e32 = (y16 - ref).abs(), (y32 - ref).abs()
-    assert float(e16.mean()) <= 2e-2 and float(e16.max()) <= 0.3
+    assert float(e16.mean()) <= 1.5e-2 and float(e16.max()) <= 0.2
     assert float(e32.max()) <= TIGHT and float(e16.mean()) > 10 * float(e32.mean())     # it really is a different mode
     tap = p16.tap("up.3.out", B, F, ws)
     assert tap.dtype == torch.bfloat16 and tuple(tap.shape) == (B, 24, F * 160)
@@ -468,7 +501,7 @@ def test_bfloat16_activation_storage_mode(dev):
     yr = p16.forward(blob, *ins, lengths=[36, 48]).cpu()                                # ragged
     r0 = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[:1, :, :36], b.sine[:1, :, :36 * 160],
                          b.lft[:1, :, :36 * 160], b.spk_emb[:1])
-    assert float((yr[:1, :, :36 * 160] - r0).abs().mean()) <= 2e-2 and float(yr[0, :, 36 * 160:].abs().max()) == 0.0
+    assert float((yr[:1, :, :36 * 160] - r0).abs().mean()) <= 1.5e-2 and float(yr[0, :, 36 * 160:].abs().max()) == 0.0
     b2 = S.synth_batch(cfg, 1, 41, 83)
     with pytest.raises(A.FastSVCError):
         p16.forward(blob, *_to(dev, b2.ppg, b2.sine, b2.lft, b2.spk_emb))

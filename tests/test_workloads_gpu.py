@@ -1,0 +1,129 @@
+"""Full-size workloads under pytest -m gpu (BASELINE.json configs[2] and the single-GPU leg of
+configs[3]): cfg3 = 64 x 10 s in float32 AND bfloat16 storage with the SHIPPED launch-shape table
+(`|64|...` and `...|b` entries), and the utterance-parallel host path with the nccl (RCCL) backend
+on the real generator.  The oracle checks utterances run ALONE (batch items are independent -
+SURVEY.md §8 e - and one 10 s utterance costs the CPU oracle about a second); everything at full
+size is a size-independent property: shape, finiteness, determinism, batch-permutation
+equivariance, batch item == the same utterance alone."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import svcc23_fastsvc_amd as A
+from svcc23_fastsvc_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-4
+# bf16 activations: observed mean-abs 7e-3 / max-abs 0.08 on an output of rms 0.7 (SURVEY 8c proposes
+# the ceiling 2e-2 / 0.3; the reference's own bf16 autocast sits at 1.3e-2 / 0.2): hold ~2x observed
+BF16_MEAN, BF16_MAX = 1.5e-2, 0.2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (and fail loudly without one)"
+    A.load_library()
+    return torch.device("cuda:0")
+
+
+def _oracle_alone(sd_folded, cfg, ins, i):
+    from oracle import fastsvc_oracle as O
+    one = [t[i:i + 1].cpu().numpy() for t in ins]
+    return O.forward_dedup(sd_folded, cfg.upsampling_scales, *one)
+
+
+@pytest.mark.parametrize("storage", ["float32", "bfloat16"])
+def test_cfg3_full_size_with_the_shipped_table(dev, storage):
+    cfg = S.FULL_CONFIG
+    wl = S.WORKLOADS["cfg3"]
+    B, F = wl["B"], wl["F"]
+    T = F * cfg.hop
+    sd = S.synth_state_dict(cfg, 201)
+    plan = A.Plan(cfg, storage=storage)                   # loads svcc23_fastsvc_amd/tuned_mi355x.json
+    suffix = "|b" if storage == "bfloat16" else ""
+    keys = [k for k in plan.tuned_shapes() if k.split("|")[1] == str(B) and k.endswith("|b") == (storage == "bfloat16")]
+    assert len(keys) >= 30, f"the shipped table has no |{B}|...{suffix} entries for cfg3"
+    blob = plan.pack(sd).to(dev)
+    ins = list(S.device_batch(cfg, B, F, wl["seed"], dev))
+    ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    y1 = plan.forward(blob, *ins, workspace=ws).clone()
+    assert tuple(y1.shape) == (B, 1, T) and bool(torch.isfinite(y1).all())
+    rms = float(y1.pow(2).mean().sqrt())
+    assert 0.05 < rms < 10.0
+    # determinism (f64 atomics jitter only) and batch-permutation equivariance at full size
+    y2 = plan.forward(blob, *ins, workspace=ws)
+    jitter = 1e-5 if storage == "float32" else 2e-2       # a flipped bf16 rounding moves an element by one bf16 ulp
+    assert float((y1 - y2).abs().max()) <= jitter
+    perm = torch.roll(torch.arange(B, device=dev), 17)
+    yp = plan.forward(blob, *[t[perm].contiguous() for t in ins], workspace=ws)
+    assert float((y1[perm] - yp).abs().max()) <= 2 * jitter
+    # first and last utterance against the oracle run alone, and against the HIP path run alone
+    wf = S.fold_weight_norm(sd)
+    for i in (0, B - 1):
+        ref = _oracle_alone(wf, cfg, ins, i)
+        err = (y1[i:i + 1].cpu() - ref).abs()
+        if storage == "float32":
+            assert float(err.max()) <= TIGHT * max(1.0, float(ref.abs().max()))
+        else:
+            assert float(err.mean()) <= BF16_MEAN and float(err.max()) <= BF16_MAX
+        alone = plan.forward(blob, *[t[i:i + 1] for t in ins])
+        assert float((alone - y1[i:i + 1]).abs().max()) <= (2e-5 if storage == "float32" else 5e-2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_utterance_parallel_path_on_the_nccl_backend(dev):
+    """broadcast -> shard -> forward -> all-gather with backend="nccl" (RCCL), world_size 1, the real
+    generator and HOST-resident utterances of three lengths (pinned double-buffered staging): every
+    gathered waveform equals the utterance run alone; same-length buckets and ragged batches."""
+    import torch.distributed as dist
+    from svcc23_fastsvc_amd import distributed as D
+    cfg = S.FULL_CONFIG
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        g = A.FastSVCGenerator(in_channels=cfg.in_channels, mid_channels=list(cfg.mid_channels),
+                               upsampling_scales=list(cfg.upsampling_scales), out_channels=1,
+                               spk_emb_size=cfg.spk_emb_size, use_spk_emb=True)
+        g.load_state_dict({k: torch.from_numpy(v) for k, v in S.synth_state_dict(cfg, 55).items()})
+        g = g.eval()                                     # parameters stay on the host: only the blob travels
+        blob = D.broadcast_packed_weights(g, dev, src=0)
+        assert blob.is_cuda and blob.numel() * 4 == g.plan.blob_bytes
+        utts = []
+        for i, F in enumerate([40, 48, 44, 40, 48, 44, 40, 36, 48, 40, 44]):
+            b = S.synth_batch(cfg, 1, F, 300 + i)
+            utts.append(dict(ppg=torch.from_numpy(b.ppg[0]), sine=torch.from_numpy(b.sine[0]),
+                             lft=torch.from_numpy(b.lft[0]), spk_emb=torch.from_numpy(b.spk_emb[0])))
+        plan = g.plan
+
+        def fwd(ppg, sine, lft, emb, lengths=None):
+            return plan.forward(blob, ppg, sine, lft, emb, lengths=lengths)
+
+        with torch.no_grad():
+            ys = D.run_utterance_parallel(fwd, utts, dev, max_batch=3)
+            yr = D.run_utterance_parallel(fwd, utts, dev, max_batch=4, ragged=True, pad_tolerance=0.3)
+            # device-resident utterances take the in-place stacking route
+            utts_dev = [{k: v.to(dev) for k, v in u.items()} for u in utts]
+            yd = D.run_utterance_parallel(fwd, utts_dev, dev, max_batch=64)
+            for i, u in enumerate(utts):
+                alone = plan.forward(blob, u["ppg"][None].to(dev), u["sine"][None].to(dev), u["lft"][None].to(dev),
+                                     u["spk_emb"][None].to(dev))[0]
+                for got in (ys[i], yr[i], yd[i]):
+                    assert got.is_cuda and tuple(got.shape) == tuple(alone.shape)
+                    assert float((got - alone).abs().max()) <= 2e-5
+        # ad-hoc gather on the GPU backend with an EMPTY local list (used to pick a CPU tensor)
+        none = D.all_gather_waveforms([], 3, device=dev, channels=1)
+        assert none == [None, None, None]
+    finally:
+        dist.destroy_process_group()
