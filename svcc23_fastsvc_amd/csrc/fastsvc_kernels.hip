@@ -26,23 +26,7 @@ namespace fastsvc {
 namespace bf16 {          // second compilation of this file: bfloat16 activation storage (see act_t below)
 #endif
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// compile-time epilogue kinds of the pipelined kernel (see ws_epilogue_kind)
-enum : int { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RES = 2, EPI_RANK1 = 3, EPI_AFF = 4 };
-
-__device__ __forceinline__ float lrelu(float v) { return v >= 0.f ? v : LRELU_SLOPE * v; }
-
-__device__ __forceinline__ int div_small(int t, int s) {
-    // nearest-stretch source index; s in {2,4,5} for the yaml config - keep those divisions cheap
-    switch (s) {
-        case 2: return t >> 1;
-        case 4: return t >> 2;
-        case 5: return t / 5;
-        case 1: return t;
-        default: return t / s;
-    }
-}
+#include "fastsvc_device.inc"
 
 // One packed weight fragment = MW consecutive floats per lane.  It is kept as a VECTOR value so
 // that it lives in consecutive VGPRs: a global_load_dwordx{2,3} can then land directly in the
@@ -633,506 +617,6 @@ void conv_mfma_kernel(const ConvParams p0) {
 //     one (signal, batch item, channel block): set-up, InstanceNorm coefficients and the weight
 //     stream are paid once, the InstanceNorm partial sums are flushed once.
 // ---------------------------------------------------------------------------------------------
-template <int NT, int NTHREADS>
-struct StageGeom {
-    static constexpr int MAXW4 = (NT + 56) / 4;                       // halo <= 28 columns per side
-    static constexpr int ITEMS = (24 * MAXW4 + NTHREADS - 1) / NTHREADS;
-};
-
-
-__device__ __forceinline__ unsigned udiv_small(unsigned t, int s) {
-    switch (s) {
-        case 1: return t;
-        case 2: return t >> 1;
-        case 4: return t >> 2;
-        case 5: return __umulhi(t, 0xCCCCCCCDu) >> 2;
-        default: return t / (unsigned)s;
-    }
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long nfloats) {
-    // raw buffer over [base, base + nfloats): out-of-range loads return 0, stores are dropped
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(nfloats * 4), 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
-}
-// Rows need not be a multiple of 4 long (T_k = 2F, F for odd frame counts): every float4 access is
-// only dword-aligned then, and the float4 that straddles the end of a row is handled by element:
-// nv = number of its elements that belong to the row (4 everywhere else, 0 for lanes off the tile).
-__device__ __forceinline__ void buf_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
-    // wave-uniform fast path: no lane of the wave is a partial float4 (rows that are a multiple of 4 long,
-    // i.e. nearly always) -> ONE store instead of four; vmcnt counts every one of them, and the weight
-    // ring's counted waits drain whatever stores are ahead of them
-    if (__builtin_amdgcn_ballot_w64(nv > 0 && nv < 4) == 0) {
-        buf_store4(r, nv > 0 ? voff : 0x7ffffff0, v);
-    } else if (nv >= 4) {
-        buf_store4(r, voff, v);
-    } else {
-        // element stores with the offset pushed out of range for the elements past the row end
-        // (dropped by the descriptor); no per-element branches
-        const float e0 = v[0], e1 = v[1], e2 = v[2];
-        const int far = 0x7ffffff0;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e0), r, nv >= 1 ? voff : far, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e1), r, nv >= 2 ? voff + 4 : far, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e2), r, nv >= 3 ? voff + 8 : far, 0, 0);
-    }
-}
-__device__ __forceinline__ f32x4 keep_first(f32x4 v, int nv) {      // zero the elements past the row end
-    if (nv < 4) v.w = 0.f;
-    if (nv < 3) v.z = 0.f;
-    if (nv < 2) v.y = 0.f;
-    if (nv < 1) v.x = 0.f;
-    return v;
-}
-__device__ __forceinline__ int row_valid(int t, int T) { return min(4, max(0, T - t)); }
-// The variants that sit at the 128-VGPR limit are compiled WITHOUT the row-end handling (they are the
-// full-rate shapes, whose rows are 160 F long); run_conv only launches them when T % 4 == 0.
-// ---- activation storage type ------------------------------------------------------------------
-// The file is compiled twice: as is (activations float32 in HBM: the parity path) and with
-// -DFASTSVC_ACT_BF16 (namespace fastsvc::bf16: every workspace tensor - conv outputs, FiLM-affined
-// tensors, scale / shift - is stored as bfloat16, halving the traffic of the HBM-bound layers; the
-// arithmetic, the LDS windows, the weights and the InstanceNorm sums stay float32 / float64).
-// All offsets in the kernels are written in "float bytes" (elements * 4); the bf16 helpers halve them.
-#ifdef FASTSVC_ACT_BF16
-typedef unsigned short act_t;
-typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned f32_to_bf16_bits(float x) {            // round to nearest even
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ f32x4 act_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(r, voff >> 1, soff >> 1, 0);
-    return f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
-                 __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
-}
-__device__ __forceinline__ float act_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(r, voff >> 1, soff >> 1, 0);
-    return __builtin_bit_cast(float, (unsigned)h << 16);
-}
-__device__ __forceinline__ void act_store4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
-    u32x2v w;
-    w.x = f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16);
-    w.y = f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16);
-    __builtin_amdgcn_raw_buffer_store_b64(w, r, voff >> 1, 0, 0);
-}
-__device__ __forceinline__ void act_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
-    if (nv >= 4) {
-        act_store4(r, voff, v);
-    } else {
-        const float e0 = v[0], e1 = v[1], e2 = v[2];
-        const int far = 0x7ffffff0, o = voff >> 1;
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(e0), r, nv >= 1 ? o : far, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(e1), r, nv >= 2 ? o + 2 : far, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(e2), r, nv >= 3 ? o + 4 : far, 0, 0);
-    }
-}
-#else
-typedef float act_t;
-__device__ __forceinline__ f32x4 act_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return buf_load4(r, voff, soff); }
-__device__ __forceinline__ float act_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return buf_load1(r, voff, soff); }
-__device__ __forceinline__ void act_store4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) { buf_store4(r, voff, v); }
-__device__ __forceinline__ void act_store4_n(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) { buf_store4_n(r, voff, v, nv); }
-#endif
-// descriptor over `nelems` activation elements starting `elem_off` elements after `base`
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const float* base, long elem_off, long nelems) {
-    const act_t* q = reinterpret_cast<const act_t*>(base) + elem_off;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(q), 0, (int)(nelems * (long)sizeof(act_t)), 0x00020000);
-}
-
-template <bool TAIL>
-__device__ __forceinline__ void store_row4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v, int nv) {
-    if constexpr (TAIL) act_store4_n(r, voff, v, nv); else act_store4(r, voff, v);
-}
-template <bool TAIL>
-__device__ __forceinline__ f32x4 keep_row(f32x4 v, int nv) {
-    if constexpr (TAIL) return keep_first(v, nv); else return v;
-}
-template <int MW, int NW, int MODE, int EPI, int S>
-constexpr bool ws_tail_ok() {
-    if (MODE == MODE_POLY) return !(MW == 2 && S >= 4 && EPI == EPI_AFF);
-    return !(MW == 2 && NW == 4);
-}
-
-// Tile epilogue of the wave-specialised kernel (T % 4 == 0).  Every tensor is addressed through a
-// buffer descriptor (wave-uniform base in SGPRs) plus ONE 32-bit byte offset per (channel, time)
-// position shared by y / y2 / residual / scale / shift: no 64-bit pointer arithmetic, few VGPRs.
-struct EpiRsrc {
-    __amdgpu_buffer_rsrc_t y, y2, res, ss, r1x;
-};
-// Per-lane epilogue constants of the wave's MW channel tiles, loaded ONCE per workgroup: fetched inside
-// the epilogue each costs an L2 round trip and a vmcnt(0) that also drains the previous item's stores.
-// HOISTED false (variants already at their register budget): fetched per item as before.
-template <int MW, bool HOISTED>
-struct EpiConst {
-    const float (&k_bias)[MW];
-    const float (&k_bias2)[MW];
-    const float (&k_r1w)[MW];
-    const float (&k_r1b)[MW];
-    // cot: channel of this lane in tile m (bias arrays are padded to the tiles), co: the same clamped to COUT
-    __device__ __forceinline__ float bias(const ConvParams& p, int sig, int m, int cot) const {
-        if constexpr (HOISTED) return k_bias[m]; else return p.bias[(long)sig * p.bias_sig + cot];
-    }
-    __device__ __forceinline__ float bias2(const ConvParams& p, int sig, int m, int cot) const {
-        if constexpr (HOISTED) return k_bias2[m]; else return p.bias2[(long)sig * p.bias2_sig + cot];
-    }
-    __device__ __forceinline__ float r1w(const ConvParams& p, int sig, int m, int co) const {
-        if constexpr (HOISTED) return k_r1w[m]; else return p.r1w[(long)sig * p.r1_sig + co];
-    }
-    __device__ __forceinline__ float r1b(const ConvParams& p, int sig, int m, int co) const {
-        if constexpr (HOISTED) return k_r1b[m]; else return p.r1b[(long)sig * p.r1_sig + co];
-    }
-};
-
-template <int MW, int NW>
-__device__ __forceinline__ void ws_epilogue_tile(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[NW][MW],
-                                                 float (&s1)[MW], float (&s2)[MW],
-                                                 int sig, int mg, int tcol0, bool active, int lane) {
-    const int flags = p.flags;
-    if (p.dbg & DBG_NO_EPILOGUE) {
-        float keep = 0.f;
-        #pragma unroll
-        for (int n = 0; n < NW; ++n)
-            #pragma unroll
-            for (int m = 0; m < MW; ++m) keep += acc[n][m].x + acc[n][m].y + acc[n][m].z + acc[n][m].w;
-        if (keep == 1.2345678e33f) (p.y ? p.y : p.y2)[0] = keep;
-        return;
-    }
-    if (!active) return;
-    const float* biasp = p.bias + (long)sig * p.bias_sig;
-    const int shift_soff = p.COUT * p.ldy * 4;            // shift rows follow the scale rows
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int co = (mg * MW + m) * 16 + (lane & 15);
-        if (co >= p.COUT) continue;
-        const float bias = biasp[co];
-        float r1w = 0.f, r1b = 0.f;
-        if (p.r1x) { r1w = p.r1w[(long)sig * p.r1_sig + co]; r1b = p.r1b[(long)sig * p.r1_sig + co]; }
-        const int rowoff = co * p.ldy;
-        #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int t = tcol0 + n * 16 + (lane >> 4) * 4;
-            if (t >= p.T) continue;
-            constexpr bool TAIL = ws_tail_ok<MW, NW, MODE_DIRECT, EPI_GENERIC, 1>();
-            const int nv = TAIL ? row_valid(t, p.T) : 4;
-            const int off = (rowoff + t) * 4;
-            f32x4 v = acc[n][m];
-            v += bias;
-            if (flags & F_POST_LRELU) {
-                v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
-            }
-            if (p.res) v += act_load4(R.res, off, 0);
-            if (p.r1x) v += buf_load4(R.r1x, t * 4, 0) * r1w + r1b;
-            if (p.y) store_row4<TAIL>(R.y, off, v, nv);
-            if (flags & (F_STATS | F_AFF_OUT)) {
-                const f32x4 u = keep_row<TAIL>(act_load4(R.ss, off, 0) * v + act_load4(R.ss, off, shift_soff), nv);
-                if (flags & F_AFF_OUT) store_row4<TAIL>(R.y2, off, u, nv);
-                s1[m] += (u.x + u.y) + (u.z + u.w);
-                s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
-            }
-        }
-    }
-}
-
-// Compile-time specialised epilogues for the NARROW (HBM-bound) layers.  The generic epilogue
-// above keeps every optional tensor behind a uniform branch, which makes hipcc wait vmcnt(0)
-// after each load: ~3 serialised memory latencies per item, 8 items per tile.  Here the kind is a
-// template parameter, the code is straight-line, out-of-range lanes use an offset beyond every
-// descriptor (loads return 0, stores are dropped) and the loads of G items are issued together.
-constexpr int OOB_OFF = 0x7ffffff0;
-
-// Epilogue operands staged in LDS by the consumer wave itself (see ws_estage): fetched inside the epilogue
-// they cost MW*NW serialised memory round trips after the MFMA loop (timeline of a C = 24 unit: 16.8k of
-// 23.6k cycles), and the 128-register budget has no room to prefetch them into VGPRs.  One LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPRs) per operand and
-// 16x16 item, issued before the MFMA loop of the tile's last K chunk.  A piece lands lane-linear
-// (wave base + lane * 16), so in the epilogue every lane reads back exactly the float4 it requested:
-// a private, conflict-free extension of the register file; no cross-wave synchronisation.
-// Wave region: [operand: scale, shift, residual][m][n][64 lanes] float4.
-// The DMA is inline assembly on purpose: behind the builtin hipcc drains vmcnt(0) before every LDS read
-// that follows (and again after each item's stores); hidden from it, its own counted waits on the
-// weight ring stay valid (loads return in order, the extra pieces only make them conservative) and
-// the epilogue waits with ws_epilogue_stage_wait.  M0 (LDS base of the piece) has no other user here.
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsigned lds_byte, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_byte), "v"(voff), "s"(r), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t r, unsigned lds_byte, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                 :: "s"(lds_byte), "v"(voff), "s"(r), "s"(soff) : "memory");
-}
-// One 16 x 16 item of an activation tensor (this lane's four consecutive elements) into the wave's slot.
-// float32: one 16-byte piece per lane (1 KB slot).  bfloat16 storage: the lane's 8 bytes go as two
-// dword pieces (LDS-DMA has no 8-byte form): elements 0-1 in the first 256 B of the slot, 2-3 in the second.
-#ifdef FASTSVC_ACT_BF16
-constexpr int EST_ITEM_FLOATS = 128;
-__device__ __forceinline__ void est_fetch(__amdgpu_buffer_rsrc_t r, unsigned slot_byte, int off, int soff) {
-    lds_dma4(r, slot_byte, off >> 1, soff >> 1);
-    lds_dma4(r, slot_byte + 256, (off >> 1) + 4, soff >> 1);
-}
-__device__ __forceinline__ f32x4 est_read(const float* slot, int lane) {
-    const unsigned w0 = __builtin_bit_cast(unsigned, slot[lane]), w1 = __builtin_bit_cast(unsigned, slot[64 + lane]);
-    return f32x4{__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
-                 __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
-}
-#else
-constexpr int EST_ITEM_FLOATS = 256;
-__device__ __forceinline__ void est_fetch(__amdgpu_buffer_rsrc_t r, unsigned slot_byte, int off, int soff) {
-    lds_dma16(r, slot_byte, off, soff);
-}
-__device__ __forceinline__ f32x4 est_read(const float* slot, int lane) {
-    return reinterpret_cast<const f32x4*>(slot)[lane];
-}
-#endif
-// all pieces landed: they are older than the NEWER weight-ring loads of at least one unit
-template <int NEWER>
-__device__ __forceinline__ void ws_epilogue_stage_wait(bool counted) {
-    if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NEWER) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int MW, int NW, int EPI>
-__device__ __forceinline__ void ws_epilogue_stage(const ConvParams& p, const EpiRsrc& R, const float* Ew,
-                                                  int mg, int tcol0, int lane) {
-    const int shift_soff = p.COUT * p.ldy * 4;
-    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)Ew;
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int cot = (mg * MW + m) * 16 + (lane & 15);
-        const bool cok = cot < p.COUT;
-        const int rowoff = (cok ? cot : 0) * p.ldy;
-        #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int t = tcol0 + n * 16 + (lane >> 4) * 4;
-            const int off = (cok && t < p.T) ? (rowoff + t) * 4 : OOB_OFF;
-            constexpr int IB = EST_ITEM_FLOATS * 4;            // bytes of one item slot
-            const unsigned slot = base + (m * NW + n) * IB;
-            if (EPI == EPI_RES) est_fetch(R.res, slot, off, 0);
-            if (EPI == EPI_AFF) {
-                est_fetch(R.ss, slot, off, 0);
-                est_fetch(R.ss, slot + MW * NW * IB, off, shift_soff);
-                if (p.res) est_fetch(R.res, slot + 2 * MW * NW * IB, off, 0);
-            }
-        }
-    }
-}
-
-template <int MW, int NW, int EPI, bool EST = false, class KT>
-__device__ __forceinline__ void ws_epilogue_kind(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[NW][MW],
-                                                 float (&s1)[MW], float (&s2)[MW],
-                                                 int sig, int mg, int tcol0, bool active, int lane,
-                                                 const KT& K, const float* Ew = nullptr) {
-    if (p.dbg & DBG_NO_EPILOGUE) { ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg, tcol0, active, lane); return; }
-    if (!active) return;                                   // whole wave (uniform)
-    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;     // max(v, slope*v): identity for 1
-    const int shift_soff = p.COUT * p.ldy * 4;
-    constexpr int G = (EPI == EPI_AFF) ? (NW == 2 ? 2 : 1) : NW;           // items whose loads fly together (register budget)
-    constexpr bool TAIL = ws_tail_ok<MW, NW, MODE_DIRECT, EPI, 1>();
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int cot = (mg * MW + m) * 16 + (lane & 15);
-        const bool cok = cot < p.COUT;
-        const int co = cok ? cot : 0;
-        const float bias = K.bias(p, sig, m, cot);
-        float r1w = 0.f, r1b = 0.f;
-        if (EPI == EPI_RANK1) { r1w = K.r1w(p, sig, m, co); r1b = K.r1b(p, sig, m, co); }
-        const int rowoff = co * p.ldy;
-        #pragma unroll
-        for (int n0 = 0; n0 < NW; n0 += G) {
-            int off[G], nv[G];
-            f32x4 l0[G], l1[G], l2[G];
-            #pragma unroll
-            for (int g = 0; g < G; ++g) {                  // every load of the group first
-                const int t = tcol0 + (n0 + g) * 16 + (lane >> 4) * 4;
-                const bool ok = cok && t < p.T;
-                nv[g] = TAIL ? (ok ? row_valid(t, p.T) : 0) : 4;
-                off[g] = ok ? (rowoff + t) * 4 : OOB_OFF;
-                if constexpr (EST) {
-                    const float* slot = Ew + (m * NW + n0 + g) * EST_ITEM_FLOATS;
-                    if (EPI == EPI_RES) l0[g] = est_read(slot, lane);
-                    if (EPI == EPI_AFF) {
-                        l1[g] = est_read(slot, lane);
-                        l2[g] = est_read(slot + MW * NW * EST_ITEM_FLOATS, lane);
-                        l0[g] = p.res ? est_read(slot + 2 * MW * NW * EST_ITEM_FLOATS, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                } else {
-                    if (EPI == EPI_RES) l0[g] = act_load4(R.res, off[g], 0);
-                    if (EPI == EPI_RANK1) l0[g] = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
-                    if (EPI == EPI_AFF) {
-                        l0[g] = act_load4(R.res, off[g], 0);              // zero-length descriptor when absent
-                        l1[g] = act_load4(R.ss, off[g], 0);
-                        l2[g] = act_load4(R.ss, off[g], shift_soff);
-                    }
-                }
-            }
-            #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                f32x4 v = acc[n0 + g][m];
-                v += bias;
-                v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
-                v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
-                if (EPI == EPI_RES || EPI == EPI_AFF) v += l0[g];
-                if (EPI == EPI_RANK1) v += l0[g] * r1w + r1b;
-                store_row4<TAIL>(R.y, off[g], v, nv[g]);              // dropped when y is absent
-                if (EPI == EPI_AFF) {
-                    const f32x4 u = keep_row<TAIL>(l1[g] * v + l2[g], nv[g]);
-                    store_row4<TAIL>(R.y2, off[g], u, nv[g]);
-                    s1[m] += (u.x + u.y) + (u.z + u.w);
-                    s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
-                }
-            }
-        }
-    }
-}
-
-// Polyphase epilogue (MODE_POLY): a lane holds z, a, c for FOUR consecutive input columns of one
-// output channel, i.e. 4*S consecutive output samples = S float4 stores.  EPI_PLAIN: y = o + bias
-// (the stretched residual conv, fastsvc.py:72-75,94); EPI_AFF: t = lrelu(o + bias),
-// u = scale * t + shift -> y2, InstanceNorm partial sums (fastsvc.py:57-62,97 + 115-140).
-template <int MW, int NW, int EPI, int S, class KT>
-__device__ __forceinline__ void ws_epilogue_poly(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[3][NW][MW],
-                                                 float (&s1)[MW], float (&s2)[MW],
-                                                 int mg, int tcol0, bool active, int lane, const KT& K) {
-    if (!active) return;                                   // whole wave (uniform)
-    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
-    const int T_out = p.ldy;                               // output row pitch
-    const int shift_soff = p.COUT * T_out * 4;
-    constexpr int G = (MW <= 2 && NW == 1) ? (S < 4 ? S : 4) : S;  // output float4s whose loads fly together (register budget)
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int cot = (mg * MW + m) * 16 + (lane & 15);
-        const bool cok = cot < p.COUT;
-        const int co = cok ? cot : 0;
-        const float bias = K.bias(p, 0, m, cot);
-        const int rowoff = co * T_out;
-        #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int t = tcol0 + n * 16 + (lane >> 4) * 4;            // input-rate column
-            const bool ok = cok && t < p.T;
-            constexpr bool TAIL = ws_tail_ok<MW, NW, MODE_POLY, EPI, S>();
-            const int nvo = TAIL ? (ok ? row_valid(t, p.T) * S : 0) : 4 * S;   // valid output samples of this lane
-            const int off0 = ok ? (rowoff + t * S) * 4 : OOB_OFF;
-            // first / last phase of each input column (bias folded in); the middle phases are z + bias
-            const f32x4 zz = acc[1][n][m] + bias;
-            const f32x4 zf = zz + acc[0][n][m];
-            const f32x4 zl = zz + acc[2][n][m];
-            auto phase_value = [&](int k) -> float {               // k: compile-time after unrolling
-                const int jj = k / S, ph = k % S;
-                return ph == 0 ? zf[jj] : ph == S - 1 ? zl[jj] : zz[jj];
-            };
-            #pragma unroll
-            for (int q0 = 0; q0 < S; q0 += G) {
-                f32x4 l1[G], l2[G];
-                if (EPI == EPI_AFF) {
-                    #pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        if (q0 + g < S) {
-                            l1[g] = act_load4(R.ss, off0 + (q0 + g) * 16, 0);
-                            l2[g] = act_load4(R.ss, off0 + (q0 + g) * 16, shift_soff);
-                        }
-                }
-                #pragma unroll
-                for (int g = 0; g < G; ++g)
-                    if (q0 + g < S) {
-                        const int q = q0 + g;
-                        f32x4 v = f32x4{phase_value(4 * q), phase_value(4 * q + 1), phase_value(4 * q + 2), phase_value(4 * q + 3)};
-                        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
-                        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
-                        const int nv = min(4, max(0, nvo - 4 * q));
-                        store_row4<TAIL>(R.y, off0 + q * 16, v, nv);   // dropped when y is absent
-                        if (EPI == EPI_AFF) {
-                            const f32x4 u = keep_row<TAIL>(l1[g] * v + l2[g], nv);
-                            store_row4<TAIL>(R.y2, off0 + q * 16, u, nv);
-                            s1[m] += (u.x + u.y) + (u.z + u.w);
-                            s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
-                        }
-                    }
-            }
-        }
-    }
-}
-
-// Winograd epilogue: a lane holds m0..m3 of FOUR consecutive pairs of one output channel = the 8
-// consecutive outputs starting at tcol0 + 32 n + 8 (lane >> 4).  The even/odd interleave depends on
-// the dilation: D=1 e0 o0 e1 o1 | e2 o2 e3 o3;  D=2 e0 e1 o0 o1 | e2 e3 o2 o3;  D=4 e0..e3 | o0..o3.
-template <int MW, int NW, int EPI, int D, class KT>
-__device__ __forceinline__ void ws_epilogue_wino(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[4][NW][MW],
-                                                 int sig, int mg, int tcol0, bool active, int lane, const KT& K) {
-    if (!active) return;                                   // whole wave (uniform)
-    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int cot = (mg * MW + m) * 16 + (lane & 15);
-        const bool cok = cot < p.COUT;
-        const int co = cok ? cot : 0;
-        const float bias = K.bias(p, sig, m, cot);
-        float r1w = 0.f, r1b = 0.f;
-        if (EPI == EPI_RANK1) { r1w = K.r1w(p, sig, m, co); r1b = K.r1b(p, sig, m, co); }
-        const int rowoff = co * p.ldy;
-        #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int t = tcol0 + n * 32 + (lane >> 4) * 8;
-            int off[2], nv[2];
-            f32x4 l0[2];
-            #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool ok = cok && t + 4 * h < p.T;
-                nv[h] = cok ? row_valid(t + 4 * h, p.T) : 0;
-                off[h] = ok ? (rowoff + t + 4 * h) * 4 : OOB_OFF;
-                if (EPI == EPI_RES) l0[h] = act_load4(R.res, off[h], 0);
-                if (EPI == EPI_RANK1) l0[h] = buf_load4(R.r1x, ok ? (t + 4 * h) * 4 : OOB_OFF, 0);
-            }
-            const f32x4 m1 = acc[1][n][m], m2 = acc[2][n][m];
-            const f32x4 e = acc[0][n][m] + m1 + m2 + bias;
-            const f32x4 o = m1 - m2 - acc[3][n][m] + bias;
-            f32x4 v[2];
-            if (D == 1) { v[0] = f32x4{e.x, o.x, e.y, o.y}; v[1] = f32x4{e.z, o.z, e.w, o.w}; }
-            else if (D == 2) { v[0] = f32x4{e.x, e.y, o.x, o.y}; v[1] = f32x4{e.z, e.w, o.z, o.w}; }
-            else { v[0] = e; v[1] = o; }
-            #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 w = v[h];
-                w.x = fmaxf(w.x, w.x * slope); w.y = fmaxf(w.y, w.y * slope);
-                w.z = fmaxf(w.z, w.z * slope); w.w = fmaxf(w.w, w.w * slope);
-                if (EPI == EPI_RES) w += l0[h];
-                if (EPI == EPI_RANK1) w += l0[h] * r1w + r1b;
-                act_store4_n(R.y, off[h], w, nv[h]);
-            }
-        }
-    }
-}
-
-// MODE_DEC2 epilogue: two plain outputs, y = acc[0] + bias, y2 = acc[1] + bias2.
-template <int MW, int NW, class KT>
-__device__ __forceinline__ void ws_epilogue_dec2(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[2][NW][MW],
-                                                 int sig, int mg, int tcol0, bool active, int lane, const KT& K) {
-    if (!active) return;
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int cot = (mg * MW + m) * 16 + (lane & 15);
-        const bool cok = cot < p.COUT;
-        const int co = cok ? cot : 0;
-        const float bias = K.bias(p, sig, m, cot), bias2 = K.bias2(p, sig, m, cot);
-        const int rowoff = co * p.ldy;
-        #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int t = tcol0 + n * 16 + (lane >> 4) * 4;
-            const bool ok = cok && t < p.T;
-            const int nv = ok ? row_valid(t, p.T) : 0;
-            const int off = ok ? (rowoff + t) * 4 : OOB_OFF;
-            act_store4_n(R.y, off, acc[0][n][m] + bias, nv);
-            act_store4_n(R.y2, off, acc[1][n][m] + bias2, nv);
-        }
-    }
-}
-
 // Register budget: 128 VGPRs (two workgroups per CU) where that fits without spills, else 256.
 // Polyphase with MW == 3 carries three accumulator sets next to the 54-register weight ring and
 // a 2*S-load epilogue: 256 (those layers launch about one workgroup per CU anyway).

@@ -57,7 +57,9 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as f:
     f.write("kernel,launches_profiled,FETCH_SIZE_KiB_per_launch_raw,WRITE_SIZE_KiB_per_launch,hbm_bytes_per_launch_corrected\n")
     for r in rows:
         f.write('"%s",%d,%.1f,%.1f,%.0f\n' % r)
-json.dump(js, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+# bench.py reads pmc_traffic.json for the cfg2 line's `roofline.traffic`; other workloads get their own file
+json.dump(js, open(os.path.join(dst, "pmc_traffic.json" if "cfg" not in tag or "cfg2" in tag else f"{tag}_pmc_traffic.json"), "w"),
+          indent=1, sort_keys=True)
 print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:3000])
 for r in rows[:8]:
     print("%-70s n=%3d fetch %9.0f KiB write %9.0f KiB -> %7.1f MB/launch" % (r[0][:70], r[1], r[2], r[3], r[4] / 1e6))
