@@ -125,6 +125,13 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
  * a latency-critical first call).  Idempotent. */
 int fastsvc_stream_prepare(void* stream);
 
+/* Host-side number formats of the half-precision-MFMA kernels (csrc/fastsvc_hx.hip), exported so that the
+ * packer's conversions can be pinned against an independent implementation (tests/test_boundary.py):
+ * for each of n floats x:  f16_hi = binary16(x), f16_lo = binary16(x - f16_hi)  (the split-half pieces:
+ * x = hi + lo to 22 significand bits) and bf16 = bfloat16(x); all round-to-nearest-even, raw bit patterns.
+ * Any output pointer may be NULL. */
+void fastsvc_split_half(const float* x, int64_t n, uint16_t* f16_hi, uint16_t* f16_lo, uint16_t* bf16);
+
 /* Test / profiling support: location of a named intermediate tensor inside the workspace after a
  * forward (names as in oracle/fastsvc_oracle.py taps: "down_lft.0", "scale.2", "up.1.xmid", ...).
  * Returns 0 and fills byte offset / element count / shape (up to 3 dims: B, C, T). */

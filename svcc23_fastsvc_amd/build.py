@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip.so")
 # the stamped diagnostic build (--timeline) is a separate file: loaded only when FASTSVC_HIP_LIB names it
 TIMELINE_LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip_timeline.so")
-SOURCES = ["fastsvc_kernels.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip"]
+SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip"]
 HEADERS = [os.path.join(CSRC, "fastsvc_kernels.h"), os.path.join(ROOT, "include", "fastsvc_hip.h")]
 ARCH = "gfx950"
 
@@ -42,6 +42,8 @@ def needs_build() -> bool:
 UNITS = [
     ("fastsvc_kernels.hip", [], "kernels_f32.o"),
     ("fastsvc_kernels.hip", ["-DFASTSVC_ACT_BF16=1"], "kernels_bf16.o"),
+    ("fastsvc_hx.hip", [], "hx_f32.o"),
+    ("fastsvc_hx.hip", ["-DFASTSVC_ACT_BF16=1"], "hx_bf16.o"),
     ("fastsvc_plan.cpp", [], "plan.o"),
     ("fastsvc_signal.hip", [], "signal.o"),
 ]
@@ -70,12 +72,14 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
     for src, extra, obj in UNITS:
         key = hashlib.sha1(open(os.path.join(CSRC, src), "rb").read() + hdr_hash.digest() +
                            " ".join(common + extra).encode()).hexdigest()[:16]
-        path = os.path.join(cache, f"{os.path.splitext(obj)[0]}_{key}.o")
+        stem = os.path.splitext(obj)[0] + ("_tl" if timeline else "")
+        path = os.path.join(cache, f"{stem}_{key}.o")
         objs.append(path)
         if os.path.exists(path) and not force:
             continue
         for stale in os.listdir(cache):
-            if stale.startswith(os.path.splitext(obj)[0] + "_") and stale.endswith(".o"):
+            if stale.startswith(stem + "_") and stale[len(stem) + 1:len(stem) + 17] != key and \
+                    len(stale) == len(stem) + 19 and stale.endswith(".o"):
                 os.remove(os.path.join(cache, stale))
         cmd = [hipcc, *common, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", path + ".tmp"]
         if verbose:

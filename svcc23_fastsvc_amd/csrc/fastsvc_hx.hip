@@ -19,8 +19,8 @@
 //     double-buffered LDS tile, p.tpw consecutive tiles per workgroup - the pipeline of conv_mfma_ws_kernel;
 //   * LDS tile = TIME-major rows of 32 channels (64 B of f16 / bf16): a lane's MFMA A-fragment - 8
 //     consecutive input channels at one time step - is ONE ds_read_b128, and a conv tap is a ROW offset
-//     (always 16-byte aligned whatever the dilation).  16-byte slot s of row r sits at slot s ^ ((r >> 1) & 2):
-//     conflict-free for the four 16-lane service groups of ds_read_b128 at any row offset;
+//     (always 16-byte aligned whatever the dilation).  Rows and 16-byte slots are swizzled (hx_lds_off) so that
+//     both the consumers' ds_read_b128 at any row offset and the producers' ds_write_b128 are conflict-free;
 //   * producers load float4 (4 time steps) of 8 channels per thread - 256 B contiguous per channel row and
 //     wave instruction -, apply InstanceNorm / LeakyReLU, split, transpose 4 x 8 in registers and write
 //     4 (+4) ds_write_b128;
@@ -59,8 +59,13 @@ constexpr int HX_KC = 32;                // input channels per K chunk = one MFM
 constexpr int HX_ROW = 64;               // bytes of one LDS tile row (32 channels)
 constexpr int HX_FRAG = 1024;            // bytes of one packed weight fragment (64 lanes x 8 halves)
 
-// LDS byte offset of 16-byte slot `oct` of tile row `row`
-__device__ __forceinline__ int hx_lds_off(int row, int oct) { return row * HX_ROW + ((oct ^ ((row >> 1) & 2)) << 4); }
+// LDS byte offset of 16-byte slot `oct` of tile row `row`: rows with bit 2 set swap places inside their pair,
+// slots 0/1 swap with 2/3 in those rows.  Conflict-free for ds_read_b128 at ANY row offset (four 16-lane
+// service groups over 64 banks) and for the producers' ds_write_b128 (8-lane groups = 4 slots x 2 row quads over
+// 32 banks) - searched exhaustively, see DESIGN.md.
+__device__ __forceinline__ int hx_lds_off(int row, int oct) {
+    return ((row ^ ((row >> 2) & 1)) * HX_ROW) + ((oct ^ ((row >> 1) & 2)) << 4);
+}
 
 // Unit-deep weight ring: NSLOT fragments = every fragment of one (tile, chunk) unit of this wave's channel
 // group, statically indexed; slot s is re-requested with the NEXT unit's fragment s right after its last use.
@@ -103,42 +108,115 @@ __device__ __forceinline__ f32x4 hx_prod(const HxFrag& a, const u32x4 (&w)[HX_NP
 }
 constexpr int HX_NPROD = HX_NP == 2 ? 3 : 1;
 
-// DIRECT unit: acc[n][m] += sum_tap X[t + (tap-1) d] W[tap].  Steps run tap-major so that a tap's weight
-// slots are re-requested (for the next unit) as early as possible; the A fragments of step s+1 are read
-// from LDS before the MFMAs of step s.  aoff[tap]: this lane's byte offset of (row of time tile 0, its octet).
+// One step = the MFMAs of ONE weight slot (MW channel tiles) on ONE time tile.  The steps of a unit run
+// slot-major, so that a slot's fragments are re-requested (for the next unit) right after their last use and
+// fly for a whole unit; the A fragments of step s+1 are read from LDS before the MFMAs of step s.
+template <int MW>
+__device__ __forceinline__ void hx_step(f32x4 (&acc)[MW], const HxFrag& a, const u32x4* w /* [MW][HX_NP] */) {
+    #pragma unroll
+    for (int pr = 0; pr < HX_NPROD; ++pr)
+        #pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            u32x4 wm[HX_NP];
+            #pragma unroll
+            for (int q = 0; q < HX_NP; ++q) wm[q] = w[m * HX_NP + q];
+            if (pr == 0) acc[m] = hx_prod<0>(a, wm, acc[m]);
+            else if (pr == 1) acc[m] = hx_prod<1>(a, wm, acc[m]);
+            else acc[m] = hx_prod<2>(a, wm, acc[m]);
+        }
+}
+__device__ __forceinline__ HxFrag hx_neg(HxFrag a) {
+    #pragma unroll
+    for (int q = 0; q < HX_NP; ++q) {
+        u32x4 b = __builtin_bit_cast(u32x4, a.p[q]);
+        b ^= 0x80008000u;
+        a.p[q] = __builtin_bit_cast(hx8, b);
+    }
+    return a;
+}
+
+// DIRECT unit: acc[n][m] += sum_tap X[t + (tap-1) d] W[tap].  aoff[tap]: this lane's byte offset of (row of
+// time tile 0 shifted by the tap, its octet).
 template <int MW, int NW, bool RELOAD>
 __device__ __forceinline__ void hx_unit_direct(f32x4 (&acc)[NW][MW], const unsigned char* tile, const int (&aoff)[3],
                                                int lo_off, HxWeightStream<3 * MW * HX_NP>& ws) {
-    constexpr int NG = (MW >= 3 || NW == 1) ? 1 : 2;          // time tiles per step (>= 3 independent accumulators)
-    constexpr int NSTEP = 3 * NW / NG;
-    HxFrag a[2][NG];
-    #pragma unroll
-    for (int g = 0; g < NG; ++g) a[0][g] = hx_read(tile, aoff[0] + g * 16 * HX_ROW, lo_off);
+    constexpr int NSTEP = 3 * NW;
+    HxFrag a[2];
+    a[0] = hx_read(tile, aoff[0], lo_off);
     #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-        const int tap = s / (NW / NG), n0 = (s % (NW / NG)) * NG;
+        const int tap = s / NW, n = s % NW;
         if (s + 1 < NSTEP) {
-            const int tap1 = (s + 1) / (NW / NG), n1 = ((s + 1) % (NW / NG)) * NG;
-            #pragma unroll
-            for (int g = 0; g < NG; ++g) a[(s + 1) & 1][g] = hx_read(tile, aoff[tap1] + (n1 + g) * 16 * HX_ROW, lo_off);
+            a[(s + 1) & 1] = hx_read(tile, aoff[(s + 1) / NW] + ((s + 1) % NW) * 16 * HX_ROW, lo_off);
             __builtin_amdgcn_sched_barrier(0);                 // reads stay ahead of the MFMAs
         }
-        #pragma unroll
-        for (int pr = 0; pr < HX_NPROD; ++pr)
-            #pragma unroll
-            for (int g = 0; g < NG; ++g)
-                #pragma unroll
-                for (int m = 0; m < MW; ++m) {
-                    u32x4 w[HX_NP];
-                    #pragma unroll
-                    for (int q = 0; q < HX_NP; ++q) w[q] = ws.wr[(tap * MW + m) * HX_NP + q];
-                    if (pr == 0) acc[n0 + g][m] = hx_prod<0>(a[s & 1][g], w, acc[n0 + g][m]);
-                    else if (pr == 1) acc[n0 + g][m] = hx_prod<1>(a[s & 1][g], w, acc[n0 + g][m]);
-                    else acc[n0 + g][m] = hx_prod<2>(a[s & 1][g], w, acc[n0 + g][m]);
-                }
-        if (RELOAD && n0 + NG == NW) {                          // last use of this tap's fragments
+        hx_step<MW>(acc[n], a[s & 1], &ws.wr[tap * MW * HX_NP]);
+        if (RELOAD && n + 1 == NW) {                            // last use of this tap's fragments
             #pragma unroll
             for (int q = 0; q < MW * HX_NP; ++q) ws.request(tap * MW * HX_NP + q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (RELOAD) ws.advance();
+}
+
+// POLY unit (Stretch2d + k=3 conv at the INPUT rate, fastsvc_kernels.h MODE_POLY): three accumulator sets
+//   a += W0 x[j-1] - W0 x[j],   z += (W0+W1+W2) x[j],   c += W2 x[j+1] - W2 x[j]
+// (the differences of the f32 kernel become a second product with the negated fragment: exact for split pieces).
+// Weight slots: W0 | W0+W1+W2 | W2.
+template <int MW, int NW, bool RELOAD>
+__device__ __forceinline__ void hx_unit_poly(f32x4 (&acc)[3][NW][MW], const unsigned char* tile, const int (&aoff)[3],
+                                             int lo_off, HxWeightStream<3 * MW * HX_NP>& ws) {
+    constexpr int NSTEP = 3 * NW;
+    HxFrag side[2], mid[2];                                     // x[j -/+ 1] and x[j] of the step, one step ahead
+    side[0] = hx_read(tile, aoff[0], lo_off);
+    mid[0] = hx_read(tile, aoff[1], lo_off);
+    #pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int slot = s / NW, n = s % NW;
+        if (s + 1 < NSTEP) {
+            const int slot1 = (s + 1) / NW, n1 = (s + 1) % NW;
+            if (slot1 != 1) side[(s + 1) & 1] = hx_read(tile, aoff[slot1] + n1 * 16 * HX_ROW, lo_off);
+            mid[(s + 1) & 1] = hx_read(tile, aoff[1] + n1 * 16 * HX_ROW, lo_off);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (slot == 1) {
+            hx_step<MW>(acc[1][n], mid[s & 1], &ws.wr[slot * MW * HX_NP]);
+        } else {
+            hx_step<MW>(acc[slot][n], side[s & 1], &ws.wr[slot * MW * HX_NP]);
+            hx_step<MW>(acc[slot][n], hx_neg(mid[s & 1]), &ws.wr[slot * MW * HX_NP]);
+        }
+        if (RELOAD && n + 1 == NW) {
+            #pragma unroll
+            for (int q = 0; q < MW * HX_NP; ++q) ws.request(slot * MW * HX_NP + q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (RELOAD) ws.advance();
+}
+
+// DEC2 unit (first k=3 conv + 1x1 residual conv of a down stage on the decimated input, MODE_DEC2):
+//   acc[0] += sum_tap lrelu(x)[t + tap - 1] W[tap]   (LeakyReLU'd tile),   acc[1] += x[t] W1x1   (raw tile)
+// Weight slots: w0 w1 w2 | w1x1.  raw_off: byte offset of the raw tile behind the LeakyReLU'd one.
+template <int MW, int NW, bool RELOAD>
+__device__ __forceinline__ void hx_unit_dec2(f32x4 (&acc)[2][NW][MW], const unsigned char* tile, const int (&aoff)[3],
+                                             int lo_off, int raw_off, HxWeightStream<4 * MW * HX_NP>& ws) {
+    constexpr int NSTEP = 4 * NW;
+    HxFrag a[2];
+    a[0] = hx_read(tile, aoff[0], lo_off);
+    #pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int slot = s / NW, n = s % NW;
+        if (s + 1 < NSTEP) {
+            const int slot1 = (s + 1) / NW, n1 = (s + 1) % NW;
+            a[(s + 1) & 1] = slot1 < 3 ? hx_read(tile, aoff[slot1] + n1 * 16 * HX_ROW, lo_off)
+                                       : hx_read(tile + raw_off, aoff[1] + n1 * 16 * HX_ROW, lo_off);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        hx_step<MW>(acc[slot == 3][n], a[s & 1], &ws.wr[slot * MW * HX_NP]);
+        if (RELOAD && n + 1 == NW) {
+            #pragma unroll
+            for (int q = 0; q < MW * HX_NP; ++q) ws.request(slot * MW * HX_NP + q);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -149,7 +227,15 @@ __device__ __forceinline__ void hx_unit_direct(f32x4 (&acc)[NW][MW], const unsig
 __device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int lo_off, const float (&e)[8]) {
     hx8 h;
     #pragma unroll
-    for (int c = 0; c < 8; ++c) h[c] = (hx_t)e[c];
+    for (int c = 0; c < 8; ++c) {
+#ifdef FASTSVC_ACT_BF16
+        h[c] = (hx_t)e[c];
+#else
+        // binary16 overflows at 65520: saturate the high piece (the low piece then carries what is left,
+        // up to another 65504) instead of producing inf - far outside anything the generator produces
+        h[c] = (hx_t)__builtin_amdgcn_fmed3f(e[c], -65504.f, 65504.f);
+#endif
+    }
     *reinterpret_cast<hx8*>(tile + off) = h;
     if constexpr (HX_NP == 2) {
         hx8 l;
@@ -159,20 +245,33 @@ __device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int
     }
 }
 
-template <int MW, int NW, int EPI>
+// variants that stage their epilogue operands (scale, shift, residual) in LDS ahead of the epilogue with
+// LDS-DMA pieces (ws_epilogue_stage, fastsvc_device.inc): fetched inside the epilogue each 16x16 item costs a
+// full memory round trip (timeline of up.3.d3 without it: 15.5k of 17k cycles per unit in the epilogue)
+template <int MW, int NW, int MODE, int EPI>
+constexpr bool hx_estage() { return MODE == MODE_DIRECT && (EPI == EPI_AFF || EPI == EPI_RES) && MW * NW <= 6; }
+
+template <int MW, int NW, int MODE, int EPI>
 constexpr int hx_min_waves() {
-    // 128 VGPRs (two workgroups per CU) when ring + accumulators + the producers' two register sets fit
-    return (MW * NW <= 4) ? 4 : 2;
+    // 128 VGPRs = two 8-wave workgroups per CU (one computes while the other stores: the C = 24 layers are
+    // bound by their store phase) where the producers' two register sets (2 x 32), the unit-deep weight ring
+    // (12 * MW) and the accumulators fit; else 256
+    return (MODE == MODE_DIRECT && MW == 2 && (EPI == EPI_PLAIN || EPI == EPI_RANK1 || EPI == EPI_RES)) ? 4 : 2;
 }
 
-template <int MW, int NW, int WM, int WN, int EPI, bool WSTATIC>
-__global__ __launch_bounds__(512, (hx_min_waves<MW, NW, EPI>()))
-void conv_hx_direct_kernel(const ConvParams p0) {
-    constexpr int NT = 16 * NW * WN;                                   // output columns per workgroup tile
+// MODE: MODE_DIRECT (any dilation <= 28), MODE_POLY (S = stretch factor; tiles walk the INPUT columns) or
+// MODE_DEC2 (p.s = decimation; two outputs).  EPI: epilogue kind (DEC2: ignored).
+template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S, bool WSTATIC>
+__global__ __launch_bounds__(512, (hx_min_waves<MW, NW, MODE, EPI>()))
+void conv_hx_kernel(const ConvParams p0) {
+    constexpr bool POLY = MODE == MODE_POLY, DEC2 = MODE == MODE_DEC2;
+    constexpr int NT = 16 * NW * WN;                                   // (input-rate) columns per workgroup tile
     constexpr int NPROD_T = 256;                                       // producer threads
-    constexpr int MAXW = NT + 56;                                      // halo <= 28 rows per side
+    constexpr int MAXW = NT + (MODE == MODE_DIRECT ? 56 : 8);          // halo <= 28 rows per side (1 for POLY / DEC2)
     constexpr int ITEMS = (MAXW + NPROD_T - 1) / NPROD_T;              // (octet, 4 time steps) items per producer thread
-    constexpr int NSLOT = 3 * MW * HX_NP;
+    constexpr int NWS = DEC2 ? 4 : 3;                                  // weight slots per unit and channel tile
+    constexpr int NVAR = DEC2 ? 2 : 1;                                 // tile variants: LeakyReLU'd (+ raw)
+    constexpr int NSLOT = NWS * MW * HX_NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tid = threadIdx.x;
@@ -193,7 +292,7 @@ void conv_hx_direct_kernel(const ConvParams p0) {
     }
     const int mg = blockIdx.y * WM + wave_m;
     const bool active = !producer && mg < p.ngroups;
-    const int halo = p.dil;
+    const int halo = MODE == MODE_DIRECT ? p.dil : 1;
     const int halo_al = (halo + 3) & ~3;
     const int W = NT + 2 * halo_al;                                    // tile rows
     const int nch = p.nch32;
@@ -204,31 +303,62 @@ void conv_hx_direct_kernel(const ConvParams p0) {
     const int ntiles = min(p.tpw, ntx - tile0);
     if (ntiles <= 0) return;
     const int nunits = ntiles * nch;
+#ifdef FASTSVC_TIMELINE
+    // diagnostic build (tools/timeline.py): lane 0 of every wave stamps s_memtime at its phase boundaries
+    const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned long long* tlw = (p.tl && wg_lin < p.tl_wgs) ? p.tl + ((long)wg_lin * 8 + wave) * 64 : nullptr;
+    int tli = 0;
+    auto stamp = [&](int tag) {
+        if (tlw && lane == 0 && tli < 62) { tlw[tli++] = ((unsigned long long)tag << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); }
+    };
+    stamp(1);
+    if (tlw && lane == 0) {
+        tlw[62] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        tlw[63] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+    }
+#else
+    auto stamp = [](int) {};
+#endif
 
+    // Two workgroups share a CU in the 128-VGPR variants.  Dispatched together they would run their phases
+    // in lockstep (both load, both multiply, both store): the second one of a CU (workgroup ids 256 apart
+    // in dispatch order) starts about half a unit late, so one stores while the other multiplies.
+    if constexpr (hx_min_waves<MW, NW, MODE, EPI>() >= 4) {
+        const int wg_id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if ((wg_id >> 8) & 1) {
+            for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles per step
+        }
+    }
     double* sstat = reinterpret_cast<double*>(smem_raw);                               // [WM*MW*16][2]
     float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);   // [CINp]
     unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp);             // [2][HX_NP][W rows][64 B]
-    const int lo_off = W * HX_ROW;                                     // hi tile, then lo tile
-    const int bufsz = HX_NP * W * HX_ROW;
+    const int lo_off = (W + 4) * HX_ROW;                               // hi tile (+ 4 spare rows), then lo tile
+    const int raw_off = HX_NP * (W + 4) * HX_ROW;                      // DEC2: the raw tile behind the LeakyReLU'd one
+    const int bufsz = NVAR * HX_NP * (W + 4) * HX_ROW;
 
     auto setup_shared = [&]() {
         if (flags & F_STATS) {
             for (int i = tid; i < 2 * 16 * MW * WM; i += 512) sstat[i] = 0.0;
         }
-        if (flags & F_PRE_NORM) {
-            // (u - mean) * rstd + p  ==  u * A + Bc  with A = rstd, Bc = p - mean * rstd   (fastsvc.py:134-139)
+        // prologue coefficients of every input channel, applied by the producers as ONE FMA u * A + Bc:
+        // InstanceNorm + speaker bias (u - mean) * rstd + p  ->  A = rstd, Bc = p - mean * rstd (fastsvc.py:134-139);
+        // no norm: (1, 0); channel padding: (0, 0)
+        {
             const double inv_len = 1.0 / (double)p.x_T;
             for (int c = tid; c < CINp; c += 512) {
                 float2 ab = make_float2(0.f, 0.f);
                 if (c < p.CIN) {
-                    const double q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
-                    const double q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
-                    const double mean = q1 * inv_len;
-                    double var = q2 * inv_len - mean * mean;          // biased variance (InstanceNorm2d)
-                    var = var > 0.0 ? var : 0.0;
-                    const double rstd = 1.0 / sqrt(var + IN_EPS);
-                    ab.x = (float)rstd;
-                    ab.y = (float)((double)p.spk[(long)b * p.CIN + c] - mean * rstd);
+                    ab = make_float2(1.f, 0.f);
+                    if (flags & F_PRE_NORM) {
+                        const double q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
+                        const double q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
+                        const double mean = q1 * inv_len;
+                        double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
+                        var = var > 0.0 ? var : 0.0;
+                        const double rstd = 1.0 / sqrt(var + IN_EPS);
+                        ab.x = (float)rstd;
+                        ab.y = (float)((double)p.spk[(long)b * p.CIN + c] - mean * rstd);
+                    }
                 }
                 ncoef[c] = ab;
             }
@@ -241,92 +371,119 @@ void conv_hx_direct_kernel(const ConvParams p0) {
         const int ptid = tid - 256;
         const __amdgpu_buffer_rsrc_t xr =
             act_rsrc(p.x, (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
+        // item = (octet of 8 channels, quad of 4 rows); threads without an item park theirs in the 4 spare rows
+        // behind the tile, so that the code below is straight-line (any branch between the loads and their use
+        // makes hipcc wait vmcnt(0), i.e. for the NEXT unit's loads as well)
         int it_oct[ITEMS], it_q[ITEMS];
+        bool it_in[ITEMS];
         #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const int idx = i * NPROD_T + ptid;
             it_oct[i] = idx & 3;
-            it_q[i] = (idx >> 2) < (W >> 2) ? (idx >> 2) : -1;          // quad of rows 4q .. 4q+3; -1: no item
+            it_in[i] = (idx >> 2) < (W >> 2);
+            it_q[i] = it_in[i] ? (idx >> 2) : (W >> 2);
         }
+        const float slope = (DEC2 || (flags & F_PRE_LRELU)) ? LRELU_SLOPE : 1.0f;     // max(v, slope * v): identity for 1
         // unconditional loads of unit `un`: 8 channels x 4 time steps per item; whatever lies outside the
         // tensor or the utterance reads as 0 through the descriptor (offset pushed out of range)
-        auto pload = [&](int un, f32x4 (&px)[ITEMS][8], unsigned& okmask) {
+        auto pload = [&](int un, f32x4 (&px)[ITEMS][8], unsigned& tokmask) {
             const int tl = un / nch;
             const int ch = un - tl * nch;
             const int t_start = (tile0 + tl) * NT - halo_al;
             const int soff = ch * HX_KC * p.ldx * 4;
             const int rows_left = p.CIN - ch * HX_KC;
-            okmask = 0;
+            tokmask = 0;
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const int t = t_start + 4 * it_q[i];
-                const bool tok = it_q[i] >= 0 && (unsigned)t < (unsigned)p.T;
+                const bool tok = it_in[i] && (unsigned)t < (unsigned)p.T && un < nunits && !(p.dbg & DBG_NO_LOAD);
+                tokmask |= (tok ? 1u : 0u) << i;
                 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const int r = it_oct[i] * 8 + c;
-                    const bool ok = tok && r < rows_left;
-                    okmask |= (ok ? 1u : 0u) << (i * 8 + c);
-                    px[i][c] = act_load4(xr, ok ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
+                    if constexpr (DEC2) {
+                        // x[..., ::s] (Squeeze2d): four strided elements; negative t lies before the tensor -> 0
+                        const int o = (tok && r < rows_left) ? (r * p.ldx + t * p.s) * 4 : OOB_OFF;
+                        px[i][c].x = act_load1(xr, o, soff);
+                        px[i][c].y = act_load1(xr, o + 4 * p.s, soff);
+                        px[i][c].z = act_load1(xr, o + 8 * p.s, soff);
+                        px[i][c].w = act_load1(xr, o + 12 * p.s, soff);
+                    } else {
+                        px[i][c] = act_load4(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
+                    }
                 }
             }
         };
-        // prologue transform (InstanceNorm-apply + speaker bias as one FMA, LeakyReLU), split, transpose, LDS write
-        auto pcommit = [&](int un, const f32x4 (&px)[ITEMS][8], unsigned okmask, unsigned char* tile) {
+        // prologue transform (one FMA: InstanceNorm-apply + speaker bias; LeakyReLU), split, transpose, LDS write
+        auto pcommit = [&](int un, const f32x4 (&px)[ITEMS][8], unsigned tokmask, unsigned char* tile) {
+            if (p.dbg & DBG_NO_COMMIT) return;
             const int ch = un % nch;
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
-                if (it_q[i] < 0) continue;
-                f32x4 v[8];
+                // (A, Bc) of the item's 8 channels: 64 contiguous bytes
+                const f32x4* cf = reinterpret_cast<const f32x4*>(ncoef + ch * HX_KC + it_oct[i] * 8);
+                const f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+                const float A[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
+                float Bc[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
+                // rows outside the utterance are the conv's zero padding AFTER the prologue: their loads
+                // returned 0, so only the additive term has to go
+                const bool tok = (tokmask >> i) & 1u;
                 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    v[c] = f32x4{0.f, 0.f, 0.f, 0.f};                  // zero "same" padding / channel padding
-                    if (okmask & (1u << (i * 8 + c))) {
-                        v[c] = px[i][c];
-                        if (flags & F_PRE_NORM) {
-                            const float2 ab = ncoef[ch * HX_KC + it_oct[i] * 8 + c];
-                            v[c] = v[c] * ab.x + ab.y;
-                        }
-                        if (flags & F_PRE_LRELU) {
-                            v[c].x = lrelu(v[c].x); v[c].y = lrelu(v[c].y); v[c].z = lrelu(v[c].z); v[c].w = lrelu(v[c].w);
-                        }
-                    }
-                }
+                for (int c = 0; c < 8; ++c) Bc[c] = tok ? Bc[c] : 0.f;
+                // one time step (= one 16-byte slot of 8 channels per piece) at a time: the transformed values
+                // never exist as a second copy of the register set
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    // odd quads write their rows in the order 1 0 3 2: the 8 lanes of a ds_write_b128 service
-                    // group (two quads) then cover both 64-byte halves of the 32 write banks
-                    const int jj = j ^ (it_q[i] & 1);
                     float e[8];
                     #pragma unroll
-                    for (int c = 0; c < 8; ++c) e[c] = jj == 0 ? v[c].x : jj == 1 ? v[c].y : jj == 2 ? v[c].z : v[c].w;
-                    hx_commit_slot(tile, hx_lds_off(4 * it_q[i] + jj, it_oct[i]), lo_off, e);
+                    for (int c = 0; c < 8; ++c) {
+                        const float u = px[i][c][j] * A[c] + Bc[c];
+                        e[c] = fmaxf(u, u * slope);
+                    }
+                    hx_commit_slot(tile, hx_lds_off(4 * it_q[i] + j, it_oct[i]), lo_off, e);
+                    if constexpr (DEC2) {                  // the raw copy for the 1x1 residual conv (no prologue at all)
+                        float r[8];
+                        #pragma unroll
+                        for (int c = 0; c < 8; ++c) r[c] = px[i][c][j];
+                        hx_commit_slot(tile + raw_off, hx_lds_off(4 * it_q[i] + j, it_oct[i]), lo_off, r);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
 
         f32x4 pa[ITEMS][8], pb[ITEMS][8];
-        unsigned oka = 0, okb = 0;
+        unsigned oka = 0, okb = 0;                       // per-item "rows inside the utterance" bits
+        // No branch may sit between a load and its use (hipcc then counts vmcnt for the path WITHOUT the
+        // newer loads and so waits for them too - a full memory latency per unit): loads and commits are
+        // unconditional; past the last unit they fetch nothing (offsets out of range) and stage zeros into the
+        // buffer nobody reads.
         pload(0, pa, oka);
-        if (nunits > 1) pload(1, pb, okb);
+        pload(1, pb, okb);
+        stamp(2);
         setup_shared();
         pcommit(0, pa, oka, tiles);
+        stamp(3);
         __syncthreads();                               // unit 0 staged
+        stamp(4);
         for (int u = 0; u < nunits; u += 2) {
-            if (u + 1 < nunits) {
-                if (u + 2 < nunits) pload(u + 2, pa, oka);
-                pcommit(u + 1, pb, okb, tiles + bufsz);
-            }
+            pload(u + 2, pa, oka);
+            pcommit(u + 1, pb, okb, tiles + bufsz);
+            stamp(5);
             __syncthreads();                           // end of unit u
+            stamp(6);
             if (u + 1 >= nunits) break;
-            if (u + 2 < nunits) {
-                if (u + 3 < nunits) pload(u + 3, pb, okb);
-                pcommit(u + 2, pa, oka, tiles);
-            }
+            pload(u + 3, pb, okb);
+            pcommit(u + 2, pa, oka, tiles);
+            stamp(5);
             __syncthreads();                           // end of unit u+1
+            stamp(6);
         }
     } else {
         // ================================ CONSUMER WAVES ================================
-        f32x4 acc[NW][MW];
+        f32x4 acc[(POLY || DEC2) ? 1 : NW][MW];
+        f32x4 acc3[3][POLY ? NW : 1][MW];             // polyphase: a / z / c accumulator sets
+        f32x4 acc2[2][DEC2 ? NW : 1][MW];             // decimating pair: k=3 / 1x1
         float s1[MW], s2[MW];
         HxWeightStream<NSLOT> wst;
         wst.init(reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
@@ -340,7 +497,7 @@ void conv_hx_direct_kernel(const ConvParams p0) {
             const long ct = (long)p.COUT * p.ldy;
             const float* nul = p.bias;
             R.y = act_rsrc(p.y ? p.y : nul, p.y ? (long)sig * p.y_sig + (long)b * p.y_b : 0, p.y ? ct : 0);
-            const bool has_y2 = (flags & F_AFF_OUT) != 0;
+            const bool has_y2 = DEC2 || (flags & F_AFF_OUT) != 0;
             R.y2 = act_rsrc(has_y2 ? p.y2 : nul, has_y2 ? (long)sig * p.y2_sig + (long)b * p.y2_b : 0, has_y2 ? ct : 0);
             R.res = act_rsrc(p.res ? p.res : nul, p.res ? (long)sig * p.res_sig + (long)b * p.res_b : 0, p.res ? ct : 0);
             const bool has_ss = (flags & (F_STATS | F_AFF_OUT)) != 0;
@@ -355,28 +512,56 @@ void conv_hx_direct_kernel(const ConvParams p0) {
             const bool cok = active && cot < p.COUT;
             k_bias[m] = cok ? p.bias[(long)sig * p.bias_sig + co] : 0.f;
             k_bias2[m] = 0.f; k_r1w[m] = 0.f; k_r1b[m] = 0.f;
+            if constexpr (DEC2) k_bias2[m] = cok ? p.bias2[(long)sig * p.bias2_sig + co] : 0.f;
             if constexpr (EPI == EPI_RANK1) {
                 k_r1w[m] = cok ? p.r1w[(long)sig * p.r1_sig + co] : 0.f;
                 k_r1b[m] = cok ? p.r1b[(long)sig * p.r1_sig + co] : 0.f;
             }
         }
         const EpiConst<MW, true> K{k_bias, k_bias2, k_r1w, k_r1b};
+        constexpr bool EST = hx_estage<MW, NW, MODE, EPI>();
+        // this wave's epilogue-operand slots, behind the tile buffers (hx_launch_direct sizes them)
+        const float* Ew = reinterpret_cast<const float*>(tiles + 2 * bufsz) +
+                          cw * ((EPI == EPI_RES ? 1 : p.res ? 3 : 2) * MW * NW * EST_ITEM_FLOATS);
+        stamp(2);
         setup_shared();
         __syncthreads();                               // unit 0 staged
+        stamp(4);
         int u = 0;
         for (int tl = 0; tl < ntiles; ++tl) {
             #pragma unroll
             for (int n = 0; n < NW; ++n)
                 #pragma unroll
-                for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int m = 0; m < MW; ++m) {
+                    if constexpr (POLY) { acc3[0][n][m] = acc3[1][n][m] = acc3[2][n][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    else if constexpr (DEC2) { acc2[0][n][m] = acc2[1][n][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    else acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             for (int ch = 0; ch < nch; ++ch, ++u) {
-                if (active) hx_unit_direct<MW, NW, !WSTATIC>(acc, tiles + (u & 1) * bufsz, aoff, lo_off, wst);
+                if constexpr (EST) {
+                    // one unit earlier when the tile has several K chunks: more time to land
+                    if (active && ch == max(nch - 2, 0) && !(p.dbg & DBG_NO_EPILOGUE))
+                        ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
+                }
+                if (active && !(p.dbg & DBG_NO_MFMA)) {
+                    if constexpr (POLY) hx_unit_poly<MW, NW, !WSTATIC>(acc3, tiles + (u & 1) * bufsz, aoff, lo_off, wst);
+                    else if constexpr (DEC2) hx_unit_dec2<MW, NW, !WSTATIC>(acc2, tiles + (u & 1) * bufsz, aoff, lo_off, raw_off, wst);
+                    else hx_unit_direct<MW, NW, !WSTATIC>(acc, tiles + (u & 1) * bufsz, aoff, lo_off, wst);
+                }
+                stamp(7);
                 if (ch + 1 == nch) {
                     #pragma unroll
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
-                    ws_epilogue_kind<MW, NW, EPI, false, 0>(p, R, acc, s1, s2, sig, mg,
-                                                            (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
-                    if (flags & F_STATS) {
+                    // the staged pieces are older than the NSLOT ring re-requests of this unit
+                    if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(p.dbg & DBG_NO_MFMA)); }
+                    if constexpr (POLY)
+                        ws_epilogue_poly<MW, NW, EPI, S, 0>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
+                    else if constexpr (DEC2)
+                        ws_epilogue_dec2<MW, NW>(p, R, acc2, sig, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
+                    else
+                        ws_epilogue_kind<MW, NW, EPI, EST, 0>(p, R, acc, s1, s2, sig, mg,
+                                                              (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
+                    if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
                             float a1 = s1[m], a2 = s2[m];
@@ -390,11 +575,13 @@ void conv_hx_direct_kernel(const ConvParams p0) {
                         }
                     }
                 }
+                stamp(8);
                 __syncthreads();                       // end of unit u
+                stamp(6);
             }
         }
     }
-    if (flags & F_STATS) {                             // one f64 global atomic per channel per workgroup
+    if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {   // one f64 global atomic per channel per workgroup
         __syncthreads();
         for (int i = tid; i < 2 * 16 * MW * WM; i += 512) {
             const int co = blockIdx.y * (WM * MW * 16) + (i >> 1);
@@ -414,39 +601,87 @@ static hipError_t hx_launch_instance(dim3 grid, size_t smem, hipStream_t stream,
     return hipGetLastError();
 }
 
-template <int MW, int NW, int WM, int WN>
-static hipError_t hx_launch_direct(const ConvParams& p, int nsig, hipStream_t stream) {
+template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S>
+static hipError_t hx_launch_kind(dim3 grid, size_t smem, hipStream_t stream, const ConvParams& p) {
+    // the ring holds the whole layer when there is a single K chunk: nothing to re-request (MW = 2 layers: C_in <= 32)
+    if constexpr (MW == 2) {
+        if (p.nch32 == 1) return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, true>>(grid, smem, stream, p);
+    }
+    return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, false>>(grid, smem, stream, p);
+}
+
+template <int MW, int NW, int WM, int WN, int MODE>
+static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t stream) {
     constexpr int NT = 16 * NW * WN;
     const int ntx = (p.T + NT - 1) / NT;
     const int tpw = p.tpw > 0 ? p.tpw : 1;
     dim3 grid((ntx + tpw - 1) / tpw, (p.ngroups + WM - 1) / WM, nsig * p.B);
-    const int halo_al = (p.dil + 3) & ~3;
+    const int halo_al = MODE == MODE_DIRECT ? ((p.dil + 3) & ~3) : 4;
     const int W = NT + 2 * halo_al;
-    const int nbuf = (p.nch32 > 1 || tpw > 1) ? 2 : 1;
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM + sizeof(float) * 2 * (size_t)p.nch32 * HX_KC +
-                        (size_t)nbuf * HX_NP * W * HX_ROW;
+                        (size_t)2 * (MODE == MODE_DEC2 ? 2 : 1) * HX_NP * (W + 4) * HX_ROW;
     const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
-    const int kind = aff ? EPI_AFF : p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
-    const bool wstatic = p.nch32 == 1;                 // the ring holds the whole layer: nothing to re-request
-#define FASTSVC_HX(k) \
-    if (kind == k) return wstatic ? hx_launch_instance<&conv_hx_direct_kernel<MW, NW, WM, WN, k, true>>(grid, smem, stream, p) \
-                                  : hx_launch_instance<&conv_hx_direct_kernel<MW, NW, WM, WN, k, false>>(grid, smem, stream, p);
-    FASTSVC_HX(EPI_PLAIN) FASTSVC_HX(EPI_RES) FASTSVC_HX(EPI_RANK1) FASTSVC_HX(EPI_AFF)
+    if constexpr (MODE == MODE_DEC2) {
+        return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 1>(grid, smem, stream, p);
+    } else if constexpr (MODE == MODE_POLY) {
+#define FASTSVC_HXP(sv) \
+        if (p.s == sv) return aff ? hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_AFF, sv>(grid, smem, stream, p) \
+                                  : hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_PLAIN, sv>(grid, smem, stream, p);
+        FASTSVC_HXP(2) FASTSVC_HXP(4) FASTSVC_HXP(5)
+#undef FASTSVC_HXP
+        return hipErrorInvalidValue;
+    } else {
+        const int kind = aff ? EPI_AFF : p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
+        size_t est = 0;
+        if ((kind == EPI_AFF && hx_estage<MW, NW, MODE_DIRECT, EPI_AFF>()) || (kind == EPI_RES && hx_estage<MW, NW, MODE_DIRECT, EPI_RES>()))
+            est = sizeof(float) * 4 * (size_t)(aff ? (p.res ? 3 : 2) : 1) * MW * NW * EST_ITEM_FLOATS;
+#define FASTSVC_HX(k) if (kind == k) return hx_launch_kind<MW, NW, WM, WN, MODE_DIRECT, k, 1>(grid, smem + est, stream, p);
+        FASTSVC_HX(EPI_PLAIN) FASTSVC_HX(EPI_RES) FASTSVC_HX(EPI_RANK1) FASTSVC_HX(EPI_AFF)
 #undef FASTSVC_HX
-    return hipErrorInvalidValue;
+        return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream) {
-    if (p.mode != MODE_DIRECT || p.ntaps != 3 || p.dil < 1 || p.dil > 28 || (p.T & 3) || !p.whx) return hipErrorInvalidValue;
-#define FASTSVC_HXS(mw, nw, wm, wn) \
-    if (cfg.MW == mw && cfg.NW == nw && cfg.WM == wm && cfg.WN == wn) return hx_launch_direct<mw, nw, wm, wn>(p, cfg.nsig, stream);
-    FASTSVC_HXS(2, 2, 1, 4) FASTSVC_HXS(2, 4, 1, 4)
-    FASTSVC_HXS(3, 2, 1, 4) FASTSVC_HXS(3, 4, 1, 4)
-    FASTSVC_HXS(3, 2, 2, 2) FASTSVC_HXS(3, 4, 2, 2)
-    FASTSVC_HXS(3, 4, 4, 1)
+    if (p.ntaps != 3 || (p.T & 3) || !p.whx) return hipErrorInvalidValue;
+#define FASTSVC_HXS(md, mw, nw, wm, wn) \
+    if (cfg.MW == mw && cfg.NW == nw && cfg.WM == wm && cfg.WN == wn) \
+        return hx_launch_shape<mw, nw, wm, wn, md>(p, cfg.nsig, stream);
+    if (p.mode == MODE_DIRECT) {
+        if (p.dil < 1 || p.dil > 28) return hipErrorInvalidValue;
+        // workgroup tiles of 128 or 192 output columns: with the halo (<= 2 x 28) the window stays within 256 rows
+        // = one item per producer thread
+        FASTSVC_HXS(MODE_DIRECT, 2, 2, 1, 4) FASTSVC_HXS(MODE_DIRECT, 2, 3, 1, 4)
+        FASTSVC_HXS(MODE_DIRECT, 3, 2, 1, 4) FASTSVC_HXS(MODE_DIRECT, 3, 3, 1, 4)
+        FASTSVC_HXS(MODE_DIRECT, 3, 4, 2, 2) FASTSVC_HXS(MODE_DIRECT, 3, 6, 2, 2)
+        FASTSVC_HXS(MODE_DIRECT, 3, 8, 4, 1)
+    } else if (p.mode == MODE_POLY) {
+        if (p.dil != 1) return hipErrorInvalidValue;
+        FASTSVC_HXS(MODE_POLY, 2, 2, 1, 4) FASTSVC_HXS(MODE_POLY, 2, 3, 1, 4)
+        FASTSVC_HXS(MODE_POLY, 3, 2, 1, 4) FASTSVC_HXS(MODE_POLY, 3, 2, 2, 2)
+    } else if (p.mode == MODE_DEC2) {
+        if (p.dil != 1 || !p.bias2 || !p.y2) return hipErrorInvalidValue;
+        FASTSVC_HXS(MODE_DEC2, 3, 2, 1, 4) FASTSVC_HXS(MODE_DEC2, 3, 3, 1, 4) FASTSVC_HXS(MODE_DEC2, 3, 2, 2, 2)
+    }
 #undef FASTSVC_HXS
     return hipErrorInvalidValue;
 }
+
+#ifndef FASTSVC_ACT_BF16      // storage-independent host query: defined once
+bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN) {
+    if (mode == MODE_POLY)
+        return (MW == 2 && WM == 1 && WN == 4 && (NW == 2 || NW == 3)) ||
+               (MW == 3 && NW == 2 && ((WM == 1 && WN == 4) || (WM == 2 && WN == 2)));
+    if (mode == MODE_DEC2)
+        return MW == 3 && ((WM == 1 && WN == 4 && (NW == 2 || NW == 3)) || (WM == 2 && WN == 2 && NW == 2));
+    if (mode != MODE_DIRECT) return false;
+    if (MW == 2) return WM == 1 && WN == 4 && (NW == 2 || NW == 3);
+    if (MW != 3) return false;
+    if (WM == 1 && WN == 4) return NW == 2 || NW == 3;
+    if (WM == 2 && WN == 2) return NW == 4 || NW == 6;
+    return WM == 4 && WN == 1 && NW == 8;
+}
+#endif
 
 #ifdef FASTSVC_ACT_BF16
 }  // namespace bf16

@@ -61,6 +61,12 @@ struct ConvParams {
     const float* bias;
     long bias_sig;
     int Q;                       // k-steps per 16*MW-row group = ntaps * nchunks * KC / 4
+    // half-precision-MFMA kernels (fastsvc_hx.hip): pre-split weight fragments
+    // [group of 16*MW channels][32-channel chunk][tap][16-channel tile][hi, lo][lane][8 halves]
+    const void* whx;
+    long whx_sig;                // lft -> sine stride in BYTES (paired convs)
+    int nch32;                   // 32-channel K chunks = ceil(CIN / 32)
+    int stagger;                 // start delay (x 1024 cycles) of the second workgroup of a CU (two-per-CU variants)
     int ngroups;                 // number of 16*MW-row groups
     // destination (nsig, B, COUT, T); y may be null when only the FiLM-affine output y2 is needed
     float* y;
@@ -131,6 +137,13 @@ bool conv_ws_tail_ok(int MW, int NW, int mode, int epi_kind, int S);
 // generic k in {1,3} dilated conv, MFMA f32 16x16x4
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 
+// the same convolutions on the 16x16x32 half-precision MFMA (fastsvc_hx.hip): float32 storage = split-half
+// (hi + lo binary16 pieces, three products, fp32-class), bfloat16 storage = one bf16 product.  Needs
+// p.whx / p.nch32, rows that are a multiple of 4 long; cfg.pipe is ignored.
+hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
+// whether launch_conv_hx is compiled for this mode / shape
+bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN);
+
 // down-sampling stage 0, first conv (C_in = 1, k = 3, d = 1, LeakyReLU on the input):
 //   y[sig][b][co][t] = bias[co] + sum_tap w[co][tap] * lrelu(x[sig][b][t + tap - 1])
 //   lens / len_mul: ragged batches (valid length of utterance b = lens[b] * len_mul, rows keep pitch T)
@@ -156,6 +169,7 @@ hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks
 // stay in elements); weights, biases, the raw signals (r1x), statistics and speaker biases stay float32.
 namespace bf16 {
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
+hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, long w_sig, long b_sig,
                            float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream);
 hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -62,6 +63,14 @@ struct PackedConv {
     bool dec2 = false;
     size_t b2_off = 0;
     long b2_pair = 0;
+    // half-precision-MFMA kernels (fastsvc_hx.hip): pre-split fragments [group][32-channel chunk][tap]
+    // [16-channel tile][piece][lane][8 halves]; index 0 = binary16 hi + lo pieces (float32 storage),
+    // 1 = bfloat16 (bfloat16 storage).  Offsets in floats, pair strides (lft -> sine) in bytes.
+    bool hx = false;
+    int nch32 = 0;
+    size_t hx_off[2] = {0, 0};
+    long hx_pair[2] = {0, 0};
+    size_t hxp_off[2] = {0, 0};       // the polyphase taps W0 | W0+W1+W2 | W2 in the same format (stretch convs)
 };
 
 // Source description used by the packer: virtual weight W[co][ci][tap] assembled from up to four
@@ -96,6 +105,53 @@ struct UpStage {
 };
 
 struct BufferSpec { std::string name; size_t off_bytes; int64_t numel; int64_t shape[3]; };
+
+// IEEE binary16 / bfloat16 conversions (round to nearest even), host side of the split-half weights;
+// pinned against numpy in tests/test_boundary.py
+uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
+    if (x >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);                // >= 65536: inf
+    if (x < 0x38800000u) {                                                  // below 2^-14: subnormal, n * 2^-24
+        float a;
+        std::memcpy(&a, &x, 4);
+        return (uint16_t)(sign | (uint32_t)std::lrintf(a * 16777216.0f));   // lrintf: nearest even
+    }
+    const uint32_t mant = x & 0x7fffffu;
+    uint32_t h = (((x >> 23) - 112u) << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;                 // a carry walks into the exponent (65520 -> inf)
+    return (uint16_t)(sign | h);
+}
+
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    float out;
+    if (e == 0) {
+        out = std::ldexp((float)m, -24);
+    } else if (e == 31) {
+        const uint32_t x = 0x7f800000u | (m << 13);
+        std::memcpy(&out, &x, 4);
+    } else {
+        const uint32_t x = ((e + 112u) << 23) | (m << 13);
+        std::memcpy(&out, &x, 4);
+    }
+    uint32_t x;
+    std::memcpy(&x, &out, 4);
+    x |= sign;
+    std::memcpy(&out, &x, 4);
+    return out;
+}
+
+uint16_t f32_to_bf16(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40u);
+    return (uint16_t)((x + 0x7fffu + ((x >> 16) & 1u)) >> 16);
+}
 
 int choose_mw(int cout) {
     if (cout % 48 == 0) return 3;
@@ -162,6 +218,14 @@ struct fastsvc_plan {
                 c[i].ww2_off = alloc((size_t)(cout / 32) * c[i].Qw * 64 * 2);
             }
         if (npair == 2 && c[0].wino2) c[0].ww2_pair = (long)(c[1].ww2_off - c[0].ww2_off);
+        if (ntaps == 3 && c[0].MW >= 2) {
+            for (int i = 0; i < npair; ++i) { c[i].hx = true; c[i].nch32 = (cin + 31) / 32; }
+            for (int prec = 0; prec < 2; ++prec) {
+                const size_t fl = (size_t)c[0].ngroups * c[0].nch32 * 3 * c[0].MW * (prec == 0 ? 2 : 1) * 256;   // 1 KB fragments
+                for (int i = 0; i < npair; ++i) c[i].hx_off[prec] = alloc(fl);
+                if (npair == 2) c[0].hx_pair[prec] = (long)(c[1].hx_off[prec] - c[0].hx_off[prec]) * 4;
+            }
+        }
         for (int i = 0; i < npair; ++i) pack_jobs.emplace_back(&c[i], src[i]);
     }
 
@@ -180,6 +244,14 @@ struct fastsvc_plan {
         for (int i = 0; i < 2; ++i) c[i].b_off = alloc(c[i].b_floats);
         for (int i = 0; i < 2; ++i) c[i].b2_off = alloc(c[i].b_floats);
         c[0].b2_pair = (long)(c[1].b2_off - c[0].b2_off);
+        if (c[0].MW == 3) {                                  // four slots per chunk: w0 w1 w2 | w1x1
+            for (int i = 0; i < 2; ++i) { c[i].hx = true; c[i].nch32 = (cin + 31) / 32; }
+            for (int prec = 0; prec < 2; ++prec) {
+                const size_t fl = (size_t)c[0].ngroups * c[0].nch32 * 4 * c[0].MW * (prec == 0 ? 2 : 1) * 256;
+                for (int i = 0; i < 2; ++i) c[i].hx_off[prec] = alloc(fl);
+                c[0].hx_pair[prec] = (long)(c[1].hx_off[prec] - c[0].hx_off[prec]) * 4;
+            }
+        }
         for (int i = 0; i < 2; ++i) {
             PackSource src;
             src.dec2 = true;
@@ -269,6 +341,9 @@ int build_plan(fastsvc_plan& P) {
             if (pc->KC == 24 && (u.scale == 2 || u.scale == 4 || u.scale == 5)) {
                 pc->poly = true;
                 pc->wp_off = P.alloc(pc->w_floats);
+                if (pc->hx)
+                    for (int prec = 0; prec < 2; ++prec)
+                        pc->hxp_off[prec] = P.alloc((size_t)pc->ngroups * pc->nch32 * 3 * pc->MW * (prec == 0 ? 2 : 1) * 256);
             }
         }
         P.add_conv(&u.d3, 1, u.C, u.C, 3, 3, {single(p + ".conv_block1.1")});
@@ -368,6 +443,34 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
     float* blob = static_cast<float*>(host_blob);
     std::memset(blob, 0, plan->blob_floats * sizeof(float));
 
+    // split-half / bf16 fragments (fastsvc_hx.hip): lane l of fragment (group, chunk, slot, tile m) holds
+    // Wt[co = (group*MW + m)*16 + (l & 15)][ci = chunk*32 + 8*(l >> 4) + e][slot], e = 0..7
+    auto pack_hx = [&](const PackedConv& c, const size_t (&off)[2], int nslots,
+                       const std::function<float(int, int, int)>& wt) {
+        for (int prec = 0; prec < 2; ++prec) {
+            const int np = prec == 0 ? 2 : 1;
+            uint16_t* hp = reinterpret_cast<uint16_t*>(blob + off[prec]);
+            for (int grp = 0; grp < c.ngroups; ++grp)
+                for (int ch = 0; ch < c.nch32; ++ch)
+                    for (int slot = 0; slot < nslots; ++slot)
+                        for (int m = 0; m < c.MW; ++m) {
+                            uint16_t* frag = hp + ((((size_t)grp * c.nch32 + ch) * nslots + slot) * c.MW + m) * np * 512;
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int co = (grp * c.MW + m) * 16 + (lane & 15);
+                                    const int ci = ch * 32 + 8 * (lane >> 4) + e;
+                                    const float v = (co < c.cout && ci < c.cin) ? wt(co, ci, slot) : 0.f;
+                                    if (prec == 0) {
+                                        const uint16_t hi = f32_to_f16(v);
+                                        frag[lane * 8 + e] = hi;
+                                        frag[512 + lane * 8 + e] = f32_to_f16(v - f16_to_f32(hi));
+                                    } else {
+                                        frag[lane * 8 + e] = f32_to_bf16(v);
+                                    }
+                                }
+                        }
+        }
+    };
     for (const auto& job : plan->pack_jobs) {
         const PackedConv& c = *job.first;
         const PackSource& src = job.second;
@@ -398,6 +501,10 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                                 }
                             }
             for (int co = 0; co < c.cout; ++co) { blob[c.b_off + co] = L3.b[co]; blob[c.b2_off + co] = L1.b[co]; }
+            if (c.hx)
+                pack_hx(c, c.hx_off, 4, [&](int co, int ci, int slot) {
+                    return slot < 3 ? L3.w[((size_t)co * c.cin + ci) * 3 + slot] : L1.w[(size_t)co * c.cin + ci];
+                });
             continue;
         }
         // virtual dense weight W[co][ci][tap] and bias
@@ -441,6 +548,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                         }
         };
         pack_fragments(W, blob + c.w_off, c.ntaps);
+        if (c.hx) pack_hx(c, c.hx_off, 3, [&](int co, int ci, int tap) { return W[((size_t)co * c.cin + ci) * 3 + tap]; });
         if (c.wino) {
             // Winograd F(2,3) weight transform G w (fastsvc_kernels.h, MODE_WINO), in f64
             std::vector<float> Ww((size_t)c.cout * c.cin * 4);
@@ -483,6 +591,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                 Wp[i + 2] = W[i + 2];
             }
             pack_fragments(Wp, blob + c.wp_off, c.ntaps);
+            if (c.hx) pack_hx(c, c.hxp_off, 3, [&](int co, int ci, int tap) { return Wp[((size_t)co * c.cin + ci) * 3 + tap]; });
         }
         float* bp = blob + c.b_off;
         for (int co = 0; co < c.cout; ++co) bp[co] = bias[co];
@@ -661,6 +770,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
     p.w = blob + c.w_off; p.w_sig = pair_w_stride;
     const bool act_bf16 = g_tune.plan && g_tune.plan->storage == 1;
     auto launch = [&](const ConvParams& q, const ConvLaunch& Lq, hipStream_t st) {
+        if (Lq.pipe == 2) return act_bf16 ? bf16::launch_conv_hx(q, Lq, st) : launch_conv_hx(q, Lq, st);
         return act_bf16 ? bf16::launch_conv(q, Lq, st) : launch_conv(q, Lq, st);
     };
     static const bool no_poly = std::getenv("FASTSVC_NO_POLY") != nullptr;   // A/B switch
@@ -703,7 +813,9 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
             epi_kind = aff ? 4 : ((p.mode == MODE_STRETCH || poly) ? 1 : p.r1x ? 3 : p.res ? 2 : 1);
         }
-        struct Cand { int NW, WM, WN, algo; };       // algo 0: as launched, 1: Winograd (MW of the layer), 2: Winograd MW = 2
+        // algo 0: as launched, 1: Winograd (MW of the layer), 2: Winograd MW = 2, 3: half-precision MFMA (fastsvc_hx.hip)
+        struct Cand { int NW, WM, WN, algo; };
+        auto is_wino = [](int algo) { return algo == 1 || algo == 2; };
         std::vector<Cand> cands;
         if (poly) {
             if (c.MW == 3 && c.ngroups % 2 == 0) cands = {{1, 2, 2}, {1, 1, 4}};
@@ -733,12 +845,28 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 if (ng2 % 4 == 0) cands.push_back(Cand{1, 4, 1, 2});
             }
         }
+        // Half-precision MFMA variants (split-half f16 products in float32 storage, bf16 products in bfloat16
+        // storage): FASTSVC_HX=0 switches them off (A/B), they need rows that are a multiple of 4 long
+        static const int hx_env = std::getenv("FASTSVC_HX") ? std::atoi(std::getenv("FASTSVC_HX")) : 1;
+        const bool hx_mode = (p.mode == MODE_DIRECT && p.x_T == p.T) || (p.mode == MODE_POLY && c.hxp_off[0]) ||
+                             (p.mode == MODE_DEC2 && (p.x_T & 3) == 0);
+        const bool hx_ok = hx_env != 0 && c.hx && hx_mode && c.ntaps == 3 && (p.T & 3) == 0 &&
+                           c.dil <= 28 && !(p.flags & F_PRE_AFFINE) &&
+                           (!p.lens || ((p.len_mul & 3) == 0 && (p.xlen_mul & 3) == 0));
+        if (hx_ok) {
+            static const int shapes[][3] = {{8, 4, 1}, {6, 2, 2}, {4, 2, 2}, {2, 2, 2}, {3, 1, 4}, {2, 1, 4}};
+            for (const auto& sh : shapes)
+                if (conv_hx_shape(p.mode, c.MW, sh[0], sh[1], sh[2]) && c.ngroups % sh[1] == 0 &&
+                    !(p.mode == MODE_DIRECT && epi_kind >= 3 && sh[0] * c.MW > 12))   // FiLM-affine / rank-1 epilogues: those tiles spill
+                    cands.push_back(Cand{sh[0], sh[1], sh[2], 3});
+        }
         if ((p.T & 3) != 0 || (p.lens && (p.len_mul & 3) != 0)) {
             // rows that are not a multiple of 4 long (with a ragged batch: ANY utterance's own length,
             // whatever the padded maximum is): only the variants compiled with the row-end handling
             std::vector<Cand> keep;
             for (const Cand& cd : cands)
-                if (conv_ws_tail_ok(cd.algo == 2 ? 2 : c.MW, cd.NW, cd.algo >= 1 ? (int)MODE_WINO : p.mode, epi_kind,
+                if (cd.algo != 3 &&
+                    conv_ws_tail_ok(cd.algo == 2 ? 2 : c.MW, cd.NW, is_wino(cd.algo) ? (int)MODE_WINO : p.mode, epi_kind,
                                     poly ? p.s : 1)) keep.push_back(cd);
             if (!keep.empty()) cands.swap(keep);       // (never empty: NW <= 2 variants always have it)
         }
@@ -746,7 +874,13 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         // LDS geometry of a candidate: row stride (== 16 mod 32) and, for Winograd, the phase-plane
         // stride that keeps the component reads conflict-free (planes land 16/D banks apart)
         auto geometry = [&](const Cand& cd, ConvParams& q) {
-            if (cd.algo >= 1) {
+            if (cd.algo == 3) {
+                const int prec = act_bf16 ? 1 : 0;
+                q.whx = blob + (p.mode == MODE_POLY ? c.hxp_off[prec] : c.hx_off[prec]); q.whx_sig = c.hx_pair[prec]; q.nch32 = c.nch32;
+                static const int stagger = std::getenv("FASTSVC_STAGGER") ? std::atoi(std::getenv("FASTSVC_STAGGER")) : 2;
+                q.stagger = stagger;
+                q.xs = 0; q.ps = 0;
+            } else if (cd.algo >= 1) {
                 const int NTo = 32 * cd.NW * cd.WN, D = c.dil;
                 const int Q = (NTo + 16) / (2 * D);
                 const int ps = D == 1 ? (Q + 1) / 2 * 2 : D == 2 ? round_to(Q, 8, 32) : round_to(Q, 12, 32);
@@ -773,7 +907,8 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 // a loaded table may be stale: only shapes this launch is compiled for are taken
                 for (const Cand& cd : cands)
                     if (cd.NW == it->second.NW && cd.WM == it->second.WM && cd.WN == it->second.WN &&
-                        cd.algo == it->second.algo && it->second.tpw >= 1 && it->second.tpw <= 64) {
+                        cd.algo == it->second.algo && it->second.tpw >= 1 && it->second.tpw <= 64 &&
+                        !(hx_env == 2 && hx_ok && cd.algo != 3)) {        // FASTSVC_HX=2: older tables do not hold it back
                         best = cd; p.tpw = it->second.tpw;
                         have = true;
                     }
@@ -790,13 +925,13 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             ConvParams q = p;
             q.flags &= ~F_STATS;
             for (const Cand& cd : cands) {
-                const int NT = (cd.algo >= 1 ? 32 : 16) * cd.NW * cd.WN;
+                const int NT = (is_wino(cd.algo) ? 32 : 16) * cd.NW * cd.WN;
                 const long ntx = (p.T + NT - 1) / NT;
                 q = p; q.flags &= ~F_STATS;
                 geometry(cd, q);
                 for (int tpw : tpws) {
                     q.tpw = tpw;
-                    ConvLaunch Lq{cd.algo == 2 ? 2 : c.MW, cd.NW, cd.WM, cd.WN, nsig, 1};
+                    ConvLaunch Lq{cd.algo == 2 ? 2 : c.MW, cd.NW, cd.WM, cd.WN, nsig, cd.algo == 3 ? 2 : 1};
                     hipError_t e = launch(q, Lq, stream);                 // warm
                     if (e != hipSuccess) return e;
                     hipEventRecord(e0, stream);
@@ -829,6 +964,29 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             // Winograd variant loses to the scalar phase-plane staging.  FASTSVC_WINO = 0 / 1 / 2
             // forces direct / layer grouping / 32-channel grouping.
             const int wino_pref = wino_env >= 0 ? wino_env : (c.MW == 2 ? 0 : 2);
+            if (hx_ok != (cd.algo == 3)) continue;          // the half-precision MFMA variant wherever the layer has one
+            if (cd.algo == 3) {
+                // data-movement model: one workgroup per CU; a unit moves its window in and (per tile) its
+                // outputs; the matrix work (3 taps x NW x MW x 1|3 products of 16 cycles) hides under it
+                const int NT = 16 * cd.NW * cd.WN;
+                const long ntx = (p.T + NT - 1) / NT;
+                const long gy = c.ngroups / cd.WM;
+                const double win = NT + 2.0 * ((halo + 3) & ~3);
+                const double esz = act_bf16 ? 2.0 : 4.0;
+                const double out_streams = (p.y ? 1 : 0) + ((p.flags & F_AFF_OUT) ? 3 : 0) + (p.res ? 1 : 0);
+                const double bytes_unit = 32.0 * win * esz + 16.0 * c.MW * cd.WM * NT * (poly ? p.s : 1) * esz *
+                                          (out_streams + (p.mode == MODE_DEC2 ? 1 : 0)) / c.nch32;
+                const double mem_us = bytes_unit / (4.5e6 / 256.0);
+                const double mfma_us = (poly ? 5.0 : p.mode == MODE_DEC2 ? 4.0 : 3.0) * cd.NW * c.MW * (act_bf16 ? 1 : 3) * 17.0 / 2.0e3;
+                const double unit_us = mem_us > mfma_us ? mem_us : mfma_us;
+                for (int tpw = 1; tpw <= 16; ++tpw) {
+                    const long wgs = ((ntx + tpw - 1) / tpw) * gy * zb;
+                    const long rounds = (wgs + 255) / 256;
+                    const double t = rounds * (startup_us + tpw * c.nch32 * unit_us);
+                    if (t < best_t * 0.999) { best_t = t; best = cd; p.tpw = tpw; }
+                }
+                continue;
+            }
             if ((cd.algo >= 1) != (wino_ok && wino_pref >= 1)) continue;
             if (wino_pref >= 1 && wino_ok && c.wino2 && (cd.algo == 2) != (wino_pref == 2)) continue;
             const int NT = (cd.algo >= 1 ? 32 : 16) * cd.NW * cd.WN;
@@ -858,7 +1016,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             }
         }
         }
-        L.pipe = 1;
+        L.pipe = best.algo == 3 ? 2 : 1;
         L.NW = best.NW; L.WM = best.WM; L.WN = best.WN;
         if (best.algo == 2) L.MW = 2;
         geometry(best, p);
@@ -891,7 +1049,12 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (p.flags & (F_STATS | F_AFF_OUT)) el += 2.0 * c.cout * T_out;
         const double bytes = (act_bf16 ? 2.0 : 4.0) * el * p.B * nsig + 4.0 * (double)(c.w_floats + c.b_floats) * nsig;
         char kname[40];
-        if (L.pipe)
+        if (L.pipe == 2) {
+            const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+            const int kind = aff ? 4 : p.r1x ? 3 : p.res ? 2 : 1;
+            std::snprintf(kname, sizeof(kname), "conv_hx<%d,%d,%d,%d,%d,%d,%d,%s>", L.MW, L.NW, L.WM, L.WN, p.mode,
+                          p.mode == MODE_DEC2 ? 1 : poly ? (aff ? 4 : 1) : kind, poly ? p.s : 1, act_bf16 ? "x1" : "x3");
+        } else if (L.pipe)
         {
             // same rule as launch_conv_pipe: compile-time epilogue kind of the 3-tap DIRECT / STRETCH launches
             int kind = 0;
@@ -1262,6 +1425,15 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                                  P.cfg.out_channels, (int)T, lengths, (int)hop, stream));
     if (prof) HIP_TRY(prof->end());
     return FASTSVC_OK;
+}
+
+void fastsvc_split_half(const float* x, int64_t n, uint16_t* f16_hi, uint16_t* f16_lo, uint16_t* bf16) {
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t hi = f32_to_f16(x[i]);
+        if (f16_hi) f16_hi[i] = hi;
+        if (f16_lo) f16_lo[i] = f32_to_f16(x[i] - f16_to_f32(hi));
+        if (bf16) bf16[i] = f32_to_bf16(x[i]);
+    }
 }
 
 int fastsvc_stream_prepare(void* stream) {

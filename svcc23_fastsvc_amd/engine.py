@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "fastsvc_forward", "fastsvc_autotune", "fastsvc_tuned_count", "fastsvc_tuned_get", "fastsvc_tuned_set",
     "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
     "fastsvc_flops_per_sample", "fastsvc_signal_scratch_bytes", "fastsvc_signal_generate",
-    "fastsvc_stream_prepare",
+    "fastsvc_stream_prepare", "fastsvc_split_half",
 )
 
 
@@ -96,6 +96,8 @@ def load_library():
     lib.fastsvc_workspace_bytes.restype = sz
     lib.fastsvc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.fastsvc_forward.restype = ctypes.c_int
+    lib.fastsvc_split_half.argtypes = [vp, i64, vp, vp, vp]
+    lib.fastsvc_split_half.restype = None
     lib.fastsvc_stream_prepare.argtypes = [vp]
     lib.fastsvc_stream_prepare.restype = ctypes.c_int
     lib.fastsvc_autotune.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, ctypes.POINTER(i32)]
@@ -210,8 +212,15 @@ class Plan:
 
     @property
     def arithmetic(self) -> str:
-        """The type the path computes in, for bench.py's `dtype`."""
-        return "f32" if self.storage == "float32" else "f32 arithmetic, bf16 activation storage"
+        """The type the path computes in, for bench.py's `dtype` (FASTSVC_HX=0 selects the f32-input MFMA kernels
+        everywhere; by default every k=3 convolution whose rows are a multiple of 4 long runs on the
+        half-precision MFMA kernels of csrc/fastsvc_hx.hip)."""
+        hx = os.environ.get("FASTSVC_HX", "1") != "0"
+        if self.storage == "float32":
+            return ("f32 (conv products as exact split-binary16 pairs on the f16 MFMA, x*w = xh*wh + xh*wl + xl*wh, "
+                    "f32 accumulate: fp32-class, 4e-6 of the f32-MFMA path)") if hx else "f32"
+        return ("bf16 (bf16 MFMA products, f32 accumulate, bf16 activation storage)" if hx
+                else "f32 arithmetic, bf16 activation storage")
 
     @property
     def blob_bytes(self) -> int:

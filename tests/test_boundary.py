@@ -67,6 +67,29 @@ def _unpack_conv(blob, w_off, cout, cin, ntaps, MW, KC):
     return W
 
 
+def _unpack_hx(blob, off_floats, cout, cin, MW, prec):
+    """Inverse of the split-half / bf16 fragment order (fastsvc_plan.cpp, fastsvc_hx.hip): returns
+    W[co][ci][tap] as float64 = hi + lo (prec 0, binary16 pieces) or the bf16 value (prec 1)."""
+    np_ = 2 if prec == 0 else 1
+    nch = (cin + 31) // 32
+    ngroups = (cout + 16 * MW - 1) // (16 * MW)
+    halves = blob[off_floats: off_floats + ngroups * nch * 3 * MW * np_ * 256].view(np.uint16)
+    W = np.zeros((cout, cin, 3))
+    for co in range(cout):
+        grp, m, l15 = co // (16 * MW), (co % (16 * MW)) // 16, co % 16
+        for ci in range(cin):
+            ch, lhi, e = ci // 32, (ci % 32) // 8, ci % 8
+            for tap in range(3):
+                frag = ((((grp * nch + ch) * 3 + tap) * MW + m) * np_) * 512
+                lane = lhi * 16 + l15
+                if prec == 0:
+                    W[co, ci, tap] = float(halves[frag + lane * 8 + e: frag + lane * 8 + e + 1].view(np.float16)[0]) + \
+                                     float(halves[frag + 512 + lane * 8 + e: frag + 512 + lane * 8 + e + 1].view(np.float16)[0])
+                else:
+                    W[co, ci, tap] = float((halves[frag + lane * 8 + e: frag + lane * 8 + e + 1].astype(np.uint32) << 16).view(np.float32)[0])
+    return W
+
+
 def test_pack_first_layer_fragment_order_and_fold():
     """The first allocation in the blob is down stage 0's raw 1x1 pair, then raw c1 pair, then the
     packed c2 pair: check the packed c2 (24->24, MW=2, KC=24) of the lft chain against the folded
@@ -84,9 +107,19 @@ def test_pack_first_layer_fragment_order_and_fold():
     off_c2 = off_c1 + 2 * 128 + 2 * 64
     W = _unpack_conv(blob, off_c2, 24, 24, 3, 2, 24)
     assert np.abs(W - folded["downsampling_lft.0.downsample_block.4.weight"]).max() <= 2e-7
-    # both key layouts pack to the same blob
+    # the same layer's split-half (binary16 hi + lo) and bfloat16 fragments: after the two plain copies, the two
+    # bias rows and the two Winograd copies of the pair
+    want = folded["downsampling_lft.0.downsample_block.4.weight"].astype(np.float64)
+    off_hx = off_c2 + 2 * 2304 + 2 * 64 + 2 * 3072
+    Wh = _unpack_hx(blob, off_hx, 24, 24, 2, 0)
+    assert np.abs(Wh - want).max() <= np.abs(want).max() * 2.0 ** -20
+    Wb = _unpack_hx(blob, off_hx + 2 * 3072, 24, 24, 2, 1)
+    assert np.abs(Wb - want).max() <= np.abs(want).max() * 2.0 ** -8 and np.abs(Wb - want).max() > 0
+    # both key layouts pack to the same blob (float sections compared as floats; the half-precision
+    # sections, where a last-bit difference of the fold moves a 16-bit pattern, through their decoded values)
     blob2 = plan.pack(folded).numpy()
-    assert np.abs(blob - blob2).max() <= 2e-7
+    assert np.abs(blob[:off_hx] - blob2[:off_hx]).max() <= 2e-7
+    assert np.abs(_unpack_hx(blob2, off_hx, 24, 24, 2, 0) - Wh).max() <= 2e-7
 
 
 def test_pack_is_strict():
@@ -330,3 +363,29 @@ def test_reference_load_model_and_decode_sequence_with_the_swapped_class(tmp_pat
         assert torch.allclose(plan.pack(model.state_dict()), plan.pack(torch.load(str(ckpt))["model"]["generator"]), atol=1e-6)
     finally:
         ref_models.FastSVCGenerator = original
+
+
+def test_split_half_conversions_match_numpy():
+    """The packer's binary16 / bfloat16 conversions (fastsvc_plan.cpp) against numpy / torch: normal range,
+    subnormals, ties, the overflow edge, and the split x = hi + lo holding 22 significand bits."""
+    lib = A.load_library()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        rng.standard_normal(4096).astype(np.float32) * np.float32(10.0) ** rng.integers(-8, 5, 4096).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e5, 6.1035156e-05, 6.0e-05, 5.9604645e-08,
+                  2.9802322e-08, 2.98e-08, 1.0009765625, 1.00048828125, 1.00146484375, 0.3, -0.1], dtype=np.float32)])
+    n = x.size
+    hi = np.zeros(n, np.uint16); lo = np.zeros(n, np.uint16); bf = np.zeros(n, np.uint16)
+    lib.fastsvc_split_half(x.ctypes.data, n, hi.ctypes.data, lo.ctypes.data, bf.ctypes.data)
+    with np.errstate(over="ignore"):
+        want_hi = x.astype(np.float16)
+        assert np.array_equal(hi, want_hi.view(np.uint16))
+        fin = np.isfinite(want_hi)
+        want_lo = (x[fin] - want_hi[fin].astype(np.float32)).astype(np.float16)
+    assert np.array_equal(lo[fin], want_lo.view(np.uint16))
+    want_bf = torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(bf, want_bf)
+    # the two pieces reproduce x to 2^-21 relative (or the subnormal step 2^-25 absolute)
+    mid = fin & (np.abs(x) < 6e4)
+    rec = hi.view(np.float16)[mid].astype(np.float64) + lo.view(np.float16)[mid].astype(np.float64)
+    assert np.all(np.abs(rec - x[mid]) <= np.maximum(np.abs(x[mid]) * 2.0 ** -21, 2.0 ** -25))

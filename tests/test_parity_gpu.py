@@ -360,8 +360,9 @@ def test_polyphase_stretch_convs_taps_and_fallback(dev, F, expect_poly):
     kern = {r["layer"]: r["kernel"] for r in recs}
     for i in range(cfg.n_stages):
         for layer in (f"up.{i}.res_stretch", f"up.{i}.up_stretch"):
-            k = kern[layer]              # conv_mfma_ws<MW,NW,WM,WN,mode,ntaps,kind> or the generic conv_mfma<..>
-            mode = int(k.split("<")[1].split(",")[4]) if k.startswith("conv_mfma_ws<") else 2
+            # conv_mfma_ws<MW,NW,WM,WN,mode,ntaps,kind,..> / conv_hx<MW,NW,WM,WN,mode,kind,S,x3> or the generic conv_mfma<..>
+            k = kern[layer]
+            mode = int(k.split("<")[1].split(",")[4]) if k.startswith(("conv_mfma_ws<", "conv_hx<")) else 2
             assert mode == (3 if expect_poly[i] else 2), (layer, k)
         for name in ("xr", "u1"):
             got = plan.tap(f"up.{i}.{name}", B, F, ws).cpu()
@@ -422,8 +423,8 @@ def test_winograd_time_convs_match_oracle_taps(dev, algo):
     # eligible: down.k c2/c3 and film.k conv/heads for k = 1..3, film.0.heads, conv_first of blocks
     # 0..2 = 16 launches.  The 48-channel ones (stage 1, film.0.heads, up.2.conv_first) have no
     # 32-channel grouping: for algo 2 their entries are ignored and the cost model picks for them
-    # (Winograd with the layer's own grouping), so 11 launches run with 32-channel groups (MW = 2).
-    assert n_wino == 16, sorted(kern.items())
+    # (the half-precision MFMA kernel, conv_hx), so 11 launches run Winograd with 32-channel groups (MW = 2).
+    assert n_wino == (16 if algo == 1 else 11), sorted(kern.items())
     n_mw2 = sum(1 for k in kern.values() if k.startswith("conv_mfma_ws<2,") and k.split(",")[4] == "4")
     assert n_mw2 == (0 if algo == 1 else 11), sorted(kern.items())
     ref, taps = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft,

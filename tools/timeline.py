@@ -53,6 +53,19 @@ def analyse(path, layer):
           f"p90 {int(np.percentile(span, 90))} cyc")
     cus = set(zip(xcc[ok, 0], se[ok, 0], sh[ok, 0], cu[ok, 0]))
     print(f"distinct (xcc, se, sh, cu) seen: {len(cus)}; simd of wave 0..7 in wg 0: {simd[0].tolist()}")
+    # residency: workgroups of one CU whose lives overlap (same XCD -> same s_memtime base)
+    by_cu = defaultdict(list)
+    for w in np.flatnonzero(ok):
+        by_cu[(int(xcc[w, 0]), int(se[w, 0]), int(sh[w, 0]), int(cu[w, 0]))].append((int(t_in[w]), int(last[w])))
+    peak = []
+    for spans in by_cu.values():
+        ev = sorted([(a, 1) for a, _ in spans] + [(b, -1) for _, b in spans])
+        cur = best = 0
+        for _, d in ev:
+            cur += d
+            best = max(best, cur)
+        peak.append(best)
+    print(f"workgroups resident together on one CU: max {max(peak)}, median {int(np.median(peak))}")
     # phase durations per role
     seg = defaultdict(list)
     for w in np.flatnonzero(ok)[:2048]:
@@ -87,10 +100,14 @@ def main():
     layers = sys.argv[2:] or ["up.3.d9"]
     cfg = S.FULL_CONFIG
     dev = torch.device("cuda:0")
-    plan = A.Plan(cfg)
+    storage = os.environ.get("FASTSVC_TIMELINE_STORAGE", "float32")
+    plan = A.Plan(cfg, storage=storage)
     blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
-    b = S.synth_batch(cfg, wl["B"], wl["F"], wl["seed"])
-    ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
+    if wl["B"] * wl["F"] > 20000:
+        ins = list(S.device_batch(cfg, wl["B"], wl["F"], wl["seed"], dev))
+    else:
+        b = S.synth_batch(cfg, wl["B"], wl["F"], wl["seed"])
+        ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
     ws = torch.empty(plan.workspace_bytes(wl["B"], wl["F"]), dtype=torch.uint8, device=dev)
     os.makedirs("gpurun_out", exist_ok=True)
     for _ in range(3):

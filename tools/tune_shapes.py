@@ -15,11 +15,11 @@ import svcc23_fastsvc_amd as A
 from svcc23_fastsvc_amd import synth as S
 from svcc23_fastsvc_amd.engine import TUNED_TABLE_PATH
 
-REPS = 3
+REPS = int(os.environ.get("TUNE_REPS", "3"))
 names = sys.argv[1:] or ["cfg1", "cfg2"]          # "cfg3:bf16" tunes the bfloat16-storage entries (keys end in "|b")
 cfg = S.FULL_CONFIG
 dev = torch.device("cuda:0")
-ROUNDS = 3          # independent tunings per workload; the table that runs the whole forward fastest is kept
+ROUNDS = int(os.environ.get("TUNE_ROUNDS", "3"))          # independent tunings per workload; the table that runs the whole forward fastest is kept
 sig = None
 table = {}
 
