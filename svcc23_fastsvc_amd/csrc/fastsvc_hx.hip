@@ -245,11 +245,189 @@ __device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int
     }
 }
 
+#ifdef FASTSVC_ACT_BF16
+// ---------------------------------------------------------------------------------------------------------
+// bfloat16 storage: 8-wide tile epilogue.  In the MFMA result layout a lane owns 4 consecutive time steps of
+// one channel = 8 BYTES of bf16, so every epilogue access of a wave was 16 rows x 32-byte segments (measured:
+// 4.2 TB/s for that shape against 5.8 TB/s for 16-byte lanes, tools/micro/rw_pattern.hip, and twice the
+// memory instructions).  Two neighbouring 16-column tiles are therefore re-laid through a wave-private LDS
+// patch so that a lane owns 8 consecutive time steps (16 B): lane (co = lane & 15, g = lane >> 4) of the pair
+// k holds columns 32 k + 8 g .. + 8.  Every load / store / LDS-DMA piece of the epilogue is then 16 B per lane.
+// ---------------------------------------------------------------------------------------------------------
+struct f32x8 { f32x4 lo, hi; };
+
+__device__ __forceinline__ f32x8 bf8_unpack(u32x4 w) {
+    f32x8 r;
+    r.lo = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                 __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+    r.hi = f32x4{__builtin_bit_cast(float, w.z << 16), __builtin_bit_cast(float, w.z & 0xffff0000u),
+                 __builtin_bit_cast(float, w.w << 16), __builtin_bit_cast(float, w.w & 0xffff0000u)};
+    return r;
+}
+__device__ __forceinline__ u32x4 bf8_pack(const f32x8& v) {
+    u32x4 w;
+    w.x = f32_to_bf16_bits(v.lo.x) | (f32_to_bf16_bits(v.lo.y) << 16);
+    w.y = f32_to_bf16_bits(v.lo.z) | (f32_to_bf16_bits(v.lo.w) << 16);
+    w.z = f32_to_bf16_bits(v.hi.x) | (f32_to_bf16_bits(v.hi.y) << 16);
+    w.w = f32_to_bf16_bits(v.hi.z) | (f32_to_bf16_bits(v.hi.w) << 16);
+    return w;
+}
+// boff: BYTE offset of the lane's first element inside the descriptor
+__device__ __forceinline__ f32x8 act_load8(__amdgpu_buffer_rsrc_t r, int boff, int soff) {
+    return bf8_unpack(__builtin_amdgcn_raw_buffer_load_b128(r, boff, soff, 0));
+}
+// nv: valid elements of the lane (0, 4 or 8 - rows are a multiple of 4 long)
+__device__ __forceinline__ void act_store8(__amdgpu_buffer_rsrc_t r, int boff, const f32x8& v, int nv) {
+    const u32x4 w = bf8_pack(v);
+    if (__builtin_amdgcn_ballot_w64(nv == 4) == 0) {           // wave-uniform: no half lane (nearly always)
+        __builtin_amdgcn_raw_buffer_store_b128(w, r, nv > 0 ? boff : OOB_OFF, 0, 0);
+    } else {
+        u32x2v a, b;
+        a.x = w.x; a.y = w.y; b.x = w.z; b.y = w.w;
+        __builtin_amdgcn_raw_buffer_store_b64(a, r, nv >= 4 ? boff : OOB_OFF, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(b, r, nv >= 8 ? boff + 8 : OOB_OFF, 0, 0);
+    }
+}
+__device__ __forceinline__ f32x8 keep8(f32x8 v, int nv) {
+    if (nv < 8) v.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nv < 4) v.lo = f32x4{0.f, 0.f, 0.f, 0.f};
+    return v;
+}
+constexpr int EST8_ITEM_BYTES = 1024;                       // one 16-byte LDS-DMA piece per lane
+
+// two neighbouring 16 x 16 result tiles of one channel tile -> pair layout, through the wave's LDS patch
+// Xw ([16][36] floats; LDS executes a wave's accesses in order, so the patch is reused tile pair after tile pair)
+__device__ __forceinline__ f32x8 hx_pair(const f32x4& a0, const f32x4& a1, float* Xw, int lane) {
+    constexpr int XS8 = 36;
+    float* row = Xw + (lane & 15) * XS8;
+    *reinterpret_cast<f32x4*>(row + (lane >> 4) * 4) = a0;
+    *reinterpret_cast<f32x4*>(row + 16 + (lane >> 4) * 4) = a1;
+    // lanes read what OTHER lanes of the wave wrote: per thread the addresses never overlap, so without a
+    // wave-level fence hipcc hoists the first read above the second write (seen in the ISA)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x8 out;
+    out.lo = *reinterpret_cast<const f32x4*>(row + (lane >> 4) * 8);
+    out.hi = *reinterpret_cast<const f32x4*>(row + (lane >> 4) * 8 + 4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return out;
+}
+
+// LDS-DMA pieces of the pair epilogue's operands (see ws_epilogue_stage): [scale, shift, residual][m][k][64 lanes] x 16 B
+template <int MW, int NP2, int EPI>
+__device__ __forceinline__ void hx_epilogue8_stage(const ConvParams& p, const EpiRsrc& R, const float* Ew, int mg, int tcol0, int lane) {
+    const int shift_soff = p.COUT * p.ldy * 2;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)Ew;
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const bool cok = cot < p.COUT;
+        const int rowoff = (cok ? cot : 0) * p.ldy;
+        #pragma unroll
+        for (int k = 0; k < NP2; ++k) {
+            const int t = tcol0 + k * 32 + (lane >> 4) * 8;
+            const int boff = (cok && t < p.T) ? (rowoff + t) * 2 : OOB_OFF;
+            const unsigned slot = base + (m * NP2 + k) * EST8_ITEM_BYTES;
+            if (EPI == EPI_RES) lds_dma16(R.res, slot, boff, 0);
+            if (EPI == EPI_AFF) {
+                lds_dma16(R.ss, slot, boff, 0);
+                lds_dma16(R.ss, slot + MW * NP2 * EST8_ITEM_BYTES, boff, shift_soff);
+                if (p.res) lds_dma16(R.res, slot + 2 * MW * NP2 * EST8_ITEM_BYTES, boff, 0);
+            }
+        }
+    }
+}
+
+template <int MW, int NP2, int EPI, bool EST, class KT>
+__device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[2 * NP2][MW],
+                                             float (&s1)[MW], float (&s2)[MW], int sig, int mg, int tcol0,
+                                             bool active, int lane, const KT& K, const float* Ew, float* Xw) {
+    if (!active) return;
+    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
+    const int shift_soff = p.COUT * p.ldy * 2;
+    const f32x8 zero8 = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const bool cok = cot < p.COUT;
+        const int co = cok ? cot : 0;
+        const float bias = K.bias(p, sig, m, cot);
+        float r1w = 0.f, r1b = 0.f;
+        if (EPI == EPI_RANK1) { r1w = K.r1w(p, sig, m, co); r1b = K.r1b(p, sig, m, co); }
+        const int rowoff = co * p.ldy;
+        // pairs whose loads fly together (register budget: 24 registers per pair with the FiLM operands)
+        constexpr int G = (EPI == EPI_AFF) ? 1 : (NP2 % 2 == 0 ? 2 : 1);
+        #pragma unroll
+        for (int k0 = 0; k0 < NP2; k0 += G) {
+            int boff[G], nv[G];
+            f32x8 l0[G], l1[G], l2[G];
+            #pragma unroll
+            for (int g = 0; g < G; ++g) {                          // every load of the group first
+                const int k = k0 + g;
+                const int t = tcol0 + k * 32 + (lane >> 4) * 8;
+                const bool ok = cok && t < p.T;
+                nv[g] = ok ? min(8, p.T - t) : 0;
+                boff[g] = ok ? (rowoff + t) * 2 : OOB_OFF;
+                l0[g] = zero8; l1[g] = zero8; l2[g] = zero8;
+                if constexpr (EST) {
+                    const u32x4* slot = reinterpret_cast<const u32x4*>(Ew) + (m * NP2 + k) * 64 + lane;
+                    if (EPI == EPI_RES) l0[g] = bf8_unpack(slot[0]);
+                    if (EPI == EPI_AFF) {
+                        l1[g] = bf8_unpack(slot[0]);
+                        l2[g] = bf8_unpack(slot[MW * NP2 * 64]);
+                        if (p.res) l0[g] = bf8_unpack(slot[2 * MW * NP2 * 64]);
+                    }
+                } else {
+                    if (EPI == EPI_RES) l0[g] = act_load8(R.res, boff[g], 0);
+                    if (EPI == EPI_RANK1) {                        // the raw float32 signal
+                        l0[g].lo = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
+                        l0[g].hi = buf_load4(R.r1x, (ok && nv[g] == 8) ? t * 4 + 16 : OOB_OFF, 0);
+                    }
+                    if (EPI == EPI_AFF) {
+                        l0[g] = act_load8(R.res, boff[g], 0);      // zero-length descriptor when absent
+                        l1[g] = act_load8(R.ss, boff[g], 0);
+                        l2[g] = act_load8(R.ss, boff[g], shift_soff);
+                    }
+                }
+            }
+            #pragma unroll
+            for (int g = 0; g < G; ++g) {
+                f32x8 v = hx_pair(acc[2 * (k0 + g)][m], acc[2 * (k0 + g) + 1][m], Xw, lane);
+                v.lo += bias; v.hi += bias;
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) { v.lo[e] = fmaxf(v.lo[e], v.lo[e] * slope); v.hi[e] = fmaxf(v.hi[e], v.hi[e] * slope); }
+                if (EPI == EPI_RES || EPI == EPI_AFF) { v.lo += l0[g].lo; v.hi += l0[g].hi; }
+                if (EPI == EPI_RANK1) { v.lo += l0[g].lo * r1w + r1b; v.hi += l0[g].hi * r1w + r1b; }
+                act_store8(R.y, boff[g], v, nv[g]);                // dropped when y is absent
+                if (EPI == EPI_AFF) {
+                    f32x8 u;
+                    u.lo = l1[g].lo * v.lo + l2[g].lo; u.hi = l1[g].hi * v.hi + l2[g].hi;
+                    u = keep8(u, nv[g]);
+                    act_store8(R.y2, boff[g], u, nv[g]);
+                    s1[m] += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
+                    s2[m] += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
+                             ((u.hi.x * u.hi.x + u.hi.y * u.hi.y) + (u.hi.z * u.hi.z + u.hi.w * u.hi.w));
+                }
+            }
+        }
+    }
+}
+// the pair epilogue needs an even number of time tiles per wave; its operands are staged while they fit
+template <int MW, int NW, int MODE> constexpr bool hx_pairs_epi() { return MODE == MODE_DIRECT && NW % 2 == 0; }
+#else
+template <int MW, int NW, int MODE> constexpr bool hx_pairs_epi() { return false; }
+#endif
+
 // variants that stage their epilogue operands (scale, shift, residual) in LDS ahead of the epilogue with
 // LDS-DMA pieces (ws_epilogue_stage, fastsvc_device.inc): fetched inside the epilogue each 16x16 item costs a
 // full memory round trip (timeline of up.3.d3 without it: 15.5k of 17k cycles per unit in the epilogue)
 template <int MW, int NW, int MODE, int EPI>
-constexpr bool hx_estage() { return MODE == MODE_DIRECT && (EPI == EPI_AFF || EPI == EPI_RES) && MW * NW <= 6; }
+constexpr bool hx_estage() {
+    return MODE == MODE_DIRECT && (EPI == EPI_AFF || EPI == EPI_RES) && (hx_pairs_epi<MW, NW, MODE>() ? MW * NW <= 12 : MW * NW <= 6);
+}
 
 template <int MW, int NW, int MODE, int EPI>
 constexpr int hx_min_waves() {
@@ -521,8 +699,14 @@ void conv_hx_kernel(const ConvParams p0) {
         const EpiConst<MW, true> K{k_bias, k_bias2, k_r1w, k_r1b};
         constexpr bool EST = hx_estage<MW, NW, MODE, EPI>();
         // this wave's epilogue-operand slots, behind the tile buffers (hx_launch_direct sizes them)
-        const float* Ew = reinterpret_cast<const float*>(tiles + 2 * bufsz) +
-                          cw * ((EPI == EPI_RES ? 1 : p.res ? 3 : 2) * MW * NW * EST_ITEM_FLOATS);
+        constexpr bool PAIRS = hx_pairs_epi<MW, NW, MODE>();
+        constexpr int EST_WAVE_FLOATS = EST ? (PAIRS ? MW * (NW / 2) * 256 : MW * NW * EST_ITEM_FLOATS) : 0;   // per operand
+        const int est_ops = EPI == EPI_RES ? 1 : p.res ? 3 : 2;
+        const float* Ew = reinterpret_cast<const float*>(tiles + 2 * bufsz) + cw * (est_ops * EST_WAVE_FLOATS);
+        // bfloat16 pair epilogue: this wave's re-layout patch behind every wave's operand slots
+        float* Xw = const_cast<float*>(reinterpret_cast<const float*>(tiles + 2 * bufsz)) + 4 * est_ops * EST_WAVE_FLOATS +
+                    cw * (16 * 36);
+        (void)Xw;
         stamp(2);
         setup_shared();
         __syncthreads();                               // unit 0 staged
@@ -540,8 +724,13 @@ void conv_hx_kernel(const ConvParams p0) {
             for (int ch = 0; ch < nch; ++ch, ++u) {
                 if constexpr (EST) {
                     // one unit earlier when the tile has several K chunks: more time to land
-                    if (active && ch == max(nch - 2, 0) && !(p.dbg & DBG_NO_EPILOGUE))
+                    if (active && ch == max(nch - 2, 0) && !(p.dbg & DBG_NO_EPILOGUE)) {
+#ifdef FASTSVC_ACT_BF16
+                        if constexpr (PAIRS) hx_epilogue8_stage<MW, NW / 2, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
+                        else
+#endif
                         ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
+                    }
                 }
                 if (active && !(p.dbg & DBG_NO_MFMA)) {
                     if constexpr (POLY) hx_unit_poly<MW, NW, !WSTATIC>(acc3, tiles + (u & 1) * bufsz, aoff, lo_off, wst);
@@ -558,9 +747,17 @@ void conv_hx_kernel(const ConvParams p0) {
                         ws_epilogue_poly<MW, NW, EPI, S, 0>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
                     else if constexpr (DEC2)
                         ws_epilogue_dec2<MW, NW>(p, R, acc2, sig, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
-                    else
+                    else {
+#ifdef FASTSVC_ACT_BF16
+                        if constexpr (PAIRS) {
+                            if (!(p.dbg & DBG_NO_EPILOGUE))
+                                hx_epilogue8<MW, NW / 2, EPI, EST>(p, R, acc, s1, s2, sig, mg,
+                                                                   (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew, Xw);
+                        } else
+#endif
                         ws_epilogue_kind<MW, NW, EPI, EST, 0>(p, R, acc, s1, s2, sig, mg,
                                                               (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
+                    }
                     if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
@@ -633,8 +830,10 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
     } else {
         const int kind = aff ? EPI_AFF : p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
         size_t est = 0;
+        constexpr bool PAIRS = hx_pairs_epi<MW, NW, MODE_DIRECT>();
         if ((kind == EPI_AFF && hx_estage<MW, NW, MODE_DIRECT, EPI_AFF>()) || (kind == EPI_RES && hx_estage<MW, NW, MODE_DIRECT, EPI_RES>()))
-            est = sizeof(float) * 4 * (size_t)(aff ? (p.res ? 3 : 2) : 1) * MW * NW * EST_ITEM_FLOATS;
+            est = sizeof(float) * 4 * (size_t)(aff ? (p.res ? 3 : 2) : 1) * (PAIRS ? MW * (NW / 2) * 256 : MW * NW * EST_ITEM_FLOATS);
+        if (PAIRS) est += sizeof(float) * 4 * 16 * 36;                             // the waves' re-layout patches
 #define FASTSVC_HX(k) if (kind == k) return hx_launch_kind<MW, NW, WM, WN, MODE_DIRECT, k, 1>(grid, smem + est, stream, p);
         FASTSVC_HX(EPI_PLAIN) FASTSVC_HX(EPI_RES) FASTSVC_HX(EPI_RANK1) FASTSVC_HX(EPI_AFF)
 #undef FASTSVC_HX

@@ -472,10 +472,11 @@ def test_batched_decode_equals_the_reference_decode_loop(dev):
 
 
 def test_bfloat16_activation_storage_mode(dev):
-    """BASELINE config 3's dtype: workspace tensors stored as bfloat16 (fp32 MFMA arithmetic, fp32
-    weights / statistics).  Not the 1e-3 parity path: tolerance is that of bf16 activations, the
-    bound is ~2x what is observed (mean-abs 7e-3, max-abs 0.08 on an output of rms 0.66; SURVEY 8(c)'s
-    proposed ceiling is 2e-2 / 0.3), and the
+    """BASELINE config 3's dtype: workspace tensors stored as bfloat16 and the convolutions multiplied on
+    the bf16 MFMA (bf16-rounded activations AND weights, f32 accumulation; InstanceNorm statistics in
+    f64) - what the reference does under torch.autocast(bfloat16).  Not the 1e-3 parity path: the bound
+    is ~2x what is observed (mean-abs 1.25e-2, max-abs 0.11 on an output of rms 0.66; the reference's own
+    bf16 autocast sits at 1.3e-2 / 0.2 and SURVEY 8(c)'s proposed ceiling is 2e-2 / 0.3), and the
     float32 path must stay an order of magnitude closer.  Also: half the workspace, bf16 taps,
     ragged batches work, frame counts that are not multiples of 4 are refused (not silently slow)."""
     O = _oracle()
@@ -494,7 +495,7 @@ def test_bfloat16_activation_storage_mode(dev):
     y16 = p16.forward(blob, *ins, workspace=ws).cpu()
     y32 = p32.forward(blob, *ins).cpu()
     e16, e32 = (y16 - ref).abs(), (y32 - ref).abs()
-    assert float(e16.mean()) <= 1.5e-2 and float(e16.max()) <= 0.2
+    assert float(e16.mean()) <= 2e-2 and float(e16.max()) <= 0.25
     assert float(e32.max()) <= TIGHT and float(e16.mean()) > 10 * float(e32.mean())     # it really is a different mode
     tap = p16.tap("up.3.out", B, F, ws)
     assert tap.dtype == torch.bfloat16 and tuple(tap.shape) == (B, 24, F * 160)
@@ -502,7 +503,7 @@ def test_bfloat16_activation_storage_mode(dev):
     yr = p16.forward(blob, *ins, lengths=[36, 48]).cpu()                                # ragged
     r0 = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[:1, :, :36], b.sine[:1, :, :36 * 160],
                          b.lft[:1, :, :36 * 160], b.spk_emb[:1])
-    assert float((yr[:1, :, :36 * 160] - r0).abs().mean()) <= 1.5e-2 and float(yr[0, :, 36 * 160:].abs().max()) == 0.0
+    assert float((yr[:1, :, :36 * 160] - r0).abs().mean()) <= 2e-2 and float(yr[0, :, 36 * 160:].abs().max()) == 0.0
     b2 = S.synth_batch(cfg, 1, 41, 83)
     with pytest.raises(A.FastSVCError):
         p16.forward(blob, *_to(dev, b2.ppg, b2.sine, b2.lft, b2.spk_emb))

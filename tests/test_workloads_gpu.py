@@ -18,9 +18,9 @@ from svcc23_fastsvc_amd import synth as S
 pytestmark = pytest.mark.gpu
 
 TIGHT = 1e-4
-# bf16 activations: observed mean-abs 7e-3 / max-abs 0.08 on an output of rms 0.7 (SURVEY 8c proposes
-# the ceiling 2e-2 / 0.3; the reference's own bf16 autocast sits at 1.3e-2 / 0.2): hold ~2x observed
-BF16_MEAN, BF16_MAX = 1.5e-2, 0.2
+# bf16 products and activations: observed mean-abs 1.25e-2 / max-abs 0.11 on an output of rms 0.7 (the
+# reference's own bf16 autocast sits at 1.3e-2 / 0.2; SURVEY 8c proposes the ceiling 2e-2 / 0.3)
+BF16_MEAN, BF16_MAX = 2e-2, 0.25
 
 
 @pytest.fixture(scope="module")
