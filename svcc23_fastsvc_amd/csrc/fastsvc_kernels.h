@@ -146,8 +146,9 @@ bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN);
 
 // down-sampling stage 0, first conv (C_in = 1, k = 3, d = 1, LeakyReLU on the input):
 //   y[sig][b][co][t] = bias[co] + sum_tap w[co][tap] * lrelu(x[sig][b][t + tap - 1])
+//   x: signal 0 (B, T); signal 1 starts x_sig floats further (the caller's two tensors, no copy)
 //   lens / len_mul: ragged batches (valid length of utterance b = lens[b] * len_mul, rows keep pitch T)
-hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, long w_sig, long b_sig,
+hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const float* bias, long w_sig, long b_sig,
                            float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream);
 
 // conv_last: 1x1, y[b][o][t] = bias[o] + sum_c w[o][c] * x[b][c][t]
@@ -170,7 +171,7 @@ hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks
 namespace bf16 {
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
-hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, long w_sig, long b_sig,
+hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const float* bias, long w_sig, long b_sig,
                            float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream);
 hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
                                 int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream);

@@ -1234,7 +1234,7 @@ hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t s
 // HBM-write bound (C floats written per float read).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void in1_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+void in1_conv_kernel(const float* __restrict__ x, long x_sig, const float* __restrict__ w,
                      const float* __restrict__ bias, long w_sig, long b_sig, float* __restrict__ y,
                      int B, int C, int ld, const int* __restrict__ lens, int len_mul) {
     const int z = blockIdx.z;
@@ -1242,7 +1242,7 @@ void in1_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
     const int T = lens ? lens[z - sig * B] * len_mul : ld;          // valid length of this utterance (pitch ld)
     const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (t >= T) return;
-    const float* xr = x + (long)z * ld;
+    const float* xr = x + (long)sig * x_sig + (long)(z - sig * B) * ld;      // the two signals are separate tensors
     float xv[6];
     #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -1278,10 +1278,10 @@ void in1_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
     }
 }
 
-hipError_t launch_in1_conv(const float* x, const float* w, const float* bias, long w_sig, long b_sig,
+hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const float* bias, long w_sig, long b_sig,
                            float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream) {
     dim3 grid((T + 1023) / 1024, 1, nsig * B);
-    hipLaunchKernelGGL(in1_conv_kernel, grid, dim3(256), 0, stream, x, w, bias, w_sig, b_sig, y, B, C, T, lens, len_mul);
+    hipLaunchKernelGGL(in1_conv_kernel, grid, dim3(256), 0, stream, x, x_sig, w, bias, w_sig, b_sig, y, B, C, T, lens, len_mul);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -644,7 +645,6 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
     for (int i = 0; i < n; ++i) hop *= P.cfg.upsampling_scales[i];
     const int64_t T = hop * F;
     const size_t ae = P.storage == 1 ? 2 : sizeof(float);      // activation element size
-    ws.add("sig", 2, B, T);                                   // [lft ; sine] raw signals (always float32)
     if (P.storage == 1) ws.add("ppg_act", B, P.cfg.in_channels, F, ae);
     int64_t Tk = T;
     for (int k = 0; k < n; ++k) {
@@ -1220,10 +1220,12 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     }
     const bool spk = spk_emb != nullptr;
 
-    // ---- raw signals side by side: sig 0 = lft, sig 1 = sine ----
-    float* sigbuf = buf("sig");
-    HIP_TRY(hipMemcpyAsync(sigbuf, lft, sizeof(float) * B * T, hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(sigbuf + (long)B * T, sine, sizeof(float) * B * T, hipMemcpyDeviceToDevice, stream));
+    // ---- raw signals: sig 0 = lft, sig 1 = sine, read in place (the dual-signal launches address signal
+    // `sig` as base + sig * stride; the stride between the caller's two tensors is whatever it is) ----
+    const float* sigbuf = lft;
+    const std::ptrdiff_t sig_bytes = reinterpret_cast<const char*>(sine) - reinterpret_cast<const char*>(lft);
+    if (sig_bytes % (std::ptrdiff_t)sizeof(float) != 0) return fail(FASTSVC_E_INVALID, "sine / lft must be 4-byte aligned");
+    const long sig_stride = (long)(sig_bytes / (std::ptrdiff_t)sizeof(float));
 
     // ---- speaker bias for all blocks + zeroed InstanceNorm accumulators ----
     if (spk) {
@@ -1271,7 +1273,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         if (k == 0) {
             if (prof) HIP_TRY(prof->begin(stream, "down.0.c1", "in1_conv", 2.0 * 3 * d.C * (double)Tk * B * 2,
                                           4.0 * (1.0 + d.C) * (double)Tk * B * 2));
-            HIP_TRY((P.storage == 1 ? bf16::launch_in1_conv : launch_in1_conv)(sigbuf, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
+            HIP_TRY((P.storage == 1 ? bf16::launch_in1_conv : launch_in1_conv)(sigbuf, sig_stride, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
                                     (long)(d.c1_raw[1].w_off - d.c1_raw[0].w_off),
                                     (long)(d.c1_raw[1].b_off - d.c1_raw[0].b_off), c1, 2, B, d.C, (int)Tk,
                                     lengths, (int)(Tk / F), stream));
@@ -1306,7 +1308,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             HIP_TRY(run_conv(d.c2[0], blob, p, 2, (long)(d.c2[1].w_off - d.c2[0].w_off), (long)(d.c2[1].b_off - d.c2[0].b_off), stream, prof, ("down." + s + ".c2_d2").c_str()));
             p.x = c2; p.y = h;                                     // h = conv3_d4(lrelu(c2)) + r
             if (k == 0) {
-                p.r1x = sigbuf; p.r1x_sig = (long)B * T; p.r1x_b = T;
+                p.r1x = sigbuf; p.r1x_sig = sig_stride; p.r1x_b = T;
                 p.r1w = blob + d.r_raw[0].w_off; p.r1b = blob + d.r_raw[0].b_off;
                 p.r1_sig = (long)(d.r_raw[1].w_off - d.r_raw[0].w_off);
                 if ((d.r_raw[1].b_off - d.r_raw[0].b_off) != (d.r_raw[1].w_off - d.r_raw[0].w_off))

@@ -47,6 +47,14 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
         n0 = merged.get(key, 0)
         js[key] = (js.get(key, 0.0) * n0 + hbm * fetch[k][1]) / (n0 + fetch[k][1])
         merged[key] = n0 + fetch[k][1]
+    # half-precision MFMA kernels: MW, NW, WM, WN, mode, epilogue kind, S (+ resident weights: merged); x3 = split
+    # binary16 products (float32 storage), x1 = bf16 products (namespace fastsvc::bf16)
+    m = re.search(r"conv_hx_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", k)
+    if m:
+        key = "conv_hx<%s,%s,%s,%s,%s,%s,%s," % m.groups() + ("x1>" if "bf16::" in k else "x3>")
+        n0 = merged.get(key, 0)
+        js[key] = (js.get(key, 0.0) * n0 + hbm * fetch[k][1]) / (n0 + fetch[k][1])
+        merged[key] = n0 + fetch[k][1]
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
     if m:
         js["conv_mfma<%s,%s,%s,%s>" % m.groups()] = hbm
