@@ -555,3 +555,58 @@ def test_signal_generator_long_utterance_and_noise_statistics(dev):
     assert abs(resid.mean()) < 1e-4
     assert abs(out[:, 1].std() - 1) < 0.02 and abs(out[:, 1].mean()) < 0.01
     assert np.array_equal(out[:, 2], vuv[:, 0])
+
+
+def test_half_precision_and_f32_mfma_families_agree(dev):
+    """The two kernel families (csrc/fastsvc_hx.hip: split-binary16 products; csrc/fastsvc_kernels.hip:
+    f32-input MFMA) compute the same dataflow: force each through the launch-shape table on the same
+    inputs and compare the waveform and every up-block output - both fp32-class, so they must agree
+    to a few 1e-6, far inside the 1e-4 the parity tests hold against the oracle."""
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 61)
+    B, F = 2, 48                                       # every rate a multiple of 4: all 45 convs are eligible
+    b = S.synth_batch(cfg, B, F, 62)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    p_hx = A.Plan(cfg, load_shipped_table=False)       # cost model: the half-precision family wherever it exists
+    blob = p_hx.pack(sd).to(dev)
+    ws_hx = torch.zeros(p_hx.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    recs = []
+    y_hx = p_hx.forward(blob, *ins, workspace=ws_hx, profile=recs)
+    n_hx = sum(1 for r in recs if r["kernel"].startswith("conv_hx<"))
+    assert n_hx == 43, sorted((r["layer"], r["kernel"]) for r in recs)     # all convs but in1 / conv_last
+    p_32 = A.Plan(cfg, load_shipped_table=False)
+    p_32.load_tuned({f"{r['layer']}|{B}|{t}": [1, 1, 4, 1, 0] for r in recs
+                     for t in (F, 2 * F, 8 * F, 32 * F, 160 * F)})          # algo 0 = the f32-input MFMA kernels
+    ws_32 = torch.zeros(p_32.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    recs32 = []
+    y_32 = p_32.forward(blob, *ins, workspace=ws_32, profile=recs32)
+    assert not any(r["kernel"].startswith("conv_hx<") for r in recs32)
+    assert float((y_hx - y_32).abs().max()) <= 2e-5
+    for i in range(cfg.n_stages):
+        a, c = p_hx.tap(f"up.{i}.out", B, F, ws_hx), p_32.tap(f"up.{i}.out", B, F, ws_32)
+        assert float((a - c).abs().max()) <= 2e-5 * max(1.0, float(c.abs().max()))
+
+
+def test_ragged_batch_on_a_non_default_configuration(dev):
+    """with `lengths` one utterance's row length can be a non-multiple of 4 while the padded maximum
+    is one; variants compiled without the row-end handling must then not be picked.  A generator with other
+    widths / scales (hop 60, the 24-channel stages at 4F and 12F) and odd frame counts: every utterance of
+    the ragged batch equals the utterance run alone, and the oracle."""
+    O = _oracle()
+    cfg = S.GeneratorConfig.from_kwargs(in_channels=48, mid_channels=[96, 48, 24, 24], upsampling_scales=[2, 2, 3, 5],
+                                        out_channels=1, spk_emb_size=32, use_spk_emb=True)
+    sd = S.synth_state_dict(cfg, 71)
+    lens = [13, 16, 9]
+    B, F = len(lens), max(lens)
+    b = S.synth_batch(cfg, B, F, 72)
+    plan = A.Plan(cfg, load_shipped_table=False)
+    blob = plan.pack(sd).to(dev)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    y = plan.forward(blob, *ins, lengths=lens).cpu()
+    wf = S.fold_weight_norm(sd)
+    hop = cfg.hop
+    for j, n in enumerate(lens):
+        ref = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[j:j + 1, :, :n], b.sine[j:j + 1, :, : n * hop],
+                              b.lft[j:j + 1, :, : n * hop], b.spk_emb[j:j + 1])
+        assert float((y[j:j + 1, :, : n * hop] - ref).abs().max()) <= TIGHT * max(1.0, float(ref.abs().max())), j
+        assert float(y[j, :, n * hop:].abs().max() if n < F else 0.0) == 0.0
