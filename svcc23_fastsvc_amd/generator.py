@@ -259,10 +259,6 @@ class FastSVCGenerator(nn.Module):
         Extension (keyword only, not in the reference): ``lengths`` = per-utterance frame counts of
         a padded ragged batch; utterance b is computed as if run alone with lengths[b] frames and
         the padding of the output is zero."""
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "the HIP path implements the generator forward only (backward is SURVEY.md §8 f2): "
-                "call under torch.no_grad() / model.eval()")
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise FastSVCError("FastSVCGenerator (HIP) needs GPU tensors; there is no CPU fallback "
                                "(the CPU oracle lives in oracle/ and is test infrastructure only)")
@@ -272,6 +268,21 @@ class FastSVCGenerator(nn.Module):
                              f"{s.shape[-1]} / loudness {l.shape[-1]} samples")
         if spk_emb is not None and not self.use_spk_emb:
             raise ValueError("spk_emb given but the generator was built with use_spk_emb=False")
+        needs_grad = torch.is_grad_enabled() and (
+            any(p.requires_grad for p in self.parameters()) or
+            any(isinstance(t, torch.Tensor) and t.requires_grad for t in (x, s, l, spk_emb)))
+        if needs_grad:
+            # training (train_fastsvc.py:157-240 calls the module under autograd): HIP forward, PyTorch-ROCm
+            # autograd backward over a restatement of the same dataflow - see autograd.py (first slice)
+            if lengths is not None:
+                raise NotImplementedError("ragged batches (`lengths`) are an inference extension: no backward")
+            from .autograd import forward_with_grad
+            return forward_with_grad(self, x, s, l, spk_emb)
+        return self._forward_device(x, s, l, spk_emb, lengths)
+
+    def _forward_device(self, x, s, l, spk_emb, lengths):
+        """The HIP forward proper (no autograd): packed weights, workspace sub-batching, C-ABI call."""
+        hop = self._cfg.hop
         blob = self.packed_weights(x.device)
         plan = self.plan
         B, _, F = x.shape

@@ -17,6 +17,8 @@ Fixtures written:
   full_forward_cfg2.npz yaml-width generator, B=8, F=600 (BASELINE cfg2): 16 slices + checksums
   inference_f40.npz     ``inference()`` call sequence with the reference SignalGenerator, noise_amp=0
   weight_norm_fold.npz  torch ``remove_weight_norm`` result for three layers (g, v -> w)
+  tiny_grads.npz        autograd of the reference generator in train() mode (tiny width): d sum(r*y) / d every
+                        parameter (weight_g / weight_v / bias) and input, with / without speaker embedding
   decode_chain.npz      decode_fastsvc.py:160-189 per utterance for three utterances of different
                         length: F0Statistics.estimate / .convert (features.py:41-108, std forced to 1),
                         then ``inference()`` with the converted F0 (noise_amp=0)
@@ -174,6 +176,33 @@ def decode_chain(M):
     print("decode_chain", [out[f"y.{i}"].shape for i in range(3)], src_stats)
 
 
+def grads(M):
+    """Gradients of the LIVE reference generator under autograd (train_fastsvc.py:157-240 calls it that way):
+    L = sum(r * y) for a fixed r, tiny-width generator in train() mode with weight-norm parametrisation;
+    d L / d every parameter and every input, with and without the speaker embedding."""
+    cfg, seed_w, seed_x, B, F = S.TINY_CONFIG, 111, 112, 2, 12
+    out = {}
+    b = S.synth_batch(cfg, B, F, seed_x)
+    r = S.hash_normalish(77, S.stream_id("grad.r"), B * F * cfg.hop).reshape(B, 1, F * cfg.hop).astype(np.float32)
+    out["meta"] = np.array([seed_w, seed_x, B, F])
+    out["r"] = r
+    for tag, with_spk in (("spk", True), ("nospk", False)):
+        g, sd = build_reference(M, cfg, seed_w)
+        g.train()
+        ins = [torch.from_numpy(a).clone().requires_grad_(True) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
+        y = g(ins[0], ins[1], ins[2], ins[3] if with_spk else None)
+        (y * torch.from_numpy(r)).sum().backward()
+        out[f"{tag}/y"] = y.detach().numpy()
+        for name, t in zip(("ppg", "sine", "lft", "spk_emb"), ins):
+            if t.grad is not None:
+                out[f"{tag}/in/{name}"] = t.grad.numpy()
+        for name, p in g.named_parameters():
+            if p.grad is not None:
+                out[f"{tag}/p/{name}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_grads.npz"), **out)
+    print("tiny_grads.npz:", len(out), "arrays")
+
+
 def fold(M):
     cfg = S.TINY_CONFIG
     g, sd = build_reference(M, cfg, 101)
@@ -190,9 +219,9 @@ def fold(M):
 
 if __name__ == "__main__":
     M = import_reference()
-    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain"]
+    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain", "grads"]
     for name in todo:
-        {"tiny": tiny, "full": full, "inference": inference, "fold": fold, "decode_chain": decode_chain}[name](M)
+        {"tiny": tiny, "full": full, "inference": inference, "fold": fold, "decode_chain": decode_chain, "grads": grads}[name](M)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
