@@ -200,6 +200,18 @@ int fastsvc_signal_generate(const float* f0, float* out, void* scratch, int32_t 
                             float sample_rate, float sine_amp, float noise_amp,
                             const int32_t* types, int32_t ntypes, uint64_t seed, void* stream);
 
+/* ---- the producer of the generator's loudness input ----
+ * Replaces loudness_extract(audio, sampling_rate, hop_length) (harana/bin/preprocess_fastsvc.py:60-75; librosa
+ * 0.8.1 stft n_fft 2048 / periodic Hann / reflect padding, perceptual (A) weighting with the 80 dB floor below
+ * the utterance maximum, db_to_amplitude, log(mean over bins + 1e-5), nearest stretch by the hop):
+ *   audio (B, T) device float32, one utterance per row;  out (B, frames * hop), frames = 1 + T / hop
+ *   scratch  fastsvc_loudness_scratch_bytes(B, T, hop) device bytes (power spectrogram + per-utterance maximum)
+ * Asynchronous on `stream`. */
+int32_t fastsvc_loudness_frames(int32_t T, int32_t hop);
+size_t fastsvc_loudness_scratch_bytes(int32_t B, int32_t T, int32_t hop);
+int fastsvc_loudness_extract(const float* audio, float* out, void* scratch, int32_t B, int32_t T, int32_t hop,
+                             float sample_rate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

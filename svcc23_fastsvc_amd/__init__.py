@@ -4,6 +4,7 @@ from .synth import GeneratorConfig, FULL_CONFIG, TINY_CONFIG  # noqa: F401
 from .engine import FastSVCError, Plan, load_library, library_path  # noqa: F401
 from .generator import FastSVCGenerator, install_into_harana  # noqa: F401
 from .signal import SignalGenerator  # noqa: F401
+from .loudness import loudness_extract  # noqa: F401
 
-__all__ = ["FastSVCGenerator", "SignalGenerator", "GeneratorConfig", "Plan", "FastSVCError", "install_into_harana",
+__all__ = ["FastSVCGenerator", "SignalGenerator", "loudness_extract", "GeneratorConfig", "Plan", "FastSVCError", "install_into_harana",
            "load_library", "library_path", "FULL_CONFIG", "TINY_CONFIG"]

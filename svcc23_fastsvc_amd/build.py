@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip.so")
 # the stamped diagnostic build (--timeline) is a separate file: loaded only when FASTSVC_HIP_LIB names it
 TIMELINE_LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip_timeline.so")
-SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip"]
+SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip", "fastsvc_loudness.hip"]
 HEADERS = [os.path.join(CSRC, "fastsvc_kernels.h"), os.path.join(ROOT, "include", "fastsvc_hip.h")]
 ARCH = "gfx950"
 
@@ -46,6 +46,7 @@ UNITS = [
     ("fastsvc_hx.hip", ["-DFASTSVC_ACT_BF16=1"], "hx_bf16.o"),
     ("fastsvc_plan.cpp", [], "plan.o"),
     ("fastsvc_signal.hip", [], "signal.o"),
+    ("fastsvc_loudness.hip", [], "loudness.o"),
 ]
 
 

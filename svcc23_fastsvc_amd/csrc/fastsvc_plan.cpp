@@ -671,9 +671,11 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
         ws.add("up." + s + ".u3", B, u.C, Tout, ae);      // scale * t2 + shift
         ws.add("up." + s + ".out", B, u.C, Tout, ae);
         ws.add("up." + s + ".spk", B, u.C, 1);
-        ws.add("up." + s + ".stats", 3 * B, u.C, 2, sizeof(double));
         Tin = Tout;
     }
+    // InstanceNorm accumulators of all blocks side by side: ONE memset zeroes them
+    for (int i = 0; i < n; ++i)
+        ws.add("up." + std::to_string(i) + ".stats", 3 * B, P.up[i].C, 2, sizeof(double));
     return ws;
 }
 
@@ -1227,17 +1229,15 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     if (sig_bytes % (std::ptrdiff_t)sizeof(float) != 0) return fail(FASTSVC_E_INVALID, "sine / lft must be 4-byte aligned");
     const long sig_stride = (long)(sig_bytes / (std::ptrdiff_t)sizeof(float));
 
-    // ---- speaker bias for all blocks + zeroed InstanceNorm accumulators ----
+    // ---- speaker bias for all blocks + zeroed InstanceNorm accumulators: first needed by up block 0, so
+    // off the critical path (the down chains) on the second helper stream, joined before the up blocks ----
+    hipStream_t s_pre = ctx ? ctx->aux[1] : stream;
     if (spk) {
+        HIP_TRY(order_after(stream, s_pre));               // after whatever the caller enqueued before us
         const BufferSpec* s0 = ws.find("up.0.stats");
         const BufferSpec* sl = ws.find("up." + std::to_string(n - 1) + ".stats");
         const size_t span = sl->off_bytes + align_up((size_t)sl->numel * sizeof(double), 256) - s0->off_bytes;
-        // the stats buffers are not contiguous (other up.* buffers sit between them): zero each
-        (void)span;
-        for (int i = 0; i < n; ++i) {
-            const BufferSpec* sb = ws.find("up." + std::to_string(i) + ".stats");
-            HIP_TRY(hipMemsetAsync(wsb + sb->off_bytes, 0, (size_t)sb->numel * sizeof(double), stream));
-        }
+        HIP_TRY(hipMemsetAsync(wsb + s0->off_bytes, 0, span, s_pre));
         SpkBlock blocks[FASTSVC_MAX_STAGES];
         for (int i = 0; i < n; ++i) {
             blocks[i].w = blob + P.up[i].emb.w_off;
@@ -1246,9 +1246,9 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             blocks[i].C = P.up[i].C;
         }
         double spk_c = 0; for (int i = 0; i < n; ++i) spk_c += P.up[i].C;
-        if (prof) HIP_TRY(prof->begin(stream, "spk_proj", "spk_proj", 2.0 * spk_c * P.cfg.spk_emb_size * B,
+        if (prof) HIP_TRY(prof->begin(s_pre, "spk_proj", "spk_proj", 2.0 * spk_c * P.cfg.spk_emb_size * B,
                                       4.0 * (spk_c * P.cfg.spk_emb_size + (double)B * P.cfg.spk_emb_size + spk_c * B)));
-        HIP_TRY(launch_spk_proj(spk_emb, blocks, n, B, P.cfg.spk_emb_size, stream));
+        HIP_TRY(launch_spk_proj(spk_emb, blocks, n, B, P.cfg.spk_emb_size, s_pre));
         if (prof) HIP_TRY(prof->end());
     }
 
@@ -1343,6 +1343,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     }
 
     // ---- up blocks ----
+    if (spk) HIP_TRY(order_after(s_pre, stream));           // speaker biases and zeroed sums are ready
     const float* x = ppg;
     if (P.storage == 1) {                                          // external float32 input -> workspace bf16
         float* pa = buf("ppg_act");

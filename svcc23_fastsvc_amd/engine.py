@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
     "fastsvc_flops_per_sample", "fastsvc_signal_scratch_bytes", "fastsvc_signal_generate",
     "fastsvc_stream_prepare", "fastsvc_split_half",
+    "fastsvc_loudness_frames", "fastsvc_loudness_scratch_bytes", "fastsvc_loudness_extract",
 )
 
 
@@ -96,6 +97,12 @@ def load_library():
     lib.fastsvc_workspace_bytes.restype = sz
     lib.fastsvc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.fastsvc_forward.restype = ctypes.c_int
+    lib.fastsvc_loudness_frames.argtypes = [i32, i32]
+    lib.fastsvc_loudness_frames.restype = i32
+    lib.fastsvc_loudness_scratch_bytes.argtypes = [i32, i32, i32]
+    lib.fastsvc_loudness_scratch_bytes.restype = sz
+    lib.fastsvc_loudness_extract.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp]
+    lib.fastsvc_loudness_extract.restype = ctypes.c_int
     lib.fastsvc_split_half.argtypes = [vp, i64, vp, vp, vp]
     lib.fastsvc_split_half.restype = None
     lib.fastsvc_stream_prepare.argtypes = [vp]
