@@ -1231,7 +1231,8 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
 
     // ---- speaker bias for all blocks + zeroed InstanceNorm accumulators: first needed by up block 0, so
     // off the critical path (the down chains) on the second helper stream, joined before the up blocks ----
-    hipStream_t s_pre = ctx ? ctx->aux[1] : stream;
+    // (only where the helper streams pay at all: below ~1.5e5 samples per call the fork / join events cost more)
+    hipStream_t s_pre = (ctx && (streams_mask & 2)) ? ctx->aux[1] : stream;
     if (spk) {
         HIP_TRY(order_after(stream, s_pre));               // after whatever the caller enqueued before us
         const BufferSpec* s0 = ws.find("up.0.stats");
