@@ -323,6 +323,19 @@ class Plan:
         ppg, sine, lft = (t.to(torch.float32).contiguous() for t in (ppg, sine, lft))
         if spk_emb is not None:
             spk_emb = spk_emb.to(torch.float32).contiguous()
+        if self.storage == "bfloat16" and F % 4 != 0 and profile is None and not autotune:
+            # bfloat16 storage moves 4 time steps per access at the frame rate, so the library wants F % 4 == 0
+            # (three of four real utterances are not): pad to the next multiple and run the padded batch as a
+            # ragged one - `lengths` makes every utterance exactly what it would be alone at its own length
+            pad = (-F) % 4
+            hop = cfg.hop
+            fpad = torch.nn.functional.pad
+            y = self.forward(blob, fpad(ppg, (0, pad)), fpad(sine, (0, pad * hop)), fpad(lft, (0, pad * hop)), spk_emb,
+                             workspace=None, lengths=[F] * B if lengths is None else lengths)[..., :T]
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y.contiguous()
         lens_dev = None
         if lengths is not None:
             lens_host = torch.as_tensor(lengths, dtype=torch.int64, device="cpu").reshape(-1)

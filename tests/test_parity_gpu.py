@@ -478,7 +478,7 @@ def test_bfloat16_activation_storage_mode(dev):
     is ~2x what is observed (mean-abs 1.25e-2, max-abs 0.11 on an output of rms 0.66; the reference's own
     bf16 autocast sits at 1.3e-2 / 0.2 and SURVEY 8(c)'s proposed ceiling is 2e-2 / 0.3), and the
     float32 path must stay an order of magnitude closer.  Also: half the workspace, bf16 taps,
-    ragged batches work, frame counts that are not multiples of 4 are refused (not silently slow)."""
+    ragged batches work, frame counts that are not multiples of 4 are padded and run as ragged batches."""
     O = _oracle()
     cfg = S.FULL_CONFIG
     sd = S.synth_state_dict(cfg, 81)
@@ -504,9 +504,12 @@ def test_bfloat16_activation_storage_mode(dev):
     r0 = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[:1, :, :36], b.sine[:1, :, :36 * 160],
                          b.lft[:1, :, :36 * 160], b.spk_emb[:1])
     assert float((yr[:1, :, :36 * 160] - r0).abs().mean()) <= 2e-2 and float(yr[0, :, 36 * 160:].abs().max()) == 0.0
-    b2 = S.synth_batch(cfg, 1, 41, 83)
-    with pytest.raises(A.FastSVCError):
-        p16.forward(blob, *_to(dev, b2.ppg, b2.sine, b2.lft, b2.spk_emb))
+    # frame counts that are not a multiple of 4 (three of four real utterances): padded and run as a ragged batch
+    b2 = S.synth_batch(cfg, 2, 41, 83)
+    y41 = p16.forward(blob, *_to(dev, b2.ppg, b2.sine, b2.lft, b2.spk_emb)).cpu()
+    r41 = O.forward_dedup(wf, cfg.upsampling_scales, b2.ppg, b2.sine, b2.lft, b2.spk_emb)
+    assert tuple(y41.shape) == (2, 1, 41 * 160)
+    assert float((y41 - r41).abs().mean()) <= 2e-2 and float((y41 - r41).abs().max()) <= 0.25
     m = _module(cfg, sd, dev)
     m.activation_storage = "bfloat16"
     with torch.no_grad():
