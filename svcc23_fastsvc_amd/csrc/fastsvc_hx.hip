@@ -415,6 +415,85 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
         }
     }
 }
+// Polyphase epilogue in bfloat16 storage: a lane's 4 S consecutive output samples go out as 16-byte pieces
+// (8 samples; one 8-byte piece left over for odd S) instead of S 8-byte ones (see ws_epilogue_poly).
+template <int MW, int NW, int EPI, int S, class KT>
+__device__ __forceinline__ void hx_epilogue_poly8(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[3][NW][MW],
+                                                  float (&s1)[MW], float (&s2)[MW],
+                                                  int mg, int tcol0, bool active, int lane, const KT& K) {
+    if (!active) return;
+    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
+    const int T_out = p.ldy;
+    const int shift_soff = p.COUT * T_out * 2;             // bytes
+    constexpr int NP8 = S / 2;                              // 16-byte pieces; S odd: plus one 8-byte piece
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const bool cok = cot < p.COUT;
+        const int co = cok ? cot : 0;
+        const float bias = K.bias(p, 0, m, cot);
+        const int rowoff = co * T_out;
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int t = tcol0 + n * 16 + (lane >> 4) * 4;            // input-rate column (rows are a multiple of 4 long)
+            const bool ok = cok && t < p.T;
+            const int boff0 = ok ? (rowoff + t * S) * 2 : OOB_OFF;     // bytes
+            const int foff0 = ok ? (rowoff + t * S) * 4 : OOB_OFF;     // the 4-wide helpers take float bytes
+            const f32x4 zz = acc[1][n][m] + bias;
+            const f32x4 zf = zz + acc[0][n][m];
+            const f32x4 zl = zz + acc[2][n][m];
+            auto phase_value = [&](int k) -> float {
+                const int jj = k / S, ph = k % S;
+                return ph == 0 ? zf[jj] : ph == S - 1 ? zl[jj] : zz[jj];
+            };
+            f32x8 l1[NP8 > 0 ? NP8 : 1], l2[NP8 > 0 ? NP8 : 1];
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_AFF) {                                      // every operand load of the item first
+                #pragma unroll
+                for (int q = 0; q < NP8; ++q) {
+                    l1[q] = act_load8(R.ss, ok ? boff0 + q * 16 : OOB_OFF, 0);
+                    l2[q] = act_load8(R.ss, ok ? boff0 + q * 16 : OOB_OFF, shift_soff);
+                }
+                if (S & 1) {
+                    t1 = act_load4(R.ss, ok ? foff0 + (S - 1) * 16 : OOB_OFF, 0);
+                    t2 = act_load4(R.ss, ok ? foff0 + (S - 1) * 16 : OOB_OFF, shift_soff * 2);
+                }
+            }
+            #pragma unroll
+            for (int q = 0; q < NP8; ++q) {
+                f32x8 v;
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = phase_value(8 * q + e), c = phase_value(8 * q + 4 + e);
+                    v.lo[e] = fmaxf(a, a * slope); v.hi[e] = fmaxf(c, c * slope);
+                }
+                act_store8(R.y, ok ? boff0 + q * 16 : OOB_OFF, v, ok ? 8 : 0);      // dropped when y is absent
+                if (EPI == EPI_AFF) {
+                    f32x8 u;
+                    u.lo = l1[q].lo * v.lo + l2[q].lo; u.hi = l1[q].hi * v.hi + l2[q].hi;
+                    u = keep8(u, ok ? 8 : 0);
+                    act_store8(R.y2, ok ? boff0 + q * 16 : OOB_OFF, u, ok ? 8 : 0);
+                    s1[m] += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
+                    s2[m] += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
+                             ((u.hi.x * u.hi.x + u.hi.y * u.hi.y) + (u.hi.z * u.hi.z + u.hi.w * u.hi.w));
+                }
+            }
+            if (S & 1) {
+                f32x4 v;
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) { const float a = phase_value(4 * (S - 1) + e); v[e] = fmaxf(a, a * slope); }
+                act_store4(R.y, ok ? foff0 + (S - 1) * 16 : OOB_OFF, v);
+                if (EPI == EPI_AFF) {
+                    f32x4 u = t1 * v + t2;
+                    if (!ok) u = f32x4{0.f, 0.f, 0.f, 0.f};
+                    act_store4(R.y2, ok ? foff0 + (S - 1) * 16 : OOB_OFF, u);
+                    s1[m] += (u.x + u.y) + (u.z + u.w);
+                    s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+                }
+            }
+        }
+    }
+}
 // the pair epilogue needs an even number of time tiles per wave; its operands are staged while they fit
 template <int MW, int NW, int MODE> constexpr bool hx_pairs_epi() { return MODE == MODE_DIRECT && NW % 2 == 0; }
 #else
@@ -743,8 +822,13 @@ void conv_hx_kernel(const ConvParams p0) {
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
                     // the staged pieces are older than the NSLOT ring re-requests of this unit
                     if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(p.dbg & DBG_NO_MFMA)); }
-                    if constexpr (POLY)
+                    if constexpr (POLY) {
+#ifdef FASTSVC_ACT_BF16
+                        hx_epilogue_poly8<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
+#else
                         ws_epilogue_poly<MW, NW, EPI, S, 0>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
+#endif
+                    }
                     else if constexpr (DEC2)
                         ws_epilogue_dec2<MW, NW>(p, R, acc2, sig, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
                     else {

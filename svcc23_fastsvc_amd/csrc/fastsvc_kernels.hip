@@ -1233,46 +1233,54 @@ hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t s
 // K = 3 only: a VALU kernel; every thread produces 4 consecutive samples for all C channels.
 // HBM-write bound (C floats written per float read).
 // ---------------------------------------------------------------------------------------------
+#ifdef FASTSVC_ACT_BF16
+constexpr int IN1_SPT = 8;          // samples per thread: 16-byte bf16 stores
+#else
+constexpr int IN1_SPT = 4;          // 16-byte float stores
+#endif
 __global__ __launch_bounds__(256)
 void in1_conv_kernel(const float* __restrict__ x, long x_sig, const float* __restrict__ w,
                      const float* __restrict__ bias, long w_sig, long b_sig, float* __restrict__ y,
                      int B, int C, int ld, const int* __restrict__ lens, int len_mul) {
+    constexpr int SPT = IN1_SPT;
     const int z = blockIdx.z;
     const int sig = z / B;
     const int T = lens ? lens[z - sig * B] * len_mul : ld;          // valid length of this utterance (pitch ld)
-    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * SPT;
     if (t >= T) return;
     const float* xr = x + (long)sig * x_sig + (long)(z - sig * B) * ld;      // the two signals are separate tensors
-    float xv[6];
+    float xv[SPT + 2];
     #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < SPT + 2; ++i) {
         const int tt = t - 1 + i;
         xv[i] = (tt >= 0 && tt < T) ? lrelu(xr[tt]) : 0.f;
     }
     const float* ws = w + sig * w_sig;
     const float* bs = bias + sig * b_sig;
     act_t* yb = reinterpret_cast<act_t*>(y) + (long)z * C * ld;
-    const bool full = (t + 3 < T) && ((ld & 3) == 0);
+    const bool full = (t + SPT - 1 < T) && ((ld & (SPT - 1)) == 0);
     for (int co = 0; co < C; ++co) {
         const float w0 = ws[co * 3 + 0], w1 = ws[co * 3 + 1], w2 = ws[co * 3 + 2], bb = bs[co];
-        float o[4];
+        float o[SPT];
         #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = bb + (w0 * xv[i] + w1 * xv[i + 1]) + w2 * xv[i + 2];
+        for (int i = 0; i < SPT; ++i) o[i] = bb + (w0 * xv[i] + w1 * xv[i + 1]) + w2 * xv[i + 2];
         act_t* yr = yb + (long)co * ld + t;
 #ifdef FASTSVC_ACT_BF16
         if (full) {
-            u32x2v w;
-            w.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-            w.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
-            *reinterpret_cast<u32x2v*>(yr) = w;
+            u32x4 q;
+            q.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
+            q.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+            q.z = f32_to_bf16_bits(o[4]) | (f32_to_bf16_bits(o[5]) << 16);
+            q.w = f32_to_bf16_bits(o[6]) | (f32_to_bf16_bits(o[7]) << 16);
+            *reinterpret_cast<u32x4*>(yr) = q;
         } else {
-            for (int i = 0; i < 4 && t + i < T; ++i) yr[i] = (act_t)f32_to_bf16_bits(o[i]);
+            for (int i = 0; i < SPT && t + i < T; ++i) yr[i] = (act_t)f32_to_bf16_bits(o[i]);
         }
 #else
         if (full) {
             *reinterpret_cast<f32x4*>(yr) = f32x4{o[0], o[1], o[2], o[3]};
         } else {
-            for (int i = 0; i < 4 && t + i < T; ++i) yr[i] = o[i];
+            for (int i = 0; i < SPT && t + i < T; ++i) yr[i] = o[i];
         }
 #endif
     }
@@ -1280,7 +1288,7 @@ void in1_conv_kernel(const float* __restrict__ x, long x_sig, const float* __res
 
 hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const float* bias, long w_sig, long b_sig,
                            float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream) {
-    dim3 grid((T + 1023) / 1024, 1, nsig * B);
+    dim3 grid((T + 256 * IN1_SPT - 1) / (256 * IN1_SPT), 1, nsig * B);
     hipLaunchKernelGGL(in1_conv_kernel, grid, dim3(256), 0, stream, x, x_sig, w, bias, w_sig, b_sig, y, B, C, T, lens, len_mul);
     return hipGetLastError();
 }
