@@ -183,7 +183,8 @@ int fastsvc_forward_profile(const fastsvc_plan* plan, const void* dev_blob,
                             void* workspace, size_t workspace_bytes, void* stream,
                             fastsvc_launch_record* records, int32_t max_records, int32_t* n_records);
 
-/* Number of kernel launches one forward enqueues and algorithmic FLOPs (2*MAC of every conv /
+/* Number of kernel launches one forward enqueues at most (fused launches of the conditioning chains, chosen per
+ * call from its shapes and the launch table, lower it by up to n_stages + 1) and algorithmic FLOPs (2*MAC of every conv /
  * linear, de-duplicated dataflow) per output sample - used by bench.py's roofline accounting. */
 int fastsvc_forward_launch_count(const fastsvc_plan* plan, int32_t with_spk_emb);
 double fastsvc_flops_per_sample(const fastsvc_plan* plan);

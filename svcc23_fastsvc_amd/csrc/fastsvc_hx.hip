@@ -99,19 +99,21 @@ __device__ __forceinline__ HxFrag hx_read(const unsigned char* tile, int off, in
 // acc += a (.) w for one 16x16 tile and 32 input channels: hh + hl + lh (split) or one product (bf16).
 // Callers interleave independent accumulators between the products of one (the loops below run the product
 // index outermost) so that no MFMA waits for the previous one's result.
-template <int PROD>
+// SWAP: the operands trade places, i.e. the result tile comes out transposed - a lane then owns 4 consecutive
+// CHANNELS of one time step instead of 4 time steps of one channel (MODE_CHAIN writes that tile back to LDS in
+// the time-major operand format: 8-byte stores instead of 2-byte ones).
+template <int PROD, bool SWAP = false>
 __device__ __forceinline__ f32x4 hx_prod(const HxFrag& a, const u32x4 (&w)[HX_NP], f32x4 acc) {
-    if constexpr (HX_NP == 1) return hx_mfma(a.p[0], __builtin_bit_cast(hx8, w[0]), acc);
-    else if constexpr (PROD == 0) return hx_mfma(a.p[0], __builtin_bit_cast(hx8, w[0]), acc);
-    else if constexpr (PROD == 1) return hx_mfma(a.p[0], __builtin_bit_cast(hx8, w[1]), acc);
-    else return hx_mfma(a.p[1], __builtin_bit_cast(hx8, w[0]), acc);
+    constexpr int ia = (HX_NP == 2 && PROD == 2) ? 1 : 0, iw = (HX_NP == 2 && PROD == 1) ? 1 : 0;
+    if constexpr (SWAP) return hx_mfma(__builtin_bit_cast(hx8, w[iw]), a.p[ia], acc);
+    else return hx_mfma(a.p[ia], __builtin_bit_cast(hx8, w[iw]), acc);
 }
 constexpr int HX_NPROD = HX_NP == 2 ? 3 : 1;
 
 // One step = the MFMAs of ONE weight slot (MW channel tiles) on ONE time tile.  The steps of a unit run
 // slot-major, so that a slot's fragments are re-requested (for the next unit) right after their last use and
 // fly for a whole unit; the A fragments of step s+1 are read from LDS before the MFMAs of step s.
-template <int MW>
+template <int MW, bool SWAP = false>
 __device__ __forceinline__ void hx_step(f32x4 (&acc)[MW], const HxFrag& a, const u32x4* w /* [MW][HX_NP] */) {
     #pragma unroll
     for (int pr = 0; pr < HX_NPROD; ++pr)
@@ -120,9 +122,9 @@ __device__ __forceinline__ void hx_step(f32x4 (&acc)[MW], const HxFrag& a, const
             u32x4 wm[HX_NP];
             #pragma unroll
             for (int q = 0; q < HX_NP; ++q) wm[q] = w[m * HX_NP + q];
-            if (pr == 0) acc[m] = hx_prod<0>(a, wm, acc[m]);
-            else if (pr == 1) acc[m] = hx_prod<1>(a, wm, acc[m]);
-            else acc[m] = hx_prod<2>(a, wm, acc[m]);
+            if (pr == 0) acc[m] = hx_prod<0, SWAP>(a, wm, acc[m]);
+            else if (pr == 1) acc[m] = hx_prod<1, SWAP>(a, wm, acc[m]);
+            else acc[m] = hx_prod<2, SWAP>(a, wm, acc[m]);
         }
 }
 __device__ __forceinline__ HxFrag hx_neg(HxFrag a) {
@@ -137,9 +139,12 @@ __device__ __forceinline__ HxFrag hx_neg(HxFrag a) {
 
 // DIRECT unit: acc[n][m] += sum_tap X[t + (tap-1) d] W[tap].  aoff[tap]: this lane's byte offset of (row of
 // time tile 0 shifted by the tap, its octet).
-template <int MW, int NW, bool RELOAD>
+// OPT_LAST (MODE_CHAIN's first conv): transposed result tiles (hx_prod SWAP), and time tile NW-1 is computed only
+// when `do_last` (wave-uniform; the extra tile of the last wave along time) - a scalar branch around that
+// tile's MFMAs only (two whole copies of the unit under an if/else made hipcc spill).
+template <int MW, int NW, bool RELOAD, bool OPT_LAST = false>
 __device__ __forceinline__ void hx_unit_direct(f32x4 (&acc)[NW][MW], const unsigned char* tile, const int (&aoff)[3],
-                                               int lo_off, HxWeightStream<3 * MW * HX_NP>& ws) {
+                                               int lo_off, HxWeightStream<3 * MW * HX_NP>& ws, bool do_last = true) {
     constexpr int NSTEP = 3 * NW;
     HxFrag a[2];
     a[0] = hx_read(tile, aoff[0], lo_off);
@@ -150,7 +155,7 @@ __device__ __forceinline__ void hx_unit_direct(f32x4 (&acc)[NW][MW], const unsig
             a[(s + 1) & 1] = hx_read(tile, aoff[(s + 1) / NW] + ((s + 1) % NW) * 16 * HX_ROW, lo_off);
             __builtin_amdgcn_sched_barrier(0);                 // reads stay ahead of the MFMAs
         }
-        hx_step<MW>(acc[n], a[s & 1], &ws.wr[tap * MW * HX_NP]);
+        if (!OPT_LAST || n + 1 < NW || do_last) hx_step<MW, OPT_LAST>(acc[n], a[s & 1], &ws.wr[tap * MW * HX_NP]);
         if (RELOAD && n + 1 == NW) {                            // last use of this tap's fragments
             #pragma unroll
             for (int q = 0; q < MW * HX_NP; ++q) ws.request(tap * MW * HX_NP + q);
@@ -242,6 +247,44 @@ __device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int
         #pragma unroll
         for (int c = 0; c < 8; ++c) l[c] = (hx_t)(e[c] - (float)h[c]);
         *reinterpret_cast<hx8*>(tile + lo_off + off) = l;
+    }
+}
+
+// MODE_CHAIN: the first conv's result tiles -> the intermediate LDS tile the second conv reads, in the
+// producers' format (time-major rows of 32 channels, hi + lo pieces, same swizzle):
+//   T2[row][co] = split(lrelu(acc + bias_mid)),  0 where the column lies outside the utterance (the second
+//   conv's "same" zero padding).  The tiles are TRANSPOSED results (hx_prod SWAP): lane (t = lane & 15,
+//   g = lane >> 4) owns channels 4g .. 4g+3 of time step t = 8 bytes of a row.  row0 is a multiple of 16, so the
+//   swizzle of hx_lds_off depends on the lane only: one address per m, immediate offsets for n.
+typedef hx_t hx4 __attribute__((ext_vector_type(4)));
+template <int MW, int NA>
+__device__ __forceinline__ void hx_chain_store(const f32x4 (&acc)[NA][MW], int ntl, unsigned char* T2, int chunk_bytes,
+                                               int lo_off, int mg, int row0, int col0, int T, const f32x4 (&kb)[MW], int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int co0 = (mg * MW + m) * 16 + 4 * g;
+        unsigned char* base = T2 + (co0 >> 5) * chunk_bytes + hx_lds_off(row0 + l15, (co0 & 31) >> 3) + (co0 & 7) * 2;
+        #pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            if (n >= ntl) continue;
+            const bool inside = (unsigned)(col0 + n * 16 + l15) < (unsigned)T;
+            f32x4 v = acc[n][m] + kb[m];
+            #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaxf(v[e], v[e] * LRELU_SLOPE);
+                v[e] = inside ? v[e] : 0.f;
+#ifndef FASTSVC_ACT_BF16
+                v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);     // (saturates hi AND the value the low piece is cut from)
+#endif
+            }
+            const hx4 h = __builtin_convertvector(v, hx4);
+            *reinterpret_cast<hx4*>(base + n * 16 * HX_ROW) = h;
+            if constexpr (HX_NP == 2) {
+                const f32x4 back = __builtin_convertvector(h, f32x4);
+                *reinterpret_cast<hx4*>(base + lo_off + n * 16 * HX_ROW) = __builtin_convertvector(v - back, hx4);
+            }
+        }
     }
 }
 
@@ -521,10 +564,15 @@ constexpr int hx_min_waves() {
 template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S, bool WSTATIC>
 __global__ __launch_bounds__(512, (hx_min_waves<MW, NW, MODE, EPI>()))
 void conv_hx_kernel(const ConvParams p0) {
-    constexpr bool POLY = MODE == MODE_POLY, DEC2 = MODE == MODE_DEC2;
+    constexpr bool POLY = MODE == MODE_POLY, DEC2 = MODE == MODE_DEC2, CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1;
+    constexpr bool IN1 = MODE == MODE_CHAIN1;                          // the staging waves compute the stage's first conv
     constexpr int NT = 16 * NW * WN;                                   // (input-rate) columns per workgroup tile
+    // MODE_CHAIN: the first conv also produces the second one's halo (<= 4 columns per side): its tile starts 4
+    // columns early and is one 16-column MFMA tile longer (computed by the last wave along time)
+    constexpr int NTV = CHAIN ? NT + 16 : NT;                          // columns the staged window serves
+    constexpr int HB = CHAIN ? 4 : 0;                                  // aligned halo of the second conv
     constexpr int NPROD_T = 256;                                       // producer threads
-    constexpr int MAXW = NT + (MODE == MODE_DIRECT ? 56 : 8);          // halo <= 28 rows per side (1 for POLY / DEC2)
+    constexpr int MAXW = NTV + (MODE == MODE_DIRECT ? 56 : 8);         // halo <= 28 rows per side (POLY / DEC2: 1, CHAIN: <= 4)
     constexpr int ITEMS = (MAXW + NPROD_T - 1) / NPROD_T;              // (octet, 4 time steps) items per producer thread
     constexpr int NWS = DEC2 ? 4 : 3;                                  // weight slots per unit and channel tile
     constexpr int NVAR = DEC2 ? 2 : 1;                                 // tile variants: LeakyReLU'd (+ raw)
@@ -549,9 +597,9 @@ void conv_hx_kernel(const ConvParams p0) {
     }
     const int mg = blockIdx.y * WM + wave_m;
     const bool active = !producer && mg < p.ngroups;
-    const int halo = MODE == MODE_DIRECT ? p.dil : 1;
+    const int halo = (MODE == MODE_DIRECT || CHAIN) ? p.dil : 1;
     const int halo_al = (halo + 3) & ~3;
-    const int W = NT + 2 * halo_al;                                    // tile rows
+    const int W = NTV + 2 * halo_al;                                   // tile rows
     const int nch = p.nch32;
     const int CINp = nch * HX_KC;
     const int flags = p.flags;
@@ -592,10 +640,19 @@ void conv_hx_kernel(const ConvParams p0) {
     const int lo_off = (W + 4) * HX_ROW;                               // hi tile (+ 4 spare rows), then lo tile
     const int raw_off = HX_NP * (W + 4) * HX_ROW;                      // DEC2: the raw tile behind the LeakyReLU'd one
     const int bufsz = NVAR * HX_NP * (W + 4) * HX_ROW;
+    // MODE_CHAIN: the intermediate tile behind the two window buffers, [32-channel chunk][hi, lo][NT + 16 rows]
+    constexpr int T2ROWS = NT + 16;
+    constexpr int T2CHUNK = HX_NP * T2ROWS * HX_ROW;
+    unsigned char* T2 = tiles + 2 * bufsz;
+    const int t2bytes = CHAIN ? p.nch32b * T2CHUNK : 0;
 
     auto setup_shared = [&]() {
         if (flags & F_STATS) {
             for (int i = tid; i < 2 * 16 * MW * WM; i += 512) sstat[i] = 0.0;
+        }
+        if constexpr (CHAIN) {
+            // channel padding of the intermediate tile is never written: it must read as 0, not as LDS garbage
+            for (int i = tid * 16; i < t2bytes; i += 512 * 16) *reinterpret_cast<u32x4*>(T2 + i) = u32x4{0u, 0u, 0u, 0u};
         }
         // prologue coefficients of every input channel, applied by the producers as ONE FMA u * A + Bc:
         // InstanceNorm + speaker bias (u - mean) * rstd + p  ->  A = rstd, Bc = p - mean * rstd (fastsvc.py:134-139);
@@ -626,8 +683,9 @@ void conv_hx_kernel(const ConvParams p0) {
     if (producer) {
         // ================================ PRODUCER WAVES ================================
         const int ptid = tid - 256;
-        const __amdgpu_buffer_rsrc_t xr =
-            act_rsrc(p.x, (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
+        const __amdgpu_buffer_rsrc_t xr = IN1
+            ? make_rsrc(p.x + (long)sig * p.x_sig + (long)b * p.x_b, p.T)          // raw signal row: float32 whatever the storage
+            : act_rsrc(p.x, (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
         // item = (octet of 8 channels, quad of 4 rows); threads without an item park theirs in the 4 spare rows
         // behind the tile, so that the code below is straight-line (any branch between the loads and their use
         // makes hipcc wait vmcnt(0), i.e. for the NEXT unit's loads as well)
@@ -641,12 +699,25 @@ void conv_hx_kernel(const ConvParams p0) {
             it_q[i] = it_in[i] ? (idx >> 2) : (W >> 2);
         }
         const float slope = (DEC2 || (flags & F_PRE_LRELU)) ? LRELU_SLOPE : 1.0f;     // max(v, slope * v): identity for 1
+        // MODE_CHAIN1: taps and bias of the first conv for the 8 channels of this thread's item(s) (one octet per
+        // thread when ITEMS == 1, which the launcher guarantees)
+        float i1w[IN1 ? 8 : 1][3], i1b[IN1 ? 8 : 1];
+        if constexpr (IN1) {
+            #pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ci = it_oct[0] * 8 + c;
+                const bool ok = ci < p.CIN;
+                const float* wp = p.in1_w + (long)sig * p.in1_w_sig + (ok ? ci : 0) * 3;
+                i1w[c][0] = ok ? wp[0] : 0.f; i1w[c][1] = ok ? wp[1] : 0.f; i1w[c][2] = ok ? wp[2] : 0.f;
+                i1b[c] = ok ? p.in1_b[(long)sig * p.in1_b_sig + ci] : 0.f;
+            }
+        }
         // unconditional loads of unit `un`: 8 channels x 4 time steps per item; whatever lies outside the
         // tensor or the utterance reads as 0 through the descriptor (offset pushed out of range)
         auto pload = [&](int un, f32x4 (&px)[ITEMS][8], unsigned& tokmask) {
             const int tl = un / nch;
             const int ch = un - tl * nch;
-            const int t_start = (tile0 + tl) * NT - halo_al;
+            const int t_start = (tile0 + tl) * NT - HB - halo_al;
             const int soff = ch * HX_KC * p.ldx * 4;
             const int rows_left = p.CIN - ch * HX_KC;
             tokmask = 0;
@@ -655,6 +726,14 @@ void conv_hx_kernel(const ConvParams p0) {
                 const int t = t_start + 4 * it_q[i];
                 const bool tok = it_in[i] && (unsigned)t < (unsigned)p.T && un < nunits && !(p.dbg & DBG_NO_LOAD);
                 tokmask |= (tok ? 1u : 0u) << i;
+                if constexpr (IN1) {
+                    // six signal samples t-1 .. t+4 (a negative offset is out of range like any other: 0 = the
+                    // first conv's own zero padding)
+                    px[i][0] = buf_load4(xr, tok ? t * 4 : OOB_OFF, 0);
+                    px[i][1].x = buf_load1(xr, tok ? (t - 1) * 4 : OOB_OFF, 0);
+                    px[i][1].y = buf_load1(xr, tok ? (t + 4) * 4 : OOB_OFF, 0);
+                    continue;
+                }
                 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const int r = it_oct[i] * 8 + c;
@@ -675,6 +754,28 @@ void conv_hx_kernel(const ConvParams p0) {
         auto pcommit = [&](int un, const f32x4 (&px)[ITEMS][8], unsigned tokmask, unsigned char* tile) {
             if (p.dbg & DBG_NO_COMMIT) return;
             const int ch = un % nch;
+            if constexpr (IN1) {
+                #pragma unroll
+                for (int i = 0; i < ITEMS; ++i) {
+                    const float keep = ((tokmask >> i) & 1u) ? 1.f : 0.f;      // rows outside the utterance: the NEXT conv's zero padding
+                    float xv[6] = {px[i][1].x, px[i][0].x, px[i][0].y, px[i][0].z, px[i][0].w, px[i][1].y};
+                    #pragma unroll
+                    for (int q = 0; q < 6; ++q) xv[q] = fmaxf(xv[q], xv[q] * LRELU_SLOPE);
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float e[8];
+                        #pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            // (same association as in1_conv_kernel)
+                            const float u = (i1b[c] + (i1w[c][0] * xv[j] + i1w[c][1] * xv[j + 1]) + i1w[c][2] * xv[j + 2]) * keep;
+                            e[c] = fmaxf(u, u * slope);
+                        }
+                        hx_commit_slot(tile, hx_lds_off(4 * it_q[i] + j, it_oct[i]), lo_off, e);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                return;
+            }
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 // (A, Bc) of the item's 8 channels: 64 contiguous bytes
@@ -728,12 +829,14 @@ void conv_hx_kernel(const ConvParams p0) {
             pcommit(u + 1, pb, okb, tiles + bufsz);
             stamp(5);
             __syncthreads();                           // end of unit u
+            if (CHAIN && (u % nch) == nch - 1) __syncthreads();        // the consumers wrote the intermediate tile
             stamp(6);
             if (u + 1 >= nunits) break;
             pload(u + 3, pb, okb);
             pcommit(u + 2, pa, oka, tiles);
             stamp(5);
             __syncthreads();                           // end of unit u+1
+            if (CHAIN && ((u + 1) % nch) == nch - 1) __syncthreads();
             stamp(6);
         }
     } else {
@@ -743,8 +846,9 @@ void conv_hx_kernel(const ConvParams p0) {
         f32x4 acc2[2][DEC2 ? NW : 1][MW];             // decimating pair: k=3 / 1x1
         float s1[MW], s2[MW];
         HxWeightStream<NSLOT> wst;
+        const int wunits = CHAIN ? nch + p.nch32b : nch;    // weight units per tile (CHAIN: first conv's, then the second's)
         wst.init(reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
-                     (long)(active ? mg : 0) * nch * NSLOT * HX_FRAG, nch, lane);
+                     (long)(active ? mg : 0) * wunits * NSLOT * HX_FRAG, wunits, lane);
         int aoff[3];
         #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
@@ -791,6 +895,96 @@ void conv_hx_kernel(const ConvParams p0) {
         __syncthreads();                               // unit 0 staged
         stamp(4);
         int u = 0;
+        if constexpr (CHAIN) {
+            f32x4 accA[NW + 1][MW];                    // the first conv's tile; time tile NW only in the last wave along time
+            f32x4 k_mid[MW];                           // first conv's bias of this lane's 4 channels (transposed tiles)
+            #pragma unroll
+            for (int m = 0; m < MW; ++m)
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cot = (mg * MW + m) * 16 + 4 * (lane >> 4) + e;
+                    k_mid[m][e] = (active && cot < p.CMID) ? p.bias_mid[(long)sig * p.bias_mid_sig + cot] : 0.f;
+                }
+            // WSTATIC (one K chunk per conv: C <= 32): both convs' fragments stay in registers for the whole
+            // workgroup - `wst` holds the first conv's, `wstB` the second's; nothing is re-requested
+            HxWeightStream<NSLOT> wstB_static;
+            if constexpr (WSTATIC)
+                wstB_static.init(reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
+                                     ((long)(active ? mg : 0) * wunits + 1) * NSLOT * HX_FRAG, 1, lane);
+            HxWeightStream<NSLOT>& wstB = WSTATIC ? wstB_static : wst;
+            int aoffB[3];
+            #pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+                aoffB[tap] = hx_lds_off((HB - p.dil2) + tap * p.dil2 + wave_n * (NW * 16) + (lane & 15), lane >> 4);
+            constexpr int lo_offB = T2ROWS * HX_ROW;
+            const bool extra = wave_n == WN - 1;
+            for (int tl = 0; tl < ntiles; ++tl) {
+                const int tcol0 = (tile0 + tl) * NT + wave_n * (NW * 16);
+                // rank-1 residual (1-channel stage input): its row is fetched before the first conv, so that it
+                // is OLDER than every weight request the second conv waits for anyway
+                f32x4 rx[EPI == EPI_RANK1 ? NW : 1];
+                if constexpr (EPI == EPI_RANK1) {
+                    #pragma unroll
+                    for (int n = 0; n < NW; ++n) {
+                        const int t = tcol0 + n * 16 + (lane >> 4) * 4;
+                        rx[n] = buf_load4(R.r1x, (active && t < p.T) ? t * 4 : OOB_OFF, 0);
+                    }
+                }
+                #pragma unroll
+                for (int n = 0; n <= NW; ++n)
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m) accA[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // (no branch around the units and do-while loops: any path on which the loops' weight requests are
+                // not issued makes hipcc treat the residual loads as the YOUNGEST requests where they are used, i.e.
+                // wait for every weight request behind them - a memory latency per tile; FASTSVC_DBG has no
+                // no-MFMA switch in this mode for the same reason)
+                int ch = 0;
+                do {
+                    hx_unit_direct<MW, NW + 1, !WSTATIC, true>(accA, tiles + (u & 1) * bufsz, aoff, lo_off, wst, extra);
+                    stamp(7);
+                    __syncthreads();                   // end of unit u
+                    stamp(6);
+                    ++u;
+                } while (++ch < nch);
+                // every wave is past the previous tile's second conv (the barriers above): its tile may be overwritten
+                if (active)
+                    hx_chain_store<MW, NW + 1>(accA, extra ? NW + 1 : NW, T2, T2CHUNK, lo_offB, mg, wave_n * (NW * 16),
+                                               (tile0 + tl) * NT - HB + wave_n * (NW * 16), p.T, k_mid, lane);
+                // the stage's residual tensor (the 1x1 conv's output) is fetched HERE, into registers the first
+                // conv's tile has just left: it lands under the second conv instead of costing the epilogue a
+                // memory round trip per item
+                f32x4 rres[EPI == EPI_RES ? NW : 1][EPI == EPI_RES ? MW : 1];
+                #pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    const int t = tcol0 + n * 16 + (lane >> 4) * 4;
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m) {
+                        const int cot = (mg * MW + m) * 16 + (lane & 15);
+                        const bool ok = active && cot < p.COUT && t < p.T;
+                        if constexpr (EPI == EPI_RES) rres[n][m] = act_load4(R.res, ok ? (cot * p.ldy + t) * 4 : OOB_OFF, 0);
+                        if constexpr (EPI == EPI_RANK1) acc[n][m] = rx[n] * k_r1w[m] + k_r1b[m];
+                        else acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                __syncthreads();                       // intermediate tile complete
+                stamp(5);
+                int cb = 0;
+                do {
+                    hx_unit_direct<MW, NW, !WSTATIC>(acc, T2 + cb * T2CHUNK, aoffB, lo_offB, wstB);
+                } while (++cb < p.nch32b);
+                stamp(7);
+                if constexpr (EPI == EPI_RES) {
+                    #pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        #pragma unroll
+                        for (int m = 0; m < MW; ++m) acc[n][m] += rres[n][m];
+                }
+                #pragma unroll
+                for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
+                ws_epilogue_kind<MW, NW, EPI_PLAIN, false, 0>(p, R, acc, s1, s2, sig, mg, tcol0, active, lane, K, Ew);
+                stamp(8);
+            }
+        } else
         for (int tl = 0; tl < ntiles; ++tl) {
             #pragma unroll
             for (int n = 0; n < NW; ++n)
@@ -886,7 +1080,7 @@ template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S>
 static hipError_t hx_launch_kind(dim3 grid, size_t smem, hipStream_t stream, const ConvParams& p) {
     // the ring holds the whole layer when there is a single K chunk: nothing to re-request (MW = 2 layers: C_in <= 32)
     if constexpr (MW == 2) {
-        if (p.nch32 == 1) return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, true>>(grid, smem, stream, p);
+        if (p.nch32 == 1 && ((MODE != MODE_CHAIN && MODE != MODE_CHAIN1) || p.nch32b == 1)) return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, true>>(grid, smem, stream, p);
     }
     return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, false>>(grid, smem, stream, p);
 }
@@ -897,12 +1091,24 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
     const int ntx = (p.T + NT - 1) / NT;
     const int tpw = p.tpw > 0 ? p.tpw : 1;
     dim3 grid((ntx + tpw - 1) / tpw, (p.ngroups + WM - 1) / WM, nsig * p.B);
-    const int halo_al = MODE == MODE_DIRECT ? ((p.dil + 3) & ~3) : 4;
-    const int W = NT + 2 * halo_al;
+    constexpr bool CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1;
+    const int halo_al = (MODE == MODE_DIRECT || CHAIN) ? ((p.dil + 3) & ~3) : 4;
+    const int W = NT + (CHAIN ? 16 : 0) + 2 * halo_al;
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM + sizeof(float) * 2 * (size_t)p.nch32 * HX_KC +
-                        (size_t)2 * (MODE == MODE_DEC2 ? 2 : 1) * HX_NP * (W + 4) * HX_ROW;
+                        (size_t)2 * (MODE == MODE_DEC2 ? 2 : 1) * HX_NP * (W + 4) * HX_ROW +
+                        (CHAIN ? (size_t)p.nch32b * HX_NP * (NT + 16) * HX_ROW : 0);
     const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
-    if constexpr (MODE == MODE_DEC2) {
+    if constexpr (MODE == MODE_CHAIN1) {
+        if (aff || !p.r1x || smem > 160 * 1024) return hipErrorInvalidValue;
+        return hx_launch_kind<MW, NW, WM, WN, MODE_CHAIN1, EPI_RANK1, 1>(grid, smem, stream, p);
+    } else if constexpr (MODE == MODE_CHAIN) {
+        if (aff || smem > 160 * 1024) return hipErrorInvalidValue;
+        const int kind = p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
+#define FASTSVC_HXC(k) if (kind == k) return hx_launch_kind<MW, NW, WM, WN, MODE_CHAIN, k, 1>(grid, smem, stream, p);
+        FASTSVC_HXC(EPI_PLAIN) FASTSVC_HXC(EPI_RES) FASTSVC_HXC(EPI_RANK1)
+#undef FASTSVC_HXC
+        return hipErrorInvalidValue;
+    } else if constexpr (MODE == MODE_DEC2) {
         return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 1>(grid, smem, stream, p);
     } else if constexpr (MODE == MODE_POLY) {
 #define FASTSVC_HXP(sv) \
@@ -942,6 +1148,18 @@ hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_
         if (p.dil != 1) return hipErrorInvalidValue;
         FASTSVC_HXS(MODE_POLY, 2, 2, 1, 4) FASTSVC_HXS(MODE_POLY, 2, 3, 1, 4)
         FASTSVC_HXS(MODE_POLY, 3, 2, 1, 4) FASTSVC_HXS(MODE_POLY, 3, 2, 2, 2)
+    } else if (p.mode == MODE_CHAIN) {
+        // every workgroup holds the WHOLE intermediate tensor slice: one workgroup row of channel groups
+        if (p.dil < 1 || p.dil > 4 || p.dil2 < 1 || p.dil2 > 4 || !p.bias_mid || p.CMID != p.COUT) return hipErrorInvalidValue;
+        if (p.ngroups > cfg.WM) return hipErrorInvalidValue;
+        FASTSVC_HXS(MODE_CHAIN, 2, 2, 1, 4) FASTSVC_HXS(MODE_CHAIN, 2, 3, 1, 4)
+        FASTSVC_HXS(MODE_CHAIN, 3, 2, 1, 4) FASTSVC_HXS(MODE_CHAIN, 3, 3, 1, 4)
+        FASTSVC_HXS(MODE_CHAIN, 3, 4, 2, 2) FASTSVC_HXS(MODE_CHAIN, 3, 6, 2, 2)
+    } else if (p.mode == MODE_CHAIN1) {
+        // (tiles of <= 192 columns: one staging item per thread, which the first conv's per-thread taps rely on)
+        if (p.dil < 1 || p.dil > 4 || p.dil2 < 1 || p.dil2 > 4 || !p.bias_mid || p.CMID != p.COUT || p.CIN > 32 ||
+            !p.in1_w || !p.in1_b || p.ngroups > cfg.WM) return hipErrorInvalidValue;
+        FASTSVC_HXS(MODE_CHAIN1, 2, 2, 1, 4) FASTSVC_HXS(MODE_CHAIN1, 2, 3, 1, 4)
     } else if (p.mode == MODE_DEC2) {
         if (p.dil != 1 || !p.bias2 || !p.y2) return hipErrorInvalidValue;
         FASTSVC_HXS(MODE_DEC2, 3, 2, 1, 4) FASTSVC_HXS(MODE_DEC2, 3, 3, 1, 4) FASTSVC_HXS(MODE_DEC2, 3, 2, 2, 2)
@@ -957,6 +1175,10 @@ bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN) {
                (MW == 3 && NW == 2 && ((WM == 1 && WN == 4) || (WM == 2 && WN == 2)));
     if (mode == MODE_DEC2)
         return MW == 3 && ((WM == 1 && WN == 4 && (NW == 2 || NW == 3)) || (WM == 2 && WN == 2 && NW == 2));
+    if (mode == MODE_CHAIN1) return MW == 2 && WM == 1 && WN == 4 && (NW == 2 || NW == 3);
+    if (mode == MODE_CHAIN)
+        return (WM == 1 && WN == 4 && (MW == 2 || MW == 3) && (NW == 2 || NW == 3)) ||
+               (MW == 3 && WM == 2 && WN == 2 && (NW == 4 || NW == 6));
     if (mode != MODE_DIRECT) return false;
     if (MW == 2) return WM == 1 && WN == 4 && (NW == 2 || NW == 3);
     if (MW != 3) return false;

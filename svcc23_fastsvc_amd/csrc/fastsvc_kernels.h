@@ -32,7 +32,16 @@ enum : int {
     // decimated input h[..., ::s];  y = Conv3_d1(lrelu(hd)) + bias  and  y2 = Conv1x1(hd) + bias2.
     // The window is staged raw, the consumer applies LeakyReLU to the three tap operands and feeds a
     // second accumulator set with the raw centre column; 4 weight "taps" per k-group (w0 w1 w2 | w1x1).
-    MODE_DEC2 = 5
+    MODE_DEC2 = 5,
+    // Two k=3 convs back to back in ONE launch (half-precision MFMA kernels only; the c2 -> c3 pair of a down
+    // stage, fastsvc.py:174-177):  y = ConvB_dil2(lrelu(ConvA_dil(pre(x)) + bias_mid)) + bias [+ epilogue].
+    // The intermediate tile (with ConvB's halo, zero outside the utterance = ConvB's "same" padding) never
+    // leaves LDS: one launch boundary and one tensor write + read less.
+    MODE_CHAIN = 6,
+    // MODE_CHAIN behind the FIRST conv of down stage 0 (k=3, 1 input channel, fastsvc.py:172-173): x is the raw
+    // 1-channel signal (always float32) and the staging waves compute lrelu(conv3(lrelu(x)) + b1) on the fly
+    // instead of loading a C-channel tensor - the whole stage is one launch that only writes its output.
+    MODE_CHAIN1 = 7
 };
 
 enum : int {
@@ -67,6 +76,13 @@ struct ConvParams {
     long whx_sig;                // lft -> sine stride in BYTES (paired convs)
     int nch32;                   // 32-channel K chunks = ceil(CIN / 32)
     int stagger;                 // start delay (x 1024 cycles) of the second workgroup of a CU (two-per-CU variants)
+    // MODE_CHAIN: the second conv (CMID -> COUT, dilation dil2); the first one maps CIN -> CMID with `dil`
+    const float* bias_mid;       // bias of the first conv (added before the LeakyReLU in between)
+    long bias_mid_sig;
+    const float* in1_w;          // MODE_CHAIN1: first conv's raw weights (CIN, 1, 3) and bias (CIN)
+    const float* in1_b;
+    long in1_w_sig, in1_b_sig;
+    int CMID, nch32b, dil2;      // nch32b = ceil(CMID / 32); whx holds [nch32 units of A | nch32b units of B] per group
     int ngroups;                 // number of 16*MW-row groups
     // destination (nsig, B, COUT, T); y may be null when only the FiLM-affine output y2 is needed
     float* y;

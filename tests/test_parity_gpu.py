@@ -307,7 +307,8 @@ def test_profile_records_cover_every_launch(dev):
     b = S.synth_batch(cfg, 2, 20, 4)
     recs = []
     y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), profile=recs)
-    assert len(recs) == plan.launch_count(True)
+    # launch_count is the unfused schedule; fused conditioning-chain launches save up to 2 (stage 0) + 1 per stage
+    assert plan.launch_count(True) - (cfg.n_stages + 1) <= len(recs) <= plan.launch_count(True)
     assert all(r["ms"] > 0 for r in recs)
     total = sum(r["flops"] for r in recs)
     assert abs(total / (2 * 20 * 160) / plan.flops_per_sample - 1) < 0.02
@@ -333,6 +334,58 @@ def test_autotuned_launch_shapes_keep_parity(dev):
     for y in (y0, y1, y2):
         assert float((y - ref).abs().max()) <= TIGHT
     assert float((y0 - y2).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("storage", ["float32", "bfloat16"])
+def test_fused_conditioning_stages_match_the_separate_launches(dev, storage):
+    """A down stage's c2 -> c3 pair runs as ONE launch where the stage has the variant (kernel mode 6: the
+    intermediate tile stays in LDS) and stage 0 as one launch altogether (mode 7: its 1 -> C conv is computed by
+    the staging waves from the raw signal).  Same oracle tolerance as the separate launches, which a launch table
+    with algorithm 0 under the fused keys selects; ragged batches included (the intermediate tile's zero padding
+    follows each utterance's own length)."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 91)
+    B, F = 3, 44
+    lengths = [44, 29, 8]
+    b = S.synth_batch(cfg, B, F, 92)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    hop = cfg.hop
+    sfx = "|b" if storage == "bfloat16" else ""
+    n = cfg.n_stages
+    Ts, T = [], F * hop
+    for k in range(n):
+        T //= ([1] + list(reversed(cfg.upsampling_scales[1:])))[k]
+        Ts.append(T)
+    unfused = {f"down.{k}.c23|{B}|{Ts[k]}{sfx}": [3, 1, 4, 1, 0] for k in range(n)}
+    unfused[f"down.0.c123|{B}|{Ts[0]}{sfx}"] = [3, 1, 4, 1, 0]
+    outs = {}
+    for name, table in (("fused", {}), ("separate", unfused)):
+        plan = A.Plan(cfg, load_shipped_table=False, storage=storage)
+        plan.load_tuned(table)
+        blob = plan.pack(sd).to(dev)
+        recs = []
+        y = plan.forward(blob, *ins, profile=recs)
+        yr = plan.forward(blob, *ins, lengths=lengths)
+        modes = sorted({int(r["kernel"].split(",")[4]) for r in recs if r["kernel"].startswith("conv_hx")})
+        outs[name] = (y.cpu(), yr.cpu(), modes, len(recs))
+    assert 6 in outs["fused"][2] and 7 in outs["fused"][2]
+    assert 6 not in outs["separate"][2] and 7 not in outs["separate"][2]
+    assert outs["fused"][3] < outs["separate"][3]
+    ref = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)
+    tol = TIGHT if storage == "float32" else 0.25
+    for name in outs:
+        assert float((outs[name][0] - ref).abs().max()) <= tol
+    close = 2e-5 if storage == "float32" else 0.25
+    assert float((outs["fused"][0] - outs["separate"][0]).abs().max()) <= close
+    assert float((outs["fused"][1] - outs["separate"][1]).abs().max()) <= close
+    # each utterance of the ragged batch equals the same utterance run alone
+    plan = A.Plan(cfg, load_shipped_table=False, storage=storage)
+    blob = plan.pack(sd).to(dev)
+    for i, L in enumerate(lengths):
+        one = plan.forward(blob, *[t[i:i + 1, ..., :L * (hop if t.shape[-1] == F * hop else 1)].contiguous() for t in ins[:3]],
+                           ins[3][i:i + 1]).cpu()
+        assert float((outs["fused"][1][i:i + 1, ..., :L * hop] - one).abs().max()) <= close
 
 
 @pytest.mark.parametrize("F,expect_poly", [(40, (True, True, True, True)), (42, (True, True, True, True)),
@@ -408,6 +461,7 @@ def test_winograd_time_convs_match_oracle_taps(dev, algo):
     for k in (1, 2, 3):                            # stage 0 has C = 24: not eligible
         for layer in ("c2_d2", "c3_d4"):
             table[f"down.{k}.{layer}|{B}|{rates[k]}"] = [1, 1, 4, 1, algo]
+        table[f"down.{k}.c23|{B}|{rates[k]}"] = [3, 1, 4, 1, 0]      # the pair as two launches (algorithm 0 under the fused key)
         table[f"film.{k}.conv|{B}|{rates[k]}"] = [1, 1, 4, 2, algo]
         table[f"film.{k}.heads|{B}|{rates[k]}"] = [1, 1, 4, 1, algo]
     table[f"film.0.heads|{B}|{rates[0]}"] = [2 if algo == 1 else 1, 1, 4, 3, algo]
@@ -575,11 +629,13 @@ def test_half_precision_and_f32_mfma_families_agree(dev):
     ws_hx = torch.zeros(p_hx.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
     recs = []
     y_hx = p_hx.forward(blob, *ins, workspace=ws_hx, profile=recs)
-    n_hx = sum(1 for r in recs if r["kernel"].startswith("conv_hx<"))
-    assert n_hx == 43, sorted((r["layer"], r["kernel"]) for r in recs)     # all convs but in1 / conv_last
+    # every conv but conv_last (stage 0 runs as one fused launch, in1_conv included)
+    assert all(r["kernel"].startswith("conv_hx<") for r in recs if r["layer"] not in ("conv_last", "spk_proj")), \
+        sorted((r["layer"], r["kernel"]) for r in recs)
     p_32 = A.Plan(cfg, load_shipped_table=False)
-    p_32.load_tuned({f"{r['layer']}|{B}|{t}": [1, 1, 4, 1, 0] for r in recs
-                     for t in (F, 2 * F, 8 * F, 32 * F, 160 * F)})          # algo 0 = the f32-input MFMA kernels
+    layers = {r["layer"] for r in recs} | {f"down.{k}.{c}" for k in range(cfg.n_stages) for c in ("c2_d2", "c3_d4", "c23")}
+    p_32.load_tuned({f"{layer}|{B}|{t}": [1, 1, 4, 1, 0] for layer in layers
+                     for t in (F, 2 * F, 8 * F, 32 * F, 160 * F)})          # algo 0 = the f32-input MFMA kernels, unfused
     ws_32 = torch.zeros(p_32.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
     recs32 = []
     y_32 = p_32.forward(blob, *ins, workspace=ws_32, profile=recs32)

@@ -71,7 +71,8 @@ def test_cfg3_full_size_with_the_shipped_table(dev, storage):
         else:
             assert float(err.mean()) <= BF16_MEAN and float(err.max()) <= BF16_MAX
         alone = plan.forward(blob, *[t[i:i + 1] for t in ins])
-        assert float((alone - y1[i:i + 1]).abs().max()) <= (2e-5 if storage == "float32" else 5e-2)
+        # (bfloat16: other tile shapes round other elements; a few bf16 ulps of the unit-scale waveform)
+        assert float((alone - y1[i:i + 1]).abs().max()) <= (2e-5 if storage == "float32" else 1e-1)
 
 
 def _free_port():
