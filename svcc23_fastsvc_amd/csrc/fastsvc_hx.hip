@@ -444,6 +444,7 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
                 for (int e = 0; e < 4; ++e) { v.lo[e] = fmaxf(v.lo[e], v.lo[e] * slope); v.hi[e] = fmaxf(v.hi[e], v.hi[e] * slope); }
                 if (EPI == EPI_RES || EPI == EPI_AFF) { v.lo += l0[g].lo; v.hi += l0[g].hi; }
                 if (EPI == EPI_RANK1) { v.lo += l0[g].lo * r1w + r1b; v.hi += l0[g].hi * r1w + r1b; }
+                acc[2 * (k0 + g)][m] = v.lo; acc[2 * (k0 + g) + 1][m] = v.hi;     // (finished values, in the pair layout)
                 act_store8(R.y, boff[g], v, nv[g]);                // dropped when y is absent
                 if (EPI == EPI_AFF) {
                     f32x8 u;
@@ -557,6 +558,30 @@ constexpr int hx_min_waves() {
     // bound by their store phase) where the producers' two register sets (2 x 32), the unit-deep weight ring
     // (12 * MW) and the accumulators fit; else 256
     return (MODE == MODE_DIRECT && MW == 2 && (EPI == EPI_PLAIN || EPI == EPI_RANK1 || EPI == EPI_RES)) ? 4 : 2;
+}
+
+// conv_last behind the last block's conv (ConvParams::last_w): acc holds the block's finished output tile of ALL
+// C channels (one channel group): y[t] = sum_co last_w[co] * out[co][t] + last_b.  Lanes 0..15 of a row quad hold
+// the 16 channels of a tile: a 4-step butterfly over them, lane 0 of the quad stores 4 samples.  PAIRS: acc is in
+// the 8-wide pair layout of hx_epilogue8 (tile 2k = samples 0..3, tile 2k+1 = samples 4..7 of the lane's 8).
+template <int MW, int NW, bool PAIRS>
+__device__ __forceinline__ void hx_last_reduce(const ConvParams& p, const f32x4 (&acc)[NW][MW], const float (&kw)[MW],
+                                               int b, int tcol0, int lane) {
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.last_y + (long)b * p.last_y_b, p.ldy);
+    const float bias = p.last_b[0];
+    #pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        f32x4 s = acc[n][0] * kw[0];
+        #pragma unroll
+        for (int m = 1; m < MW; ++m) s += acc[n][m] * kw[m];
+        #pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            s.x += __shfl_xor(s.x, d); s.y += __shfl_xor(s.y, d);
+            s.z += __shfl_xor(s.z, d); s.w += __shfl_xor(s.w, d);
+        }
+        const int t = PAIRS ? tcol0 + (n >> 1) * 32 + (lane >> 4) * 8 + (n & 1) * 4 : tcol0 + n * 16 + (lane >> 4) * 4;
+        buf_store4(yr, ((lane & 15) == 0 && t < p.T) ? t * 4 : OOB_OFF, s + bias);
+    }
 }
 
 // MODE: MODE_DIRECT (any dilation <= 28), MODE_POLY (S = stretch factor; tiles walk the INPUT columns) or
@@ -880,6 +905,13 @@ void conv_hx_kernel(const ConvParams p0) {
             }
         }
         const EpiConst<MW, true> K{k_bias, k_bias2, k_r1w, k_r1b};
+        constexpr bool LAST_OK = MODE == MODE_DIRECT && EPI == EPI_RES && WM == 1;     // conv_last may ride on this instance
+        float k_last[MW];
+        #pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int cot = (mg * MW + m) * 16 + (lane & 15);
+            k_last[m] = (LAST_OK && p.last_w && active && cot < p.COUT) ? p.last_w[cot] : 0.f;
+        }
         constexpr bool EST = hx_estage<MW, NW, MODE, EPI>();
         // this wave's epilogue-operand slots, behind the tile buffers (hx_launch_direct sizes them)
         constexpr bool PAIRS = hx_pairs_epi<MW, NW, MODE>();
@@ -1035,6 +1067,10 @@ void conv_hx_kernel(const ConvParams p0) {
 #endif
                         ws_epilogue_kind<MW, NW, EPI, EST, 0>(p, R, acc, s1, s2, sig, mg,
                                                               (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
+                        if constexpr (LAST_OK) {
+                            if (p.last_w && !(p.dbg & DBG_NO_EPILOGUE))
+                                hx_last_reduce<MW, NW, PAIRS>(p, acc, k_last, b, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
+                        }
                     }
                     if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
                         #pragma unroll

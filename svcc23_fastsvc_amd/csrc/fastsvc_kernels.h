@@ -79,6 +79,13 @@ struct ConvParams {
     // MODE_CHAIN: the second conv (CMID -> COUT, dilation dil2); the first one maps CIN -> CMID with `dil`
     const float* bias_mid;       // bias of the first conv (added before the LeakyReLU in between)
     long bias_mid_sig;
+    // conv_last fused behind the last block's conv (half-precision MFMA kernels, residual epilogue, one channel
+    // group, one output channel; fastsvc.py:301,330): the wave that holds all C channels of its time steps also
+    // reduces them, wave = last_w . (conv + res) + last_b, and the C-channel tensor is not written (y = null)
+    const float* last_w;         // (1, C)
+    const float* last_b;         // (1)
+    float* last_y;               // (B, 1, ldy) float32
+    long last_y_b;
     const float* in1_w;          // MODE_CHAIN1: first conv's raw weights (CIN, 1, 3) and bias (CIN)
     const float* in1_b;
     long in1_w_sig, in1_b_sig;

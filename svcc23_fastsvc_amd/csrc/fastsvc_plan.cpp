@@ -811,6 +811,8 @@ struct TuneCtx {
     int trials = 0;
 };
 thread_local TuneCtx g_tune;
+// set by run_conv when the launch it made also computed conv_last (ConvParams::last_w accepted)
+thread_local bool g_last_fused = false;
 
 
 #ifdef FASTSVC_TIMELINE
@@ -1080,6 +1082,16 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                     !(p.mode == MODE_DIRECT && epi_kind >= 3 && sh[0] * c.MW > 12))   // FiLM-affine / rank-1 epilogues: those tiles spill
                     cands.push_back(Cand{sh[0], sh[1], sh[2], 3});
         }
+        if (p.last_w) {
+            // conv_last rides on the half-precision instances with one workgroup row of channel groups; it saves a
+            // launch and a write + read of the block's output, more than any shape of the other family wins back:
+            // only those candidates, timed as they will run (no store of the C-channel tensor)
+            std::vector<Cand> keep;
+            if (hx_ok && c.ngroups == 1 && p.mode == MODE_DIRECT && p.res && !p.r1x && !(p.flags & (F_STATS | F_AFF_OUT)))
+                for (const Cand& cd : cands) if (cd.algo == 3 && cd.WM == 1) keep.push_back(cd);
+            if (!keep.empty()) { cands.swap(keep); p.y = nullptr; }
+            else p.last_w = nullptr;
+        }
         if ((p.T & 3) != 0 || (p.lens && (p.len_mul & 3) != 0)) {
             // rows that are not a multiple of 4 long (with a ragged batch: ANY utterance's own length,
             // whatever the padded maximum is): only the variants compiled with the row-end handling
@@ -1238,6 +1250,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         }
         L.pipe = best.algo == 3 ? 2 : 1;
         L.NW = best.NW; L.WM = best.WM; L.WN = best.WN;
+        if (p.last_w) g_last_fused = true;                  // (the candidates were restricted to the instances that have it)
         if (best.algo == 2) L.MW = 2;
         geometry(best, p);
         {
@@ -1247,6 +1260,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                              L.MW, L.NW, L.WM, L.WN, p.tpw);
         }
     } else {
+        p.last_w = nullptr;
         int NW = 4;
         while (NW > 1 && ((p.T + 64 * NW - 1) / (64 * NW)) * zb * c.ngroups < 768) NW >>= 1;
         L.NW = NW;
@@ -1267,7 +1281,12 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (p.res) el += (double)c.cout * T_out;
         if (p.r1x) el += (double)T_out;
         if (p.flags & (F_STATS | F_AFF_OUT)) el += 2.0 * c.cout * T_out;
-        const double bytes = (act_bf16 ? 2.0 : 4.0) * el * p.B * nsig + 4.0 * (double)(c.w_floats + c.b_floats) * nsig;
+        double bytes = (act_bf16 ? 2.0 : 4.0) * el * p.B * nsig + 4.0 * (double)(c.w_floats + c.b_floats) * nsig;
+        double flops_all = flops;
+        if (p.last_w) {                                   // + conv_last: C -> 1, float32 waveform out (the C-channel tensor is not written: p.y is null)
+            flops_all += 2.0 * c.cout * cols;
+            bytes += 4.0 * cols;
+        }
         char kname[40];
         if (L.pipe == 2) {
             const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
@@ -1288,7 +1307,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         }
         else
             std::snprintf(kname, sizeof(kname), "conv_mfma<%d,%d,1,4>", L.MW, L.NW);
-        hipError_t e = prof->begin(stream, layer, kname, flops, bytes);
+        hipError_t e = prof->begin(stream, layer, kname, flops_all, bytes);
         if (e != hipSuccess) return e;
         e = launch(p, L, stream);
         if (e != hipSuccess) return e;
@@ -1614,6 +1633,16 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     }
     int Cx = P.cfg.in_channels;
     long Tin = F;
+    bool last_done = false;
+    bool last_fusable = true;
+    {
+        static const bool no_fuse = std::getenv("FASTSVC_NO_FUSE_LAST") != nullptr;     // A/B switch
+        char key[96];
+        std::snprintf(key, sizeof(key), P.storage == 1 ? "conv_last|%d|%ld|b" : "conv_last|%d|%ld", B, (long)T);
+        std::lock_guard<std::mutex> lock(P.tune_mu);
+        auto it = P.tuned.find(key);
+        if (no_fuse || (it != P.tuned.end() && it->second.algo != 3)) last_fusable = false;
+    }
     for (int i = 0; i < n; ++i) {
         const UpStage& u = P.up[i];
         const int k = n - 1 - i;
@@ -1678,12 +1707,23 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.flags = pre; p.ss_out = nullptr; p.st_out = nullptr; p.y2 = nullptr;
         p.res = xm; p.res_b = cb;
         p.y = xo; p.y_b = cb;
+        if (i == n - 1 && P.cfg.out_channels == 1 && last_fusable) {
+            // conv_last in the same launch where the launch has the variant (run_conv decides; the block's
+            // C-channel output is then not materialised - a launch table with algorithm 0 under "conv_last|B|T"
+            // keeps the two launches, e.g. to read the `up.<n-1>.out` tap)
+            p.last_w = blob + P.last.w_off; p.last_b = blob + P.last.b_off;
+            p.last_y = out; p.last_y_b = (long)P.cfg.out_channels * T;
+            if (lengths) HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * T, stream));   // ragged batch: zero padding of the waveform
+        }
+        g_last_fused = false;
         HIP_TRY(run_conv(u.d27, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d27").c_str()));
+        if (i == n - 1) last_done = g_last_fused;
 
         x = xo; Cx = u.C; Tin = Tout;
     }
 
     // ---- conv_last ----
+    if (last_done) return FASTSVC_OK;
     if (prof) HIP_TRY(prof->begin(stream, "conv_last", "pointwise_out", 2.0 * Cx * P.cfg.out_channels * (double)T * B,
                                   4.0 * (Cx + P.cfg.out_channels) * (double)T * B));
     HIP_TRY((P.storage == 1 ? bf16::launch_pointwise_out : launch_pointwise_out)(x, blob + P.last.w_off, blob + P.last.b_off, out, B, Cx,

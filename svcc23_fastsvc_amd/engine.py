@@ -201,6 +201,15 @@ class Plan:
             _check(self.lib, self.lib.fastsvc_tuned_set(self._h, k.encode(), ctypes.byref(shape)), "fastsvc_tuned_set")
         return len(table)
 
+    def keep_last_block_output(self, B: int, F: int) -> None:
+        """By default ``conv_last`` rides on the last block's final launch and the block's C-channel output is not
+        written.  This keeps the two launches for batches of this shape (launch-table entry with algorithm 0
+        under ``conv_last|B|T``), so that the ``up.<n-1>.out`` workspace tap holds the tensor."""
+        T = F
+        for sc in self.cfg.upsampling_scales:
+            T *= int(sc)
+        self.load_tuned({f"conv_last|{B}|{T}": [1, 1, 4, 1, 0], f"conv_last|{B}|{T}|b": [1, 1, 4, 1, 0]})
+
     def load_tuned_file(self, path: str, missing_ok: bool = False) -> int:
         """Load this configuration's section of a tuned-shape JSON file (tools/tune_shapes.py)."""
         if not os.path.exists(path):

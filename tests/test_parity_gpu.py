@@ -173,6 +173,7 @@ def test_frame_counts_not_multiple_of_four_stay_on_the_fast_path(dev, F):
     B = 3
     b = S.synth_batch(cfg, B, F, 62)
     plan = A.Plan(cfg)
+    plan.keep_last_block_output(B, F)                  # the `up.3.out` tap below (else conv_last rides on up.3.d27)
     blob = plan.pack(sd).to(dev)
     ws = torch.zeros(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
     recs = []
@@ -386,6 +387,39 @@ def test_fused_conditioning_stages_match_the_separate_launches(dev, storage):
         one = plan.forward(blob, *[t[i:i + 1, ..., :L * (hop if t.shape[-1] == F * hop else 1)].contiguous() for t in ins[:3]],
                            ins[3][i:i + 1]).cpu()
         assert float((outs["fused"][1][i:i + 1, ..., :L * hop] - one).abs().max()) <= close
+
+
+@pytest.mark.parametrize("storage", ["float32", "bfloat16"])
+def test_conv_last_rides_on_the_last_block(dev, storage):
+    """conv_last (fastsvc.py:301,330; C -> 1) is computed by the epilogue of the last block's final conv where that
+    launch holds all C channels in one wave (the C-channel tensor is then never written); `keep_last_block_output`
+    keeps the two launches.  Same waveform either way, ragged batches keep their zero padding."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 95)
+    B, F = 2, 52
+    b = S.synth_batch(cfg, B, F, 96)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    ys = []
+    for keep in (False, True):
+        plan = A.Plan(cfg, load_shipped_table=False, storage=storage)
+        if keep:
+            plan.keep_last_block_output(B, F)
+        blob = plan.pack(sd).to(dev)
+        recs = []
+        y = plan.forward(blob, *ins, profile=recs).cpu()
+        yr = plan.forward(blob, *ins, lengths=[52, 20]).cpu()
+        assert ("conv_last" in {r["layer"] for r in recs}) == keep
+        total = sum(r["flops"] for r in recs)
+        assert abs(total / (B * F * cfg.hop) / plan.flops_per_sample - 1) < 0.02       # conv_last's work is still accounted
+        assert float(yr[1, :, 20 * cfg.hop:].abs().max()) == 0.0
+        ys.append((y, yr))
+    ref = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)
+    tol = TIGHT if storage == "float32" else 0.25
+    assert float((ys[0][0] - ref).abs().max()) <= tol
+    close = 2e-5 if storage == "float32" else 0.1
+    assert float((ys[0][0] - ys[1][0]).abs().max()) <= close
+    assert float((ys[0][1] - ys[1][1]).abs().max()) <= close
 
 
 @pytest.mark.parametrize("F,expect_poly", [(40, (True, True, True, True)), (42, (True, True, True, True)),
@@ -625,6 +659,7 @@ def test_half_precision_and_f32_mfma_families_agree(dev):
     b = S.synth_batch(cfg, B, F, 62)
     ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
     p_hx = A.Plan(cfg, load_shipped_table=False)       # cost model: the half-precision family wherever it exists
+    p_hx.keep_last_block_output(B, F)                  # (the up.3.out tap is compared below)
     blob = p_hx.pack(sd).to(dev)
     ws_hx = torch.zeros(p_hx.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
     recs = []

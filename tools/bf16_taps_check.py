@@ -14,6 +14,7 @@ sd = S.synth_state_dict(cfg, 81)
 b = S.synth_batch(cfg, B, F, 82)
 ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
 p32, p16 = A.Plan(cfg), A.Plan(cfg, storage="bfloat16")
+p32.keep_last_block_output(B, F); p16.keep_last_block_output(B, F)      # the up.3.out tap
 blob = p32.pack(sd).to(dev)
 w32 = torch.zeros(p32.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
 w16 = torch.zeros(p16.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
