@@ -710,7 +710,9 @@ void conv_hx_kernel(const ConvParams p0) {
         const int ptid = tid - 256;
         const __amdgpu_buffer_rsrc_t xr = IN1
             ? make_rsrc(p.x + (long)sig * p.x_sig + (long)b * p.x_b, p.T)          // raw signal row: float32 whatever the storage
-            : act_rsrc(p.x, (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
+            : act_rsrc(p.x, (long)sig * p.x_sig + (long)b * p.x_b,
+                       p.xsplit > 0 ? p.x_sig + (long)p.xsplit * p.ldx : (long)p.CIN * p.ldx);
+        const int xsplit_off = (int)(p.x_sig * 4);                                  // "float bytes" (the host bounds it below 2^31)
         // item = (octet of 8 channels, quad of 4 rows); threads without an item park theirs in the 4 spare rows
         // behind the tile, so that the code below is straight-line (any branch between the loads and their use
         // makes hipcc wait vmcnt(0), i.e. for the NEXT unit's loads as well)
@@ -769,6 +771,12 @@ void conv_hx_kernel(const ConvParams p0) {
                         px[i][c].y = act_load1(xr, o + 4 * p.s, soff);
                         px[i][c].z = act_load1(xr, o + 8 * p.s, soff);
                         px[i][c].w = act_load1(xr, o + 12 * p.s, soff);
+                    } else if constexpr (CHAIN) {
+                        // (general addressing: the channel may live in the second signal's tensor, ConvParams::xsplit)
+                        const int cc = ch * HX_KC + r;
+                        const bool second = p.xsplit > 0 && cc >= p.xsplit;
+                        const int row = second ? cc - p.xsplit : cc;
+                        px[i][c] = act_load4(xr, (tok && r < rows_left) ? (row * p.ldx + t) * 4 + (second ? xsplit_off : 0) : OOB_OFF, 0);
                     } else {
                         px[i][c] = act_load4(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
                     }

@@ -86,6 +86,10 @@ struct ConvParams {
     const float* last_b;         // (1)
     float* last_y;               // (B, 1, ldy) float32
     long last_y_b;
+    // MODE_CHAIN: input channels split over the two signals' tensors (the FiLM net of a stage reads both chains'
+    // outputs as ONE 2C-channel input): channel cc lives in signal cc / xsplit (stride x_sig) at row cc % xsplit;
+    // 0 = one tensor
+    int xsplit;
     const float* in1_w;          // MODE_CHAIN1: first conv's raw weights (CIN, 1, 3) and bias (CIN)
     const float* in1_b;
     long in1_w_sig, in1_b_sig;

@@ -103,6 +103,7 @@ struct DownStage {
     PackedConv rc1[2];           // c1 and r fused (MODE_DEC2) when the stage qualifies (24-channel K chunks)
     PackedConv film[2];
     PackedConv heads;
+    PackedConv filmc;            // film conv (both signals, block-diagonal 2C -> 2C) -> heads as ONE launch (MODE_CHAIN)
 };
 
 struct UpStage {
@@ -180,6 +181,8 @@ struct fastsvc_plan {
     std::vector<std::pair<PackedConv*, PackSource>> pack_jobs;
     struct ChainJob { PackedConv* c; std::string first, second; };     // c = the SECOND conv; layer names
     std::vector<ChainJob> chain_jobs;
+    struct FilmChainJob { PackedConv* c; std::string conv[2]; PackSource heads; int C; };
+    std::vector<FilmChainJob> film_chain_jobs;
     std::vector<RawParam*> raw_jobs;
     double flops_per_sample = 0.0;
     int storage = 0;                    // activation storage in the workspace: 0 float32, 1 bfloat16
@@ -284,6 +287,19 @@ struct fastsvc_plan {
         for (int i = 0; i < 2; ++i) chain_jobs.push_back(ChainJob{&c[i], first[i], second[i]});
     }
 
+    // the FiLM net of a stage as one launch: [lrelu(conv_lft(h_lft)) ; lrelu(conv_sine(h_sine))] is a block-diagonal
+    // 2C -> 2C conv of the channel-concatenated input, the K-concatenated heads conv follows (fastsvc.py:120-131)
+    void add_film_chain(PackedConv& c, const PackedConv& heads, int C, const std::string (&conv)[2], const PackSource& hsrc) {
+        plan_conv(c, 2 * C, 2 * C, 3, 1);
+        if (c.MW < 2 || c.ngroups > 2) return;
+        c.hx = true; c.nch32 = (2 * C + 31) / 32;
+        for (int prec = 0; prec < 2; ++prec)
+            c.hxc_off[prec] = alloc((size_t)c.ngroups * 2 * c.nch32 * 3 * c.MW * (prec == 0 ? 2 : 1) * 256);
+        c.b_off = heads.b_off;
+        c.bmid_off = alloc(c.b_floats);
+        film_chain_jobs.push_back(FilmChainJob{&c, {conv[0], conv[1]}, hsrc, C});
+    }
+
     void add_raw(RawParam* r, int npair, const std::vector<std::string>& layers, size_t wf, size_t bf) {
         for (int i = 0; i < npair; ++i) { r[i].layer = layers[i]; r[i].w_floats = wf; r[i].b_floats = bf; }
         for (int i = 0; i < npair; ++i) r[i].w_off = alloc(wf);
@@ -347,6 +363,10 @@ int build_plan(fastsvc_plan& P) {
         heads.pieces = {{fl + ".conv_scale", 0, 0}, {fs + ".conv_scale", 0, d.C},
                         {fl + ".conv_shift", d.C, 0}, {fs + ".conv_shift", d.C, d.C}};
         P.add_conv(&d.heads, 1, 2 * d.C, 2 * d.C, 3, 1, {heads});
+        {
+            const std::string convs[2] = {fl + ".conv", fs + ".conv"};
+            P.add_film_chain(d.filmc, d.heads, d.C, convs, heads);
+        }
         // 2*MAC per column: 1x1 + k3 first + two k3 (C->C) + three FiLM k3 convs, two signals
         const double per_col = 2.0 * ((double)cin * d.C + 3.0 * cin * d.C + 2.0 * 3.0 * d.C * d.C + 3.0 * 3.0 * d.C * d.C);
         flops += 2.0 * per_col * rate;
@@ -642,6 +662,41 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             const int cj = second ? ci - nch * 32 : ci;
             if (cj >= cin) return 0.f;
             return (second ? LB.w : LA.w)[((size_t)co * cin + cj) * 3 + tap];
+        });
+    }
+    for (const auto& job : plan->film_chain_jobs) {
+        const PackedConv& c = *job.c;
+        const int C = job.C, C2 = 2 * C;
+        std::vector<float> WA((size_t)C2 * C2 * 3, 0.f), WB((size_t)C2 * C2 * 3, 0.f);
+        for (int sgn = 0; sgn < 2; ++sgn) {                 // block-diagonal first conv, biases side by side
+            HostLayer L;
+            const int rc = fetch_layer(sd, job.conv[sgn], C, (size_t)C * 3, L);
+            if (rc != FASTSVC_OK) return rc;
+            for (int co = 0; co < C; ++co) {
+                for (int ci = 0; ci < C; ++ci)
+                    for (int t = 0; t < 3; ++t)
+                        WA[((size_t)(co + sgn * C) * C2 + ci + sgn * C) * 3 + t] = L.w[((size_t)co * C + ci) * 3 + t];
+                blob[c.bmid_off + co + sgn * C] = L.b[co];
+            }
+        }
+        for (const auto& pc : job.heads.pieces) {            // the heads' virtual weight, as packed for the separate launch
+            HostLayer L;
+            const int rc = fetch_layer(sd, pc.layer, C, (size_t)C * 3, L);
+            if (rc != FASTSVC_OK) return rc;
+            for (int co = 0; co < C; ++co)
+                for (int ci = 0; ci < C; ++ci)
+                    for (int t = 0; t < 3; ++t)
+                        WB[((size_t)(co + pc.co_off) * C2 + ci + pc.ci_off) * 3 + t] = L.w[((size_t)co * C + ci) * 3 + t];
+        }
+        PackedConv v = c;
+        v.nch32 = 2 * c.nch32;
+        v.cin = 2 * c.nch32 * 32;
+        const int nch = c.nch32;
+        pack_hx(v, c.hxc_off, 3, [&](int co, int ci, int tap) {
+            const bool second = ci >= nch * 32;
+            const int cj = second ? ci - nch * 32 : ci;
+            if (cj >= C2) return 0.f;
+            return (second ? WB : WA)[((size_t)co * C2 + cj) * 3 + tap];
         });
     }
     for (const RawParam* r : plan->raw_jobs) {
@@ -958,7 +1013,8 @@ hipError_t run_chain(const PackedConv& a, const PackedConv& c, const float* blob
     done = true;
     if (prof) {
         const double cols = (double)p.T * p.B * nsig;
-        const double flops = 2.0 * 3.0 * ((double)a.cin * a.cout + (double)c.cin * c.cout + (in1 ? (double)a.cin : 0.0)) * cols;
+        // (split input = the FiLM net: its first conv is block-diagonal over the two signals, half the dense count)
+        const double flops = 2.0 * 3.0 * ((p.xsplit ? 0.5 : 1.0) * a.cin * a.cout + (double)c.cin * c.cout + (in1 ? (double)a.cin : 0.0)) * cols;
         double el = (in1 ? 1.0 : (double)a.cin) * p.T + (double)c.cout * p.T;
         if (p.res) el += (double)c.cout * p.T;
         if (p.r1x) el += (double)p.T;
@@ -1606,15 +1662,45 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             hipStream_t sf = (k == n - 1) ? stream : s_film;
             HIP_TRY(order_after(stream, sf));                      // h_k is ready
             float* u = buf("film_u." + s);                         // (B, 2C, Tk): [lft ; sine] channels
-            ConvParams p = base;
-            p.x = h; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
-            p.flags = F_POST_LRELU;
-            p.y = u; p.y_sig = tb; p.y_b = 2 * tb;
-            HIP_TRY(run_conv(d.film[0], blob, p, 2, (long)(d.film[1].w_off - d.film[0].w_off), (long)(d.film[1].b_off - d.film[0].b_off), sf, prof, ("film." + s + ".conv").c_str()));
-            ConvParams q = base;                                   // [scale ; shift] summed over both signals
-            q.x = u; q.x_sig = 0; q.x_b = 2 * tb; q.x_T = (int)Tk;
-            q.y = buf("ss." + s); q.y_sig = 0; q.y_b = 2 * tb;
-            HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, sf, prof, ("film." + s + ".heads").c_str()));
+            float* ssb = buf("ss." + s);
+            const std::string nconv = "film." + s + ".conv", nheads = "film." + s + ".heads", nchain = "film." + s + ".chain";
+            auto film_separate = [&](Profiler* pr) -> int {
+                ConvParams p = base;
+                p.x = h; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
+                p.flags = F_POST_LRELU;
+                p.y = u; p.y_sig = tb; p.y_b = 2 * tb;
+                HIP_TRY(run_conv(d.film[0], blob, p, 2, (long)(d.film[1].w_off - d.film[0].w_off), (long)(d.film[1].b_off - d.film[0].b_off), sf, pr, nconv.c_str()));
+                ConvParams q = base;                               // [scale ; shift] summed over both signals
+                q.x = u; q.x_sig = 0; q.x_b = 2 * tb; q.x_T = (int)Tk;
+                q.y = ssb; q.y_sig = 0; q.y_b = 2 * tb;
+                HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, sf, pr, nheads.c_str()));
+                return FASTSVC_OK;
+            };
+            // the whole FiLM net of the stage in one launch where it has the variant: the 2C-channel intermediate
+            // stays in LDS (block-diagonal first conv over both chains' outputs, then the heads)
+            bool film_fused = false;
+            if (d.filmc.hxc_off[0] && ((long)tsig + (long)d.C * Tk) * 4 < (1L << 31)) {
+                double sep_ms = 0.0;
+                if (g_tune.tuning && !prof) {
+                    int rc = film_separate(nullptr);
+                    if (rc != FASTSVC_OK) return rc;
+                    hipEvent_t e0, e1;
+                    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(FASTSVC_E_HIP, "hipEventCreate");
+                    hipEventRecord(e0, sf);
+                    for (int r = 0; r < 3 && rc == FASTSVC_OK; ++r) rc = film_separate(nullptr);
+                    hipEventRecord(e1, sf);
+                    float ms = 0.f;
+                    if (rc == FASTSVC_OK && hipEventSynchronize(e1) == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+                    hipEventDestroy(e0); hipEventDestroy(e1);
+                    if (rc != FASTSVC_OK) return rc;
+                    sep_ms = ms / 3.0;
+                }
+                ConvParams p3 = base;
+                p3.x = h; p3.x_sig = tsig; p3.x_b = tb; p3.x_T = (int)Tk; p3.xsplit = d.C;
+                p3.y = ssb; p3.y_sig = 0; p3.y_b = 2 * tb;
+                HIP_TRY(run_chain(d.filmc, d.filmc, blob, p3, 1, 0, sf, prof, nchain.c_str(), sep_ms, film_fused));
+            }
+            if (!film_fused) { const int rc = film_separate(prof); if (rc != FASTSVC_OK) return rc; }
             if (sf != stream && ctx) {
                 ss_ready[k] = ctx->ev[evi++ % ctx->ev.size()];
                 HIP_TRY(hipEventRecord(ss_ready[k], sf));

@@ -308,8 +308,9 @@ def test_profile_records_cover_every_launch(dev):
     b = S.synth_batch(cfg, 2, 20, 4)
     recs = []
     y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), profile=recs)
-    # launch_count is the unfused schedule; fused conditioning-chain launches save up to 2 (stage 0) + 1 per stage
-    assert plan.launch_count(True) - (cfg.n_stages + 1) <= len(recs) <= plan.launch_count(True)
+    # launch_count is the unfused schedule; fused launches save up to 2 (stage 0) + 1 per stage (c2 -> c3) + 1 per
+    # stage (FiLM conv -> heads) + 1 (conv_last)
+    assert plan.launch_count(True) - (2 * cfg.n_stages + 2) <= len(recs) <= plan.launch_count(True)
     assert all(r["ms"] > 0 for r in recs)
     total = sum(r["flops"] for r in recs)
     assert abs(total / (2 * 20 * 160) / plan.flops_per_sample - 1) < 0.02
@@ -340,8 +341,9 @@ def test_autotuned_launch_shapes_keep_parity(dev):
 @pytest.mark.parametrize("storage", ["float32", "bfloat16"])
 def test_fused_conditioning_stages_match_the_separate_launches(dev, storage):
     """A down stage's c2 -> c3 pair runs as ONE launch where the stage has the variant (kernel mode 6: the
-    intermediate tile stays in LDS) and stage 0 as one launch altogether (mode 7: its 1 -> C conv is computed by
-    the staging waves from the raw signal).  Same oracle tolerance as the separate launches, which a launch table
+    intermediate tile stays in LDS), stage 0 as one launch altogether (mode 7: its 1 -> C conv is computed by
+    the staging waves from the raw signal), and so does the FiLM net of the narrow stages (mode 6 on the
+    channel-concatenated outputs of both chains: block-diagonal conv, then the heads).  Same oracle tolerance as the separate launches, which a launch table
     with algorithm 0 under the fused keys selects; ragged batches included (the intermediate tile's zero padding
     follows each utterance's own length)."""
     O = _oracle()
@@ -359,6 +361,7 @@ def test_fused_conditioning_stages_match_the_separate_launches(dev, storage):
         T //= ([1] + list(reversed(cfg.upsampling_scales[1:])))[k]
         Ts.append(T)
     unfused = {f"down.{k}.c23|{B}|{Ts[k]}{sfx}": [3, 1, 4, 1, 0] for k in range(n)}
+    unfused.update({f"film.{k}.chain|{B}|{Ts[k]}{sfx}": [3, 1, 4, 1, 0] for k in range(n)})     # FiLM conv -> heads
     unfused[f"down.0.c123|{B}|{Ts[0]}{sfx}"] = [3, 1, 4, 1, 0]
     outs = {}
     for name, table in (("fused", {}), ("separate", unfused)):
@@ -369,6 +372,8 @@ def test_fused_conditioning_stages_match_the_separate_launches(dev, storage):
         y = plan.forward(blob, *ins, profile=recs)
         yr = plan.forward(blob, *ins, lengths=lengths)
         modes = sorted({int(r["kernel"].split(",")[4]) for r in recs if r["kernel"].startswith("conv_hx")})
+        layers = {r["layer"] for r in recs}
+        assert ("film.0.chain" in layers) == (name == "fused") and ("film.0.heads" in layers) == (name != "fused")
         outs[name] = (y.cpu(), yr.cpu(), modes, len(recs))
     assert 6 in outs["fused"][2] and 7 in outs["fused"][2]
     assert 6 not in outs["separate"][2] and 7 not in outs["separate"][2]
@@ -496,9 +501,11 @@ def test_winograd_time_convs_match_oracle_taps(dev, algo):
         for layer in ("c2_d2", "c3_d4"):
             table[f"down.{k}.{layer}|{B}|{rates[k]}"] = [1, 1, 4, 1, algo]
         table[f"down.{k}.c23|{B}|{rates[k]}"] = [3, 1, 4, 1, 0]      # the pair as two launches (algorithm 0 under the fused key)
+        table[f"film.{k}.chain|{B}|{rates[k]}"] = [3, 1, 4, 1, 0]
         table[f"film.{k}.conv|{B}|{rates[k]}"] = [1, 1, 4, 2, algo]
         table[f"film.{k}.heads|{B}|{rates[k]}"] = [1, 1, 4, 1, algo]
     table[f"film.0.heads|{B}|{rates[0]}"] = [2 if algo == 1 else 1, 1, 4, 3, algo]
+    table[f"film.0.chain|{B}|{rates[0]}"] = [3, 1, 4, 1, 0]
     for i, t_in in enumerate((F, 2 * F, 8 * F)):
         table[f"up.{i}.conv_first|{B}|{t_in}"] = [1, 1, 4, 1, algo]
     plan.load_tuned(table)
@@ -668,7 +675,8 @@ def test_half_precision_and_f32_mfma_families_agree(dev):
     assert all(r["kernel"].startswith("conv_hx<") for r in recs if r["layer"] not in ("conv_last", "spk_proj")), \
         sorted((r["layer"], r["kernel"]) for r in recs)
     p_32 = A.Plan(cfg, load_shipped_table=False)
-    layers = {r["layer"] for r in recs} | {f"down.{k}.{c}" for k in range(cfg.n_stages) for c in ("c2_d2", "c3_d4", "c23")}
+    layers = {r["layer"] for r in recs} | {f"down.{k}.{c}" for k in range(cfg.n_stages) for c in ("c2_d2", "c3_d4", "c23")} | \
+             {f"film.{k}.{c}" for k in range(cfg.n_stages) for c in ("conv", "heads", "chain")}
     p_32.load_tuned({f"{layer}|{B}|{t}": [1, 1, 4, 1, 0] for layer in layers
                      for t in (F, 2 * F, 8 * F, 32 * F, 160 * F)})          # algo 0 = the f32-input MFMA kernels, unfused
     ws_32 = torch.zeros(p_32.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
