@@ -246,7 +246,7 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
     wl = S.WORKLOADS[name]
     B, F = wl["B"], wl["F"]
     T = F * cfg.hop
-    plan = A.Plan(cfg, load_shipped_table=use_table, storage=storage)
+    plan = A.Plan(cfg, load_shipped_table=use_table, storage=storage, compact_workspace=True)
     blob = plan.pack(S.synth_state_dict(cfg, WEIGHT_SEED)).to(dev)
     args_dev = list(S.device_batch(cfg, B, F, wl["seed"], dev))
     ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
@@ -292,7 +292,7 @@ def main():
     strong = args.workload == "cfg4"
     B, F = (64, wl["F"]) if strong else (wl["B"], wl["F"])      # cfg4 runs in batches of 64
     T = F * cfg.hop
-    plan = A.Plan(cfg, load_shipped_table=not args.no_table, storage=args.storage)
+    plan = A.Plan(cfg, load_shipped_table=not args.no_table, storage=args.storage, compact_workspace=True)
     n_table = sum(1 for k in plan.tuned_shapes() if k.split("|")[1] == str(B))
 
     # weights: rank 0 folds + packs, everyone receives the kernel-layout blob (RCCL broadcast)

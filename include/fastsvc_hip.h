@@ -97,6 +97,12 @@ size_t fastsvc_weight_blob_bytes(const fastsvc_plan* plan);
 int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors, int32_t n_tensors,
                          void* host_blob);
 
+/* Workspace layout of the plan's later fastsvc_workspace_bytes / fastsvc_forward calls: 0 (default) = every
+ * intermediate has its own buffer (all fastsvc_workspace_tap tensors stay readable after a forward); 1 = compact,
+ * intermediates of different stages whose lifetimes cannot overlap share buffers (about 40 % less at 64 x 10 s;
+ * taps of shared buffers then hold the last stage's tensor).  Set it before sizing the workspace. */
+int fastsvc_plan_set_workspace_mode(fastsvc_plan* plan, int32_t compact);
+
 /* Device scratch needed by one forward of B utterances of F frames each (T = F * prod(scales)). */
 size_t fastsvc_workspace_bytes(const fastsvc_plan* plan, int32_t B, int32_t F);
 

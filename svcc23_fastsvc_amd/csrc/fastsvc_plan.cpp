@@ -186,6 +186,7 @@ struct fastsvc_plan {
     std::vector<RawParam*> raw_jobs;
     double flops_per_sample = 0.0;
     int storage = 0;                    // activation storage in the workspace: 0 float32, 1 bfloat16
+    bool compact = false;               // workspace layout: intermediates of different stages share buffers (fastsvc_plan_set_workspace_mode)
     // autotuned launch choices (fastsvc_autotune), keyed by "layer|B|T"; guarded by tune_mu
     struct Choice { int NW, WM, WN, tpw, algo; };    // algo: 0 direct / as launched, 1 Winograd F(2,3)
     mutable std::mutex tune_mu;
@@ -739,25 +740,70 @@ struct Workspace {
     }
 };
 
-// Every intermediate gets its own buffer (no aliasing yet): all taps stay readable after a forward.
+// Default layout: every intermediate has its own buffer, all taps stay readable after a forward.
+// Compact layout (fastsvc_plan_set_workspace_mode): buffers whose lifetimes cannot overlap share one slot sized for
+// the largest user -
+//   down_c1.k / down_c2.k of all stages (written and read on the caller's stream inside stage k only);
+//   a / xr / u1 / xmid / u2 / u3 of all up blocks (dead when the block's last conv has run; the helper-stream
+//   producer of xr.i+1 is ordered behind conv_first.i+1, i.e. behind every reader of block i's buffers) - in the
+//   SAME bytes as c1 / c2, which are dead when the first up block starts;
+//   film_u.k of the stages whose FiLM net runs on the helper stream (written and read there, stage after stage).
+// Tensors that a helper stream still reads while the caller's stream moves on (down_h, ss) and the block outputs
+// keep their own buffers.  Taps of shared slots hold the LAST user's tensor.
 Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
     Workspace ws;
+    std::map<std::string, size_t> slot_off;           // compact layout: slot name -> offset
+    auto add_shared = [&](const std::string& slot, const std::string& name, int64_t d0, int64_t d1, int64_t d2, size_t elem) {
+        if (!P.compact) { ws.add(name, d0, d1, d2, elem); return; }
+        BufferSpec b;
+        b.name = name;
+        b.off_bytes = slot_off.at(slot);
+        b.numel = d0 * d1 * d2;
+        b.shape[0] = d0; b.shape[1] = d1; b.shape[2] = d2;
+        ws.index[name] = (int)ws.bufs.size();
+        ws.bufs.push_back(b);
+    };
     const int n = P.n;
     int64_t hop = 1;
     for (int i = 0; i < n; ++i) hop *= P.cfg.upsampling_scales[i];
     const int64_t T = hop * F;
     const size_t ae = P.storage == 1 ? 2 : sizeof(float);      // activation element size
     if (P.storage == 1) ws.add("ppg_act", B, P.cfg.in_channels, F, ae);
+    if (P.compact) {
+        int64_t down_max = 0, up_max = 0, a_max = 0, u_max = 0, Td = T, Ti = F;
+        for (int k = 0; k < n; ++k) {
+            Td /= P.down[k].scale;
+            down_max = std::max<int64_t>(down_max, 2LL * B * P.down[k].C * Td);
+            if (k + 1 < n) u_max = std::max<int64_t>(u_max, 2LL * B * P.down[k].C * Td);
+        }
+        for (int i = 0; i < n; ++i) {
+            a_max = std::max<int64_t>(a_max, (int64_t)B * P.up[i].C * Ti);
+            Ti *= P.up[i].scale;
+            up_max = std::max<int64_t>(up_max, (int64_t)B * P.up[i].C * Ti);
+        }
+        // one arena for both phases: the conditioning chains' c1 / c2 are dead before the first up block starts
+        // (same stream), whose a / xr / u1 / xmid / u2 / u3 then take the same bytes
+        const size_t dn = align_up((size_t)down_max * ae, 256), up = align_up((size_t)up_max * ae, 256), aa = align_up((size_t)a_max * ae, 256);
+        const size_t arena = std::max(2 * dn, aa + 5 * up);
+        const size_t base = ws.add("shared.arena", 1, 1, (int64_t)(arena / ae), ae);
+        slot_off["c1"] = base; slot_off["c2"] = base + dn;
+        slot_off["a"] = base;
+        const char* ups[5] = {"xr", "u1", "xmid", "u2", "u3"};
+        for (int j = 0; j < 5; ++j) slot_off[ups[j]] = base + aa + j * up;
+        // film_u of the stages whose FiLM net runs on the helper stream: written and read there, one after the other
+        if (u_max > 0) slot_off["film_u"] = ws.add("shared.film_u", 1, 1, u_max, ae);
+    }
     int64_t Tk = T;
     for (int k = 0; k < n; ++k) {
         const DownStage& d = P.down[k];
         Tk = Tk / d.scale;
         const std::string s = std::to_string(k);
         if (k > 0) ws.add("down_r." + s, 2 * B, d.C, Tk, ae);
-        ws.add("down_c1." + s, 2 * B, d.C, Tk, ae);
-        ws.add("down_c2." + s, 2 * B, d.C, Tk, ae);
+        add_shared("c1", "down_c1." + s, 2 * B, d.C, Tk, ae);
+        add_shared("c2", "down_c2." + s, 2 * B, d.C, Tk, ae);
         ws.add("down_h." + s, 2 * B, d.C, Tk, ae);               // [lft batch ; sine batch]
-        ws.add("film_u." + s, B, 2 * d.C, Tk, ae);               // channels [lft ; sine]
+        if (k + 1 < n) add_shared("film_u", "film_u." + s, B, 2 * d.C, Tk, ae);     // channels [lft ; sine]
+        else ws.add("film_u." + s, B, 2 * d.C, Tk, ae);          // (last stage: on the caller's stream)
         ws.add("ss." + s, B, 2 * d.C, Tk, ae);                   // channels [scale ; shift]
     }
     int64_t Tin = F;
@@ -765,12 +811,12 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
         const UpStage& u = P.up[i];
         const int64_t Tout = Tin * u.scale;
         const std::string s = std::to_string(i);
-        ws.add("up." + s + ".a", B, u.C, Tin, ae);
-        ws.add("up." + s + ".xr", B, u.C, Tout, ae);
-        ws.add("up." + s + ".u1", B, u.C, Tout, ae);      // scale * t0 + shift      (fastsvc.py:131-132)
-        ws.add("up." + s + ".xmid", B, u.C, Tout, ae);
-        ws.add("up." + s + ".u2", B, u.C, Tout, ae);      // scale * xmid + shift
-        ws.add("up." + s + ".u3", B, u.C, Tout, ae);      // scale * t2 + shift
+        add_shared("a", "up." + s + ".a", B, u.C, Tin, ae);
+        add_shared("xr", "up." + s + ".xr", B, u.C, Tout, ae);
+        add_shared("u1", "up." + s + ".u1", B, u.C, Tout, ae);      // scale * t0 + shift      (fastsvc.py:131-132)
+        add_shared("xmid", "up." + s + ".xmid", B, u.C, Tout, ae);
+        add_shared("u2", "up." + s + ".u2", B, u.C, Tout, ae);      // scale * xmid + shift
+        add_shared("u3", "up." + s + ".u3", B, u.C, Tout, ae);      // scale * t2 + shift
         ws.add("up." + s + ".out", B, u.C, Tout, ae);
         ws.add("up." + s + ".spk", B, u.C, 1);
         Tin = Tout;
@@ -1385,6 +1431,12 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
 }  // namespace
 
 extern "C" {
+
+int fastsvc_plan_set_workspace_mode(fastsvc_plan* plan, int32_t compact) {
+    if (!plan) return fail(FASTSVC_E_INVALID, "null plan");
+    plan->compact = compact != 0;
+    return FASTSVC_OK;
+}
 
 size_t fastsvc_workspace_bytes(const fastsvc_plan* plan, int32_t B, int32_t F) {
     if (!plan || B < 1 || F < 1) return 0;

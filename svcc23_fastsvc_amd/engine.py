@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "fastsvc_forward", "fastsvc_autotune", "fastsvc_tuned_count", "fastsvc_tuned_get", "fastsvc_tuned_set",
     "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
     "fastsvc_flops_per_sample", "fastsvc_signal_scratch_bytes", "fastsvc_signal_generate",
-    "fastsvc_stream_prepare", "fastsvc_split_half",
+    "fastsvc_stream_prepare", "fastsvc_split_half", "fastsvc_plan_set_workspace_mode",
     "fastsvc_loudness_frames", "fastsvc_loudness_scratch_bytes", "fastsvc_loudness_extract",
 )
 
@@ -121,6 +121,8 @@ def load_library():
     lib.fastsvc_workspace_tap.argtypes = [vp, i32, i32, ctypes.c_char_p, ctypes.POINTER(sz),
                                           ctypes.POINTER(i64), ctypes.POINTER(i64 * 3)]
     lib.fastsvc_workspace_tap.restype = ctypes.c_int
+    lib.fastsvc_plan_set_workspace_mode.argtypes = [vp, i32]
+    lib.fastsvc_plan_set_workspace_mode.restype = ctypes.c_int
     lib.fastsvc_forward_launch_count.argtypes = [vp, i32]
     lib.fastsvc_forward_launch_count.restype = ctypes.c_int
     lib.fastsvc_flops_per_sample.argtypes = [vp]
@@ -147,10 +149,13 @@ def _check(lib, rc: int, what: str):
 class Plan:
     """Host-only plan (layer table + blob / workspace layout) for one generator configuration."""
 
-    def __init__(self, cfg: GeneratorConfig, load_shipped_table: bool = True, storage: str = "float32"):
+    def __init__(self, cfg: GeneratorConfig, load_shipped_table: bool = True, storage: str = "float32",
+                 compact_workspace: bool = False):
         """``storage``: "float32" (default, the parity path) or "bfloat16" - every workspace tensor is
         stored as bf16 (half the HBM traffic of the narrow layers, half the workspace; fp32 arithmetic;
-        bf16-activation accuracy, frame counts must be multiples of 4)."""
+        bf16-activation accuracy, frame counts must be multiples of 4).
+        ``compact_workspace``: intermediates of different stages share buffers (about 40 % less memory for long
+        batches); the ``tap`` of a shared buffer then holds the last stage's tensor only."""
         if storage not in ("float32", "bfloat16"):
             raise ValueError("storage must be 'float32' or 'bfloat16'")
         self.storage = storage
@@ -173,6 +178,9 @@ class Plan:
         if storage == "bfloat16":
             _check(self.lib, self.lib.fastsvc_plan_set_storage(handle, 1), "fastsvc_plan_set_storage")
             # (bfloat16 launches look their shapes up under "<layer>|<B>|<T>|b": separate entries of the same table)
+        self.compact_workspace = bool(compact_workspace)
+        if compact_workspace:
+            _check(self.lib, self.lib.fastsvc_plan_set_workspace_mode(handle, 1), "fastsvc_plan_set_workspace_mode")
         self.last_autotune_trials = 0
         if load_shipped_table:
             self.load_tuned_file(TUNED_TABLE_PATH, missing_ok=True)

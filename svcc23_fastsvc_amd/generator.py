@@ -227,7 +227,7 @@ class FastSVCGenerator(nn.Module):
     def packed_weights(self, device) -> torch.Tensor:
         """Device-resident kernel-layout weight blob; rebuilt when any parameter changed."""
         if self._plan is None:
-            self._plan = Plan(self._cfg, storage=self.activation_storage)
+            self._plan = Plan(self._cfg, storage=self.activation_storage, compact_workspace=True)
         key = self._weights_key(device)
         if self._blob is None or self._blob_key != key:
             host = self._plan.pack(self.state_dict())
@@ -238,7 +238,7 @@ class FastSVCGenerator(nn.Module):
     def load_packed_weights(self, blob: torch.Tensor):
         """Adopt an already packed device blob (e.g. received by RCCL broadcast)."""
         if self._plan is None:
-            self._plan = Plan(self._cfg, storage=self.activation_storage)
+            self._plan = Plan(self._cfg, storage=self.activation_storage, compact_workspace=True)
         if blob.numel() * blob.element_size() != self._plan.blob_bytes:
             raise ValueError("packed blob has the wrong size for this configuration")
         self._blob = blob
@@ -247,7 +247,7 @@ class FastSVCGenerator(nn.Module):
     @property
     def plan(self) -> Plan:
         if self._plan is None:
-            self._plan = Plan(self._cfg, storage=self.activation_storage)
+            self._plan = Plan(self._cfg, storage=self.activation_storage, compact_workspace=True)
         return self._plan
 
     # ------------------------------------------------------------------ forward
