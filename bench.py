@@ -270,6 +270,11 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL's version banner on the first
+    # collective, for one) goes to stderr - fd 1 is pointed at fd 2 until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -409,7 +414,8 @@ def main():
             "secondary": secondary,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
