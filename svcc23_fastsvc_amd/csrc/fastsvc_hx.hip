@@ -859,6 +859,7 @@ void conv_hx_kernel(const ConvParams p0) {
         stamp(4);
         for (int u = 0; u < nunits; u += 2) {
             pload(u + 2, pa, oka);
+            stamp(9);
             pcommit(u + 1, pb, okb, tiles + bufsz);
             stamp(5);
             __syncthreads();                           // end of unit u
@@ -866,6 +867,7 @@ void conv_hx_kernel(const ConvParams p0) {
             stamp(6);
             if (u + 1 >= nunits) break;
             pload(u + 3, pb, okb);
+            stamp(9);
             pcommit(u + 2, pa, oka, tiles);
             stamp(5);
             __syncthreads();                           // end of unit u+1
