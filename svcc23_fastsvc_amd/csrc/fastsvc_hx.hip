@@ -165,6 +165,36 @@ __device__ __forceinline__ void hx_unit_direct(f32x4 (&acc)[NW][MW], const unsig
     if (RELOAD) ws.advance();
 }
 
+// DIRECT unit whose weight fragments are read from LDS (`wl`: this unit's [tap][m][piece] KB-sized fragments,
+// lane-linear).  MODE_CHAIN's second conv where its whole weight slice fits next to the tiles: streamed from L2
+// its units follow each other without a barrier in between, so a unit-deep register ring has one unit's MFMA time
+// (1.3k cycles for 3 x 3 tiles) to cover the L2 latency and the phase ran at 40 % of its matrix rate.
+template <int MW, int NW>
+__device__ __forceinline__ void hx_unit_direct_wl(f32x4 (&acc)[NW][MW], const unsigned char* tile, const int (&aoff)[3],
+                                                  int lo_off, const unsigned char* wl, int lane) {
+    constexpr int NSTEP = 3 * NW;
+    HxFrag a[2];
+    u32x4 w[2][MW * HX_NP];
+    a[0] = hx_read(tile, aoff[0], lo_off);
+    #pragma unroll
+    for (int q = 0; q < MW * HX_NP; ++q) w[0][q] = *reinterpret_cast<const u32x4*>(wl + q * HX_FRAG + lane * 16);
+    #pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int tap = s / NW, n = s % NW;
+        if (s + 1 < NSTEP) {
+            a[(s + 1) & 1] = hx_read(tile, aoff[(s + 1) / NW] + ((s + 1) % NW) * 16 * HX_ROW, lo_off);
+            if (n + 1 == NW) {                                  // next step starts the next tap: its fragments
+                #pragma unroll
+                for (int q = 0; q < MW * HX_NP; ++q)
+                    w[(tap + 1) & 1][q] = *reinterpret_cast<const u32x4*>(wl + ((tap + 1) * MW * HX_NP + q) * HX_FRAG + lane * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        hx_step<MW>(acc[n], a[s & 1], &w[tap & 1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // POLY unit (Stretch2d + k=3 conv at the INPUT rate, fastsvc_kernels.h MODE_POLY): three accumulator sets
 //   a += W0 x[j-1] - W0 x[j],   z += (W0+W1+W2) x[j],   c += W2 x[j+1] - W2 x[j]
 // (the differences of the f32 kernel become a second product with the negated fragment: exact for split pieces).
@@ -591,6 +621,7 @@ __global__ __launch_bounds__(512, (hx_min_waves<MW, NW, MODE, EPI>()))
 void conv_hx_kernel(const ConvParams p0) {
     constexpr bool POLY = MODE == MODE_POLY, DEC2 = MODE == MODE_DEC2, CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1;
     constexpr bool IN1 = MODE == MODE_CHAIN1;                          // the staging waves compute the stage's first conv
+    constexpr bool WLB = CHAIN && S == 2;                              // the second conv's weights live in LDS (one channel group)
     constexpr int NT = 16 * NW * WN;                                   // (input-rate) columns per workgroup tile
     // MODE_CHAIN: the first conv also produces the second one's halo (<= 4 columns per side): its tile starts 4
     // columns early and is one 16-column MFMA tile longer (computed by the last wave along time)
@@ -670,6 +701,8 @@ void conv_hx_kernel(const ConvParams p0) {
     constexpr int T2CHUNK = HX_NP * T2ROWS * HX_ROW;
     unsigned char* T2 = tiles + 2 * bufsz;
     const int t2bytes = CHAIN ? p.nch32b * T2CHUNK : 0;
+    unsigned char* Wl = T2 + t2bytes;                                  // WLB: [K chunk][tap][m][piece] fragments of the second conv
+    const int wlbytes = WLB ? p.nch32b * NSLOT * HX_FRAG : 0;
 
     auto setup_shared = [&]() {
         if (flags & F_STATS) {
@@ -678,6 +711,13 @@ void conv_hx_kernel(const ConvParams p0) {
         if constexpr (CHAIN) {
             // channel padding of the intermediate tile is never written: it must read as 0, not as LDS garbage
             for (int i = tid * 16; i < t2bytes; i += 512 * 16) *reinterpret_cast<u32x4*>(T2 + i) = u32x4{0u, 0u, 0u, 0u};
+        }
+        if constexpr (WLB) {
+            // the second conv's fragments of this (signal, channel group 0): once per workgroup
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
+                                       (long)nch * NSLOT * HX_FRAG;
+            for (int i = tid * 16; i < wlbytes; i += 512 * 16)
+                *reinterpret_cast<u32x4*>(Wl + i) = *reinterpret_cast<const u32x4*>(src + i);
         }
         // prologue coefficients of every input channel, applied by the producers as ONE FMA u * A + Bc:
         // InstanceNorm + speaker bias (u - mean) * rstd + p  ->  A = rstd, Bc = p - mean * rstd (fastsvc.py:134-139);
@@ -883,7 +923,7 @@ void conv_hx_kernel(const ConvParams p0) {
         HxWeightStream<NSLOT> wst;
         const int wunits = CHAIN ? nch + p.nch32b : nch;    // weight units per tile (CHAIN: first conv's, then the second's)
         wst.init(reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
-                     (long)(active ? mg : 0) * wunits * NSLOT * HX_FRAG, wunits, lane);
+                     (long)(active ? mg : 0) * wunits * NSLOT * HX_FRAG, WLB ? nch : wunits, lane);
         int aoff[3];
         #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
@@ -1012,7 +1052,8 @@ void conv_hx_kernel(const ConvParams p0) {
                 stamp(5);
                 int cb = 0;
                 do {
-                    hx_unit_direct<MW, NW, !WSTATIC>(acc, T2 + cb * T2CHUNK, aoffB, lo_offB, wstB);
+                    if constexpr (WLB) hx_unit_direct_wl<MW, NW>(acc, T2 + cb * T2CHUNK, aoffB, lo_offB, Wl + cb * (NSLOT * HX_FRAG), lane);
+                    else hx_unit_direct<MW, NW, !WSTATIC>(acc, T2 + cb * T2CHUNK, aoffB, lo_offB, wstB);
                 } while (++cb < p.nch32b);
                 stamp(7);
                 if constexpr (EPI == EPI_RES) {
@@ -1150,6 +1191,15 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
     } else if constexpr (MODE == MODE_CHAIN) {
         if (aff || smem > 160 * 1024) return hipErrorInvalidValue;
         const int kind = p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
+        // S = 2: the second conv's weights in LDS - one channel group, more than one K chunk (a single chunk stays
+        // in registers), room next to the tiles, and no residual tensor: with one the phase the weights' L2 latency
+        // stretched was ALSO what hid the residual loads' latency (4-7k cycles under load; fetched earlier they
+        // block the first conv's weight ring, the queue being in order) - down.1.c23: 73.8 µs either way
+        const size_t wl = (size_t)p.nch32b * 3 * MW * HX_NP * HX_FRAG;
+        if constexpr (WM == 1 && MW == 3) {
+            if (kind == EPI_PLAIN && p.ngroups == 1 && p.nch32b > 1 && smem + wl <= 160 * 1024)
+                return hx_launch_kind<MW, NW, WM, WN, MODE_CHAIN, EPI_PLAIN, 2>(grid, smem + wl, stream, p);
+        }
 #define FASTSVC_HXC(k) if (kind == k) return hx_launch_kind<MW, NW, WM, WN, MODE_CHAIN, k, 1>(grid, smem, stream, p);
         FASTSVC_HXC(EPI_PLAIN) FASTSVC_HXC(EPI_RES) FASTSVC_HXC(EPI_RANK1)
 #undef FASTSVC_HXC
