@@ -62,6 +62,7 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
               "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     if timeline:
         common.append("-DFASTSVC_TIMELINE=1")
+        common.append("-DFASTSVC_DEBUG_SWITCHES=1")      # FASTSVC_DBG ablation switches exist in this build only
     # object cache (git-ignored build/ directory): a unit is recompiled only when its source, any header
     # under csrc/ or include/, or its flags changed - one kernel file takes minutes, the host file seconds
     cache = os.path.join(PKG_DIR, "build")

@@ -791,7 +791,7 @@ void conv_hx_kernel(const ConvParams p0) {
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const int t = t_start + 4 * it_q[i];
-                const bool tok = it_in[i] && (unsigned)t < (unsigned)p.T && un < nunits && !(p.dbg & DBG_NO_LOAD);
+                const bool tok = it_in[i] && (unsigned)t < (unsigned)p.T && un < nunits && !(FASTSVC_DBG_ON(p, DBG_NO_LOAD));
                 tokmask |= (tok ? 1u : 0u) << i;
                 if constexpr (IN1) {
                     // six signal samples t-1 .. t+4 (a negative offset is out of range like any other: 0 = the
@@ -825,7 +825,7 @@ void conv_hx_kernel(const ConvParams p0) {
         };
         // prologue transform (one FMA: InstanceNorm-apply + speaker bias; LeakyReLU), split, transpose, LDS write
         auto pcommit = [&](int un, const f32x4 (&px)[ITEMS][8], unsigned tokmask, unsigned char* tile) {
-            if (p.dbg & DBG_NO_COMMIT) return;
+            if (FASTSVC_DBG_ON(p, DBG_NO_COMMIT)) return;
             const int ch = un % nch;
             if constexpr (IN1) {
                 #pragma unroll
@@ -905,13 +905,18 @@ void conv_hx_kernel(const ConvParams p0) {
             __syncthreads();                           // end of unit u
             if (CHAIN && (u % nch) == nch - 1) __syncthreads();        // the consumers wrote the intermediate tile
             stamp(6);
-            if (u + 1 >= nunits) break;
+            // NO `if (u + 1 >= nunits) break;` here: hipcc folds that exit into the loop latch, so the state "first
+            // half only" (this half's loads in flight, their destination registers about to be reused for addresses)
+            // reaches the loop head in its bookkeeping and it puts `s_waitcnt vmcnt(0)` in front of the loads above -
+            // the two-deep prefetch ran one deep in every instance.  With an odd unit count the second half runs on
+            // a phantom unit (loads out of range, zeros into the buffer nobody reads) and the consumers add the
+            // matching barrier at their end.
             pload(u + 3, pb, okb);
             stamp(9);
             pcommit(u + 2, pa, oka, tiles);
             stamp(5);
-            __syncthreads();                           // end of unit u+1
-            if (CHAIN && ((u + 1) % nch) == nch - 1) __syncthreads();
+            __syncthreads();                           // end of unit u+1 (or the phantom one)
+            if (CHAIN && u + 1 < nunits && ((u + 1) % nch) == nch - 1) __syncthreads();
             stamp(6);
         }
     } else {
@@ -1080,7 +1085,7 @@ void conv_hx_kernel(const ConvParams p0) {
             for (int ch = 0; ch < nch; ++ch, ++u) {
                 if constexpr (EST) {
                     // one unit earlier when the tile has several K chunks: more time to land
-                    if (active && ch == max(nch - 2, 0) && !(p.dbg & DBG_NO_EPILOGUE)) {
+                    if (active && ch == max(nch - 2, 0) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
 #ifdef FASTSVC_ACT_BF16
                         if constexpr (PAIRS) hx_epilogue8_stage<MW, NW / 2, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                         else
@@ -1088,7 +1093,7 @@ void conv_hx_kernel(const ConvParams p0) {
                         ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                     }
                 }
-                if (active && !(p.dbg & DBG_NO_MFMA)) {
+                if (active && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))) {
                     if constexpr (POLY) hx_unit_poly<MW, NW, !WSTATIC>(acc3, tiles + (u & 1) * bufsz, aoff, lo_off, wst);
                     else if constexpr (DEC2) hx_unit_dec2<MW, NW, !WSTATIC>(acc2, tiles + (u & 1) * bufsz, aoff, lo_off, raw_off, wst);
                     else hx_unit_direct<MW, NW, !WSTATIC>(acc, tiles + (u & 1) * bufsz, aoff, lo_off, wst);
@@ -1098,7 +1103,7 @@ void conv_hx_kernel(const ConvParams p0) {
                     #pragma unroll
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
                     // the staged pieces are older than the NSLOT ring re-requests of this unit
-                    if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(p.dbg & DBG_NO_MFMA)); }
+                    if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))); }
                     if constexpr (POLY) {
 #ifdef FASTSVC_ACT_BF16
                         hx_epilogue_poly8<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
@@ -1111,7 +1116,7 @@ void conv_hx_kernel(const ConvParams p0) {
                     else {
 #ifdef FASTSVC_ACT_BF16
                         if constexpr (PAIRS) {
-                            if (!(p.dbg & DBG_NO_EPILOGUE))
+                            if (!(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
                                 hx_epilogue8<MW, NW / 2, EPI, EST>(p, R, acc, s1, s2, sig, mg,
                                                                    (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew, Xw);
                         } else
@@ -1119,11 +1124,11 @@ void conv_hx_kernel(const ConvParams p0) {
                         ws_epilogue_kind<MW, NW, EPI, EST, 0>(p, R, acc, s1, s2, sig, mg,
                                                               (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
                         if constexpr (LAST_OK) {
-                            if (p.last_w && !(p.dbg & DBG_NO_EPILOGUE))
+                            if (p.last_w && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
                                 hx_last_reduce<MW, NW, PAIRS>(p, acc, k_last, b, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                         }
                     }
-                    if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
+                    if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
                             float a1 = s1[m], a2 = s2[m];
@@ -1142,8 +1147,9 @@ void conv_hx_kernel(const ConvParams p0) {
                 stamp(6);
             }
         }
+        if (nunits & 1) __syncthreads();               // the staging waves' loop runs in pairs of units
     }
-    if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {   // one f64 global atomic per channel per workgroup
+    if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {   // one f64 global atomic per channel per workgroup
         __syncthreads();
         for (int i = tid; i < 2 * 16 * MW * WM; i += 512) {
             const int co = blockIdx.y * (WM * MW * 16) + (i >> 1);

@@ -142,6 +142,16 @@ struct ConvParams {
 };
 
 enum : int { DBG_NO_LOAD = 1, DBG_NO_MFMA = 2, DBG_NO_EPILOGUE = 4, DBG_NO_COMMIT = 8, DBG_NO_WEIGHTS = 16 };
+// The switches exist only in the diagnostic build (-DFASTSVC_DEBUG_SWITCHES: `build --timeline`).  A run-time branch
+// around a pipeline stage is not free even when never taken: hipcc's wait-count bookkeeping merges the path that
+// skips the stage, e.g. with `if (dbg & NO_COMMIT) return;` in front of the staging waves' commit it had to assume
+// the window loads might still be in flight at the loop head and put `s_waitcnt vmcnt(0)` in front of every second
+// unit's loads - the two-deep prefetch was one deep.
+#ifdef FASTSVC_DEBUG_SWITCHES
+#define FASTSVC_DBG_ON(p, flag) (((p).dbg & (flag)) != 0)
+#else
+#define FASTSVC_DBG_ON(p, flag) false
+#endif
 
 struct ConvLaunch {
     int MW;      // 16-channel tiles per wave (1, 2 or 3), fixed by the packed weight layout

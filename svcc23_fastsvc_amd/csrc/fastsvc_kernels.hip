@@ -378,7 +378,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
                                                    float (&s1)[MW], float (&s2)[MW],
                                                    int sig, int b, int mg, int tcol0, bool active, int lane) {
     const int flags = p.flags;
-    if (p.dbg & DBG_NO_EPILOGUE) {
+    if (FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)) {
         // keep the accumulators live (never true for finite data), then leave
         float keep = 0.f;
         #pragma unroll
@@ -451,7 +451,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
 template <int MW, int WM, int NTHREADS>
 __device__ __forceinline__ void stats_flush(const ConvParams& p, double (&d1a)[MW], double (&d2a)[MW],
                                             double* sstat, int b, int wave_m, bool active, int tid, int lane) {
-    if (!(p.flags & F_STATS) || (p.dbg & DBG_NO_EPILOGUE)) return;
+    if (!(p.flags & F_STATS) || (FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) return;
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         double d1 = d1a[m], d2 = d2a[m];
@@ -793,11 +793,11 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                     px[i] = act_load4(xr, (ro + t) * 4, soff);
                 }
             }
-            if (p.dbg & DBG_NO_LOAD) okmask = 0;
+            if (FASTSVC_DBG_ON(p, DBG_NO_LOAD)) okmask = 0;
         };
         // prologue transform + LDS write of a register set
         auto pcommit = [&](int un, const f32x4 (&px)[ITEMS], unsigned okmask, float* Xs) {
-            if (p.dbg & DBG_NO_COMMIT) return;
+            if (FASTSVC_DBG_ON(p, DBG_NO_COMMIT)) return;
             const int ch = un % p.nchunks;
             const int t_start = (tile0 + un / p.nchunks) * NT - halo_al;
             const bool tailmode = (p.T & 3) != 0;              // rows are not a multiple of 4 long
@@ -881,7 +881,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         float s1[MW], s2[MW];
         UnitWeightStream<MW, NSTEPS> wst;
         wst.init(p.w + (long)sig * p.w_sig + (long)(active ? mg : 0) * p.Q * 64 * MW,
-                 (p.dbg & DBG_NO_WEIGHTS) ? NSTEPS : p.Q, lane);
+                 (FASTSVC_DBG_ON(p, DBG_NO_WEIGHTS)) ? NSTEPS : p.Q, lane);
         const int colbase = (lane >> 4) * XS + (lane & 15) + wave_n * (NW * 16) + (halo_al - halo);
         // Winograd: pair index of this lane in M-tile 0 -> (plane position, residue) -> plane r / r+D
         const int wpair = wave_n * (NW * 16) + (lane & 15);
@@ -968,10 +968,10 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
             for (int ch = 0; ch < p.nchunks; ++ch, ++u) {
                 if constexpr (EST) {
                     // one unit earlier when the tile has several K chunks: more time to land
-                    if (active && ch == max(p.nchunks - 2, 0) && !(p.dbg & DBG_NO_EPILOGUE))
+                    if (active && ch == max(p.nchunks - 2, 0) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
                         ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                 }
-                if (active && !(p.dbg & DBG_NO_MFMA)) {
+                if (active && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))) {
                     constexpr bool RL = !WSTATIC;      // WSTATIC: the ring holds the whole layer, nothing to re-request
                     if constexpr (DEC2) mfma_unit_dec2<MW, NW, RL>(acc2, Xs0 + (u & 1) * bufsz + colbase, XS, wst);
                     else if constexpr (WINO) mfma_unit_wino<MW, NW, S, NSTEPS, RL>(acc4, Xs0 + (u & 1) * bufsz + colr, Xs0 + (u & 1) * bufsz + colrd, XS, wst);
@@ -995,11 +995,11 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                         ws_epilogue_tile<MW, NW>(p, R, acc, s1, s2, sig, mg,
                                                  (tile0 + tl) * NT + wave_n * (NW * 16), active, lane);
                     else {
-                        if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSTEPS>(!WSTATIC && !(p.dbg & DBG_NO_MFMA)); }
+                        if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSTEPS>(!WSTATIC && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))); }
                         ws_epilogue_kind<MW, NW, EPI, EST>(p, R, acc, s1, s2, sig, mg,
                                                            (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
                     }
-                    if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
+                    if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
                         // fp32 partials stay short (this tile only); the running sums are f64 in LDS
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
@@ -1021,7 +1021,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         }
     }
     // one f64 global atomic per channel per workgroup
-    if ((flags & F_STATS) && !(p.dbg & DBG_NO_EPILOGUE)) {
+    if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
         __syncthreads();
         for (int i = tid; i < 2 * 16 * MW * WM; i += 512) {
             const int co = blockIdx.y * (WM * MW * 16) + (i >> 1);
@@ -1093,7 +1093,7 @@ static hipError_t launch_ws(dim3 grid, dim3 block, size_t smem, hipStream_t stre
     }
     constexpr int NSTEPS = (MODE == MODE_WINO || MODE == MODE_DEC2) ? 24 : 6 * NTAPS;
     if constexpr (MW == 2) {
-        if (p.Q == NSTEPS && !(p.dbg & DBG_NO_WEIGHTS))
+        if (p.Q == NSTEPS && !(FASTSVC_DBG_ON(p, DBG_NO_WEIGHTS)))
             return launch_instance<&conv_mfma_ws_kernel<MW, NW, WM, WN, MODE, NTAPS, EPI, S, true>>(grid, block, smem, stream, p);
     }
     return launch_instance<&conv_mfma_ws_kernel<MW, NW, WM, WN, MODE, NTAPS, EPI, S, false>>(grid, block, smem, stream, p);
