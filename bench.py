@@ -51,8 +51,10 @@ WEIGHT_SEED = 201
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: long enough for the clocks to settle (a cfg2 step is 1.4 ms: 20 steps after 5 warm-up ones read 3-4 %
+    # slower than 200 after 50); the large workloads scale them down below
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
     ap.add_argument("--storage", default="float32", choices=["float32", "bfloat16"],
                     help="workspace tensor storage: float32 = the parity path (default, what `value` is quoted "
@@ -270,6 +272,11 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
 
 def main():
     args = parse()
+    big = args.workload in ("cfg3", "cfg4")
+    if args.steps is None:
+        args.steps = 10 if args.workload == "cfg4" else 40 if big else 200
+    if args.warmup is None:
+        args.warmup = 2 if args.workload == "cfg4" else 10 if big else 50
     # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL's version banner on the first
     # collective, for one) goes to stderr - fd 1 is pointed at fd 2 until the line is written
     sys.stdout.flush()
@@ -382,7 +389,7 @@ def main():
             secondary = {}
             for name, storage in (("cfg3", "float32"), ("cfg3", "bfloat16")):
                 try:
-                    secondary[f"{name}_{storage}"] = run_single_gpu_workload(cfg, name, storage, dev, steps=8, warmup=2,
+                    secondary[f"{name}_{storage}"] = run_single_gpu_workload(cfg, name, storage, dev, steps=20, warmup=5,
                                                                              use_table=not args.no_table)
                 except Exception as e:        # an extra block must never take the headline line down
                     secondary[f"{name}_{storage}"] = {"error": repr(e)}
