@@ -26,7 +26,10 @@
 //     4 (+4) ds_write_b128;
 //   * weights: pre-split fragments in MFMA operand order ([chunk][tap][16-channel tile][hi,lo][lane][8]),
 //     streamed from L2 into a unit-deep register ring with buffer_load_dwordx4 (resident when C_in <= 32);
-//   * epilogues: shared with the f32 kernels (fastsvc_device.inc).
+//   * epilogues: shared with the f32 kernels (fastsvc_device.inc);
+//   * fused launches (MODE_CHAIN / MODE_CHAIN1): two k=3 convs back to back with the tensor between them in LDS
+//     (c2 -> c3 of a conditioning stage, a whole stage 0 from the raw signal, the FiLM net of a stage), and
+//     conv_last computed by the epilogue of the last block's final conv (ConvParams::last_w) - see conv_hx_kernel.
 // Rows must be a multiple of 4 long (float4 everywhere); run_conv falls back to conv_mfma_ws_kernel otherwise.
 #include "fastsvc_kernels.h"
 
