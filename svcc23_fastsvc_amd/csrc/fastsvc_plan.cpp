@@ -18,6 +18,8 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <atomic>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -521,7 +523,12 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                         }
         }
     };
-    for (const auto& job : plan->pack_jobs) {
+    // Every job writes its own region of the blob: they run on a small thread pool (the fold + pack of the whole
+    // generator is ~120 ms single-threaded - paid by every training step, whose optimizer update invalidates the
+    // packed copy - and ~15 ms on 16 cores).  The first failing job's code and message are reported.
+    std::vector<std::function<int()>> tasks;
+    for (const auto& job_ : plan->pack_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
+        const auto& job = *pj;
         const PackedConv& c = *job.first;
         const PackSource& src = job.second;
         if (src.dec2) {
@@ -555,7 +562,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                 pack_hx(c, c.hx_off, 4, [&](int co, int ci, int slot) {
                     return slot < 3 ? L3.w[((size_t)co * c.cin + ci) * 3 + slot] : L1.w[(size_t)co * c.cin + ci];
                 });
-            continue;
+            return FASTSVC_OK;
         }
         // virtual dense weight W[co][ci][tap] and bias
         std::vector<float> W((size_t)c.cout * c.cin * c.ntaps, 0.f);
@@ -645,8 +652,10 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         }
         float* bp = blob + c.b_off;
         for (int co = 0; co < c.cout; ++co) bp[co] = bias[co];
-    }
-    for (const auto& job : plan->chain_jobs) {
+        return FASTSVC_OK;
+    });
+    for (const auto& job_ : plan->chain_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
+        const auto& job = *pj;
         const PackedConv& c = *job.c;                       // second conv; the first maps cout -> cin of it (square)
         HostLayer LA, LB;
         int rc = fetch_layer(sd, job.first, c.cin, (size_t)c.cout * 3, LA);
@@ -664,8 +673,10 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             if (cj >= cin) return 0.f;
             return (second ? LB.w : LA.w)[((size_t)co * cin + cj) * 3 + tap];
         });
-    }
-    for (const auto& job : plan->film_chain_jobs) {
+        return FASTSVC_OK;
+    });
+    for (const auto& job_ : plan->film_chain_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
+        const auto& job = *pj;
         const PackedConv& c = *job.c;
         const int C = job.C, C2 = 2 * C;
         std::vector<float> WA((size_t)C2 * C2 * 3, 0.f), WB((size_t)C2 * C2 * 3, 0.f);
@@ -699,15 +710,38 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             if (cj >= C2) return 0.f;
             return (second ? WB : WA)[((size_t)co * C2 + cj) * 3 + tap];
         });
-    }
-    for (const RawParam* r : plan->raw_jobs) {
+        return FASTSVC_OK;
+    });
+    for (const RawParam* r_ : plan->raw_jobs) tasks.emplace_back([&, r = r_]() -> int {
         HostLayer L;
         const int cout = (int)r->b_floats;
         const int rc = fetch_layer(sd, r->layer, cout, r->w_floats / cout, L);
         if (rc != FASTSVC_OK) return rc;
         std::memcpy(blob + r->w_off, L.w.data(), r->w_floats * sizeof(float));
         std::memcpy(blob + r->b_off, L.b.data(), r->b_floats * sizeof(float));
-    }
+        return FASTSVC_OK;
+    });
+    static const int env_threads = std::getenv("FASTSVC_PACK_THREADS") ? std::atoi(std::getenv("FASTSVC_PACK_THREADS")) : 0;
+    unsigned nthreads = env_threads > 0 ? (unsigned)env_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nthreads = (unsigned)std::min<size_t>(nthreads, tasks.size());
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_rc{FASTSVC_OK};
+    std::mutex err_mu;
+    std::string err_msg;
+    auto worker = [&]() {
+        for (size_t i = next.fetch_add(1); i < tasks.size(); i = next.fetch_add(1)) {
+            const int rc = tasks[i]();
+            if (rc != FASTSVC_OK) {
+                std::lock_guard<std::mutex> lock(err_mu);
+                if (first_rc.load() == FASTSVC_OK) { first_rc = rc; err_msg = g_err; }     // g_err: this thread's message
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+    if (first_rc.load() != FASTSVC_OK) return fail(first_rc.load(), err_msg);
     return FASTSVC_OK;
 }
 

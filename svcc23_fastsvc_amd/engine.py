@@ -267,23 +267,45 @@ class Plan:
     def workspace_bytes(self, B: int, F: int) -> int:
         return int(self.lib.fastsvc_workspace_bytes(self._h, B, F))
 
-    def pack(self, state_dict: Mapping[str, object]) -> torch.Tensor:
+    def pack(self, state_dict: Mapping[str, object], reuse_pinned: bool = False) -> torch.Tensor:
         """Fold weight-norm and pack a state dict (either key layout) into the kernel blob.
 
-        Returns a CPU float32 tensor of ``blob_bytes`` bytes (upload or broadcast it)."""
+        Returns a CPU float32 tensor of ``blob_bytes`` bytes (upload or broadcast it).  Device tensors are gathered
+        with ONE device-to-host copy (a training step re-packs after every optimizer update: 251 separate copies were
+        a third of that).  ``reuse_pinned``: return this plan's page-locked staging buffer (overwritten by the next
+        such call) - for callers that upload it right away."""
+        items = list(state_dict.items())
+        host = [None] * len(items)
+        on_dev = [i for i, (_, v) in enumerate(items) if isinstance(v, torch.Tensor) and v.device.type != "cpu"]
+        if on_dev:
+            flat = torch.cat([items[i][1].detach().reshape(-1).to(torch.float32) for i in on_dev]).cpu().numpy()
+            o = 0
+            for i in on_dev:
+                n = items[i][1].numel()
+                host[i] = flat[o:o + n]
+                o += n
         keep = []
-        arr = (_Tensor * len(state_dict))()
-        for i, (k, v) in enumerate(state_dict.items()):
-            if isinstance(v, torch.Tensor):
-                v = v.detach().to("cpu", torch.float32).contiguous().numpy()
-            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+        arr = (_Tensor * len(items))()
+        for i, (k, v) in enumerate(items):
+            if host[i] is not None:
+                a = host[i]
+            else:
+                if isinstance(v, torch.Tensor):
+                    v = v.detach().to("cpu", torch.float32).contiguous().numpy()
+                a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
             name = k.encode("utf-8")
             keep.append((a, name))
             arr[i].name = name
             arr[i].data = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
             arr[i].numel = a.size
-        blob = torch.empty(self.blob_bytes // 4, dtype=torch.float32)
-        rc = self.lib.fastsvc_pack_weights(self._h, arr, len(state_dict), ctypes.c_void_p(blob.data_ptr()))
+        if reuse_pinned:
+            if getattr(self, "_pinned_blob", None) is None:
+                self._pinned_blob = torch.empty(self.blob_bytes // 4, dtype=torch.float32,
+                                                pin_memory=torch.cuda.is_available())
+            blob = self._pinned_blob
+        else:
+            blob = torch.empty(self.blob_bytes // 4, dtype=torch.float32)
+        rc = self.lib.fastsvc_pack_weights(self._h, arr, len(items), ctypes.c_void_p(blob.data_ptr()))
         if rc == -2:
             raise KeyError(self.lib.fastsvc_last_error().decode())
         _check(self.lib, rc, "fastsvc_pack_weights")

@@ -230,7 +230,8 @@ class FastSVCGenerator(nn.Module):
             self._plan = Plan(self._cfg, storage=self.activation_storage, compact_workspace=True)
         key = self._weights_key(device)
         if self._blob is None or self._blob_key != key:
-            host = self._plan.pack(self.state_dict())
+            on_gpu = torch.device(device).type != "cpu"
+            host = self._plan.pack(self.state_dict(), reuse_pinned=on_gpu)   # staging buffer: uploaded right here
             self._blob = host.to(device)
             self._blob_key = key
         return self._blob
