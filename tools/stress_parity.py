@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity sweep on the GPU (developer tool): random (B, F), ragged or not, with / without
-speaker embedding, table / cost-model / forced-Winograd launch choices, vs the CPU oracle."""
+speaker embedding, table / cost-model / forced-Winograd launch choices, vs the CPU oracle.
+STRESS_STORAGE=bfloat16 sweeps the bfloat16-storage path (mean / max tolerances of the bf16 tests)."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,6 +9,8 @@ import svcc23_fastsvc_amd as A
 from svcc23_fastsvc_amd import synth as S
 from oracle import fastsvc_oracle as O
 
+STORAGE = os.environ.get("STRESS_STORAGE", "float32")
+BF16 = STORAGE == "bfloat16"
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 rng = random.Random(seed)
@@ -18,7 +21,7 @@ wf = S.fold_weight_norm(sd)
 worst = 0.0
 for it in range(n):
     table = rng.random() < 0.5
-    plan = A.Plan(cfg, load_shipped_table=table)
+    plan = A.Plan(cfg, load_shipped_table=table, storage=STORAGE, compact_workspace=rng.random() < 0.5)
     blob = plan.pack(sd).to(dev)
     B = rng.choice([1, 1, 2, 3, 5, 8])
     F = rng.choice([1, 2, 3, 4, 6, 9, 17, 32, 45, 63, 64, 100, 131, 150, 257])
@@ -34,14 +37,16 @@ for it in range(n):
     if lens is None:
         ref = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb if spk else None)
         err = float((y - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        if BF16: err = float((y - ref).abs().mean()) / max(1e-6, float(ref.pow(2).mean().sqrt()))     # relative to the rms
     else:
         for i, m in enumerate(lens):
             ref = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[i:i+1, :, :m], b.sine[i:i+1, :, :m*160],
                                   b.lft[i:i+1, :, :m*160], b.spk_emb[i:i+1] if spk else None)
             e = float((y[i:i+1, :, :m*160] - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+            if BF16: e = float((y[i:i+1, :, :m*160] - ref).abs().mean()) / max(1e-6, float(ref.pow(2).mean().sqrt()))
             err = max(err, e)
             assert float(y[i, :, m*160:].abs().max()) == 0.0 if m < F else True
     worst = max(worst, err)
-    flag = "" if err <= 1e-4 else "   <-- ABOVE 1e-4"
+    flag = "" if err <= (3e-2 if BF16 else 1e-4) else "   <-- ABOVE TOLERANCE"
     print(f"B={B} F={F} spk={spk} lens={lens} table={table}: rel err {err:.2e}{flag}", flush=True)
 print(f"worst {worst:.3e}")
