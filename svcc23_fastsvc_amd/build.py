@@ -54,12 +54,15 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
     """timeline=True: diagnostic build with per-wave cycle stamps in the pipelined kernel
     (-DFASTSVC_TIMELINE, tools/timeline.py) written to libfastsvc_hip_timeline.so, which only
     tools/timeline.py loads (FASTSVC_HIP_LIB); the product library is left untouched."""
-    if not force and not timeline and not needs_build():
+    if not force and not timeline and not os.environ.get("FASTSVC_BUILD_OUT") and not needs_build():
         return LIB_PATH
     import hashlib
     hipcc = _hipcc()
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
               "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    # developer A/B builds: extra -D switches and another output file (tools only; FASTSVC_HIP_LIB loads it)
+    extra_flags = os.environ.get("FASTSVC_BUILD_FLAGS", "").split()
+    common += extra_flags
     if timeline:
         common.append("-DFASTSVC_TIMELINE=1")
         common.append("-DFASTSVC_DEBUG_SWITCHES=1")      # FASTSVC_DBG ablation switches exist in this build only
@@ -92,7 +95,7 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
         if pr.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out)
         os.replace(path + ".tmp", path)
-    out_path = TIMELINE_LIB_PATH if timeline else LIB_PATH
+    out_path = os.environ.get("FASTSVC_BUILD_OUT") or (TIMELINE_LIB_PATH if timeline else LIB_PATH)
     link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", out_path + ".tmp"]
     if verbose:
         print(" ".join(link), file=sys.stderr)

@@ -5,12 +5,20 @@
 // instruction instead of the f32-input one (1/16 of its rate):
 //
 //   float32 storage (namespace fastsvc):  SPLIT-HALF products, fp32-class results.  Every operand is split
-//       exactly into two binary16 pieces, x = xh + xl with xh = f16(x), xl = f16(x - xh) (22 significand
-//       bits; the pieces' products are exact in the fp32 accumulator), and
+//       into two binary16 pieces, x = xh + xl with xh = f16(x), xl = f16(x - xh): 22 significand bits WHERE
+//       |x| >= 2^-3 - below that the low piece is a binary16 subnormal (absolute step 2^-24) - and nothing at
+//       all above 65504.  binary16's range is therefore managed explicitly (ConvParams, "dynamic range"):
+//       weights are scaled per output channel and activations per (tensor, utterance) by EXACT powers of two
+//       so that the largest magnitude sits in [2^14, 2^15): the split then keeps 22 bits for everything within
+//       2^-17 of the tensor's maximum and an absolute error of 2^-40 of the maximum below; the factors are
+//       divided out in the epilogue by the FMA that adds the bias.  The activation factor comes from the
+//       running max |value| the PRODUCING kernel recorded (amax slots) - or, behind an InstanceNorm, from the
+//       bound sqrt(T) + |p| of a normalised row.  Then
 //           x * w  ~=  xh*wh + xh*wl + xl*wh          (the dropped xl*wl term is < 2^-22 |x w|)
 //       costs three v_mfma_f32_16x16x32_f16 per 32 input channels = 3/16 of the f32-input MFMA time.
 //       End to end the generator output moves by 4e-6 against the fp32 path (oracle simulation and
-//       tests/test_parity_gpu.py), i.e. it stays at the reference's own fp32 noise floor (1e-5).
+//       tests/test_parity_gpu.py), i.e. it stays at the reference's own fp32 noise floor (1e-5), and
+//       tests/test_dynamic_range_gpu.py holds that over inputs / weights scaled by 2^-20 .. 2^8.
 //   bfloat16 storage (namespace fastsvc::bf16, -DFASTSVC_ACT_BF16):  ONE v_mfma_f32_16x16x32_bf16 product
 //       of the bf16-rounded operands - BASELINE config 3's "bf16 generator forward".
 //
@@ -264,21 +272,23 @@ __device__ __forceinline__ void hx_unit_dec2(f32x4 (&acc)[2][NW][MW], const unsi
 // convert / split 8 channel values of one time step into the tile's 16-byte slot(s)
 __device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int lo_off, const float (&e)[8]) {
     hx8 h;
+    float ec[8];
     #pragma unroll
     for (int c = 0; c < 8; ++c) {
 #ifdef FASTSVC_ACT_BF16
-        h[c] = (hx_t)e[c];
+        ec[c] = e[c];
 #else
-        // binary16 overflows at 65520: saturate the high piece (the low piece then carries what is left,
-        // up to another 65504) instead of producing inf - far outside anything the generator produces
-        h[c] = (hx_t)__builtin_amdgcn_fmed3f(e[c], -65504.f, 65504.f);
+        // the staged values are pre-scaled into [-2^15, 2^15] (hx_scale_for); the clamp is the safety net that
+        // keeps a wrong bound from ever producing inf (binary16 overflows at 65520), for both pieces
+        ec[c] = __builtin_amdgcn_fmed3f(e[c], -65504.f, 65504.f);
 #endif
+        h[c] = (hx_t)ec[c];
     }
     *reinterpret_cast<hx8*>(tile + off) = h;
     if constexpr (HX_NP == 2) {
         hx8 l;
         #pragma unroll
-        for (int c = 0; c < 8; ++c) l[c] = (hx_t)(e[c] - (float)h[c]);
+        for (int c = 0; c < 8; ++c) l[c] = (hx_t)(ec[c] - (float)h[c]);
         *reinterpret_cast<hx8*>(tile + lo_off + off) = l;
     }
 }
@@ -290,19 +300,27 @@ __device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int
 //   g = lane >> 4) owns channels 4g .. 4g+3 of time step t = 8 bytes of a row.  row0 is a multiple of 16, so the
 //   swizzle of hx_lds_off depends on the lane only: one address per m, immediate offsets for n.
 typedef hx_t hx4 __attribute__((ext_vector_type(4)));
+// smid (LDS): [bias of the first conv | its inverse operand scales], per channel, both already multiplied by the
+// intermediate tile's own scale (LeakyReLU commutes with a positive factor): v = acc * kinv + kb.  Read here, once
+// per tile, instead of living in 8 MW registers across the tile loop.
 template <int MW, int NA>
 __device__ __forceinline__ void hx_chain_store(const f32x4 (&acc)[NA][MW], int ntl, unsigned char* T2, int chunk_bytes,
-                                               int lo_off, int mg, int row0, int col0, int T, const f32x4 (&kb)[MW], int lane) {
+                                               int lo_off, int mg, int row0, int col0, int T, const float* smid,
+                                               int cmidp, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int co0 = (mg * MW + m) * 16 + 4 * g;
         unsigned char* base = T2 + (co0 >> 5) * chunk_bytes + hx_lds_off(row0 + l15, (co0 & 31) >> 3) + (co0 & 7) * 2;
+        const f32x4 kb = *reinterpret_cast<const f32x4*>(smid + co0);
+        f32x4 kinv = kb;
+        if constexpr (HX_NP == 2) kinv = *reinterpret_cast<const f32x4*>(smid + cmidp + co0);
         #pragma unroll
         for (int n = 0; n < NA; ++n) {
             if (n >= ntl) continue;
             const bool inside = (unsigned)(col0 + n * 16 + l15) < (unsigned)T;
-            f32x4 v = acc[n][m] + kb[m];
+            f32x4 v;
+            if constexpr (HX_NP == 2) v = acc[n][m] * kinv + kb; else v = acc[n][m] + kb;
             #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[e] = fmaxf(v[e], v[e] * LRELU_SLOPE);
@@ -696,6 +714,45 @@ void conv_hx_kernel(const ConvParams p0) {
     double* sstat = reinterpret_cast<double*>(smem_raw);                               // [WM*MW*16][2]
     float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);   // [CINp]
     unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp);             // [2][HX_NP][W rows][64 B]
+    // small per-workgroup constants (static LDS; HX_STATIC_LDS bounds them for the launcher's size checks)
+    __shared__ float s_inv[HX_NP == 2 ? 2 * 16 * MW * WM : 4];        // inverse operand scales [conv | second DEC2 output][channel]
+    __shared__ __attribute__((aligned(16))) float s_mid[CHAIN ? 2 * (16 * MW * WM + 32) : 4];   // MODE_CHAIN: hx_chain_store's constants
+    // ---- operand scales of the split-binary16 products (ConvParams, "dynamic range"; powers of two) ----
+    // Set by setup_shared, i.e. AFTER the staging waves have their first two windows and the consumers their weight
+    // stream in flight: the amax row is one more dependent global load, and in front of everything else it cost
+    // every launch its latency (+2-3.5 us per kernel, measured).
+    float sx = 1.f;                                    // the staging waves multiply what they stage by sx
+    float s_mid_scale = 1.f;                           // MODE_CHAIN: scale of the intermediate tile
+    const int ninv = 16 * MW * p.ngroups;
+    const float* invtab = (HX_NP == 2 && p.whx_inv) ? p.whx_inv + (long)sig * p.whx_inv_sig : nullptr;
+    auto operand_scales = [&]() {
+#ifndef FASTSVC_EXP_NOSCALE
+        if constexpr (HX_NP == 2) {
+            if (p.amax_in) {
+                auto bound_of = [&](int entry, int s) -> float {
+                    float bd = amax_read(p.amax_in, entry);
+                    #pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (p.bnd_path[j]) { const float* q = p.bnd_path[j] + (long)s * p.bnd_sig[j]; bd = bd * q[0] + q[1]; }
+                    return bd;
+                };
+                float bound = bound_of(sig * p.amax_in_sig + b, sig);
+                if (p.amax_in2 > 0) bound = fmaxf(bound, bound_of(p.amax_in2 + b, 1));
+                // behind an InstanceNorm the row is that of the speaker biases p (spk_proj_kernel fills it): a
+                // normalised row of n samples never exceeds sqrt(n - 1) in magnitude, plus its bias
+                if (flags & F_PRE_NORM) bound += sqrtf((float)p.x_T);
+                if constexpr (CHAIN) {
+                    if (invtab) {
+                        const float* cst = invtab + 2 * ninv;      // l1 / largest |bias| of the first conv (and of the 1 -> C conv)
+                        if constexpr (IN1) bound = bound * cst[2] + cst[3];
+                        s_mid_scale = hx_scale_for(bound * cst[0] + cst[1]);
+                    }
+                }
+                sx = hx_scale_for(bound);
+            }
+        }
+#endif
+    };
     const int lo_off = (W + 4) * HX_ROW;                               // hi tile (+ 4 spare rows), then lo tile
     const int raw_off = HX_NP * (W + 4) * HX_ROW;                      // DEC2: the raw tile behind the LeakyReLU'd one
     const int bufsz = NVAR * HX_NP * (W + 4) * HX_ROW;
@@ -708,6 +765,7 @@ void conv_hx_kernel(const ConvParams p0) {
     const int wlbytes = WLB ? p.nch32b * NSLOT * HX_FRAG : 0;
 
     auto setup_shared = [&]() {
+        operand_scales();
         if (flags & F_STATS) {
             for (int i = tid; i < 2 * 16 * MW * WM; i += 512) sstat[i] = 0.0;
         }
@@ -727,10 +785,19 @@ void conv_hx_kernel(const ConvParams p0) {
         // no norm: (1, 0); channel padding: (0, 0)
         {
             const double inv_len = 1.0 / (double)p.x_T;
+            if constexpr (CHAIN) {
+                // first conv's bias and inverse operand scales, times the intermediate tile's scale (hx_chain_store)
+                const int cmidp = p.nch32b * HX_KC;
+                for (int c = tid; c < cmidp; c += 512) {
+                    const bool ok = c < p.CMID;
+                    s_mid[c] = ok ? p.bias_mid[(long)sig * p.bias_mid_sig + c] * s_mid_scale : 0.f;
+                    if constexpr (HX_NP == 2) s_mid[cmidp + c] = ok ? (invtab ? invtab[c] : 1.f) * (s_mid_scale / sx) : 0.f;
+                }
+            }
             for (int c = tid; c < CINp; c += 512) {
                 float2 ab = make_float2(0.f, 0.f);
                 if (c < p.CIN) {
-                    ab = make_float2(1.f, 0.f);
+                    ab = make_float2(sx, 0.f);
                     if (flags & F_PRE_NORM) {
                         const double q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
                         const double q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
@@ -738,8 +805,8 @@ void conv_hx_kernel(const ConvParams p0) {
                         double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
                         var = var > 0.0 ? var : 0.0;
                         const double rstd = 1.0 / sqrt(var + IN_EPS);
-                        ab.x = (float)rstd;
-                        ab.y = (float)((double)p.spk[(long)b * p.CIN + c] - mean * rstd);
+                        ab.x = (float)rstd * sx;
+                        ab.y = (float)((double)p.spk[(long)b * p.CIN + c] - mean * rstd) * sx;
                     }
                 }
                 ncoef[c] = ab;
@@ -870,17 +937,14 @@ void conv_hx_kernel(const ConvParams p0) {
                 for (int j = 0; j < 4; ++j) {
                     float e[8];
                     #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float u = px[i][c][j] * A[c] + Bc[c];
-                        e[c] = fmaxf(u, u * slope);
-                    }
+                    for (int c = 0; c < 8; ++c) e[c] = px[i][c][j] * A[c] + Bc[c];
+                    // the raw copy for the 1x1 residual conv: no prologue at all, i.e. (A, Bc) = (sx, 0) and the FMA's
+                    // result IS the scaled raw value (a decimating stage never sits behind a norm); committed first,
+                    // the LeakyReLU then runs in place
+                    if constexpr (DEC2) hx_commit_slot(tile + raw_off, hx_lds_off(4 * it_q[i] + j, it_oct[i]), lo_off, e);
+                    #pragma unroll
+                    for (int c = 0; c < 8; ++c) e[c] = fmaxf(e[c], e[c] * slope);
                     hx_commit_slot(tile, hx_lds_off(4 * it_q[i] + j, it_oct[i]), lo_off, e);
-                    if constexpr (DEC2) {                  // the raw copy for the 1x1 residual conv (no prologue at all)
-                        float r[8];
-                        #pragma unroll
-                        for (int c = 0; c < 8; ++c) r[c] = px[i][c][j];
-                        hx_commit_slot(tile + raw_off, hx_lds_off(4 * it_q[i] + j, it_oct[i]), lo_off, r);
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -896,6 +960,12 @@ void conv_hx_kernel(const ConvParams p0) {
         pload(1, pb, okb);
         stamp(2);
         setup_shared();
+        if constexpr (IN1 && HX_NP == 2) {
+            // sx: the scale of the 1 -> C conv's OUTPUT, which is what gets split; a power of two, so the scaled taps
+            // give exactly sx times the unscaled result
+            #pragma unroll
+            for (int c = 0; c < 8; ++c) { i1w[c][0] *= sx; i1w[c][1] *= sx; i1w[c][2] *= sx; i1b[c] *= sx; }
+        }
         pcommit(0, pa, oka, tiles);
         stamp(3);
         __syncthreads();                               // unit 0 staged
@@ -962,7 +1032,22 @@ void conv_hx_kernel(const ConvParams p0) {
                 k_r1b[m] = cok ? p.r1b[(long)sig * p.r1_sig + co] : 0.f;
             }
         }
-        const EpiConst<MW, true> K{k_bias, k_bias2, k_r1w, k_r1b};
+        // (the inverse operand scales of this lane's channels live in LDS, s_inv, filled after setup_shared: the
+        // activation scale of a normalised edge is only known then.  MODE_CHAIN: they belong to the SECOND conv.)
+        const EpiConst<MW, true, HX_NP == 2> K{k_bias, k_bias2, k_r1w, k_r1b, s_inv + wave_m * (MW * 16) + (lane & 15), 16 * MW * WM};
+        float t_inv[MW], t_inv2[MW];                   // (requested here with the other constants; dead after setup)
+        #pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int cot = (mg * MW + m) * 16 + (lane & 15);
+            const bool cok = active && cot < p.COUT;
+            t_inv[m] = cok ? 1.f : 0.f; t_inv2[m] = t_inv[m];
+            if constexpr (HX_NP == 2) {
+                if (invtab) {
+                    t_inv[m] = cok ? invtab[(CHAIN ? ninv : 0) + cot] : 0.f;
+                    if constexpr (DEC2) t_inv2[m] = cok ? invtab[ninv + cot] : 0.f;
+                }
+            }
+        }
         constexpr bool LAST_OK = MODE == MODE_DIRECT && EPI == EPI_RES && WM == 1;     // conv_last may ride on this instance
         float k_last[MW];
         #pragma unroll
@@ -982,19 +1067,29 @@ void conv_hx_kernel(const ConvParams p0) {
         (void)Xw;
         stamp(2);
         setup_shared();
-        __syncthreads();                               // unit 0 staged
+        if constexpr (HX_NP == 2) {
+            const float isx = 1.0f / (CHAIN ? s_mid_scale : sx);   // exact: a power of two
+            if (lane < 16) {
+                #pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    const int li = (wave_m * MW + m) * 16 + lane;
+                    s_inv[li] = t_inv[m] * isx;
+                    if constexpr (DEC2) s_inv[16 * MW * WM + li] = t_inv2[m] * isx;
+                }
+            }
+        }
+        __syncthreads();                               // unit 0 staged (and s_inv visible)
         stamp(4);
         int u = 0;
         if constexpr (CHAIN) {
             f32x4 accA[NW + 1][MW];                    // the first conv's tile; time tile NW only in the last wave along time
-            f32x4 k_mid[MW];                           // first conv's bias of this lane's 4 channels (transposed tiles)
-            #pragma unroll
-            for (int m = 0; m < MW; ++m)
-                #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cot = (mg * MW + m) * 16 + 4 * (lane >> 4) + e;
-                    k_mid[m][e] = (active && cot < p.CMID) ? p.bias_mid[(long)sig * p.bias_mid_sig + cot] : 0.f;
-                }
+            const int cmidp = p.nch32b * HX_KC;
+            // terms that join the SECOND conv's accumulator directly (rank-1 / tensor residual) are multiplied by
+            // 1 / inverse scale: exact for a power of two, from its bits (exponent field e -> 254 - e)
+            auto fwd = [&](int m) -> float {
+                if constexpr (HX_NP == 2) return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, K.inv(m)));
+                else return 1.f;
+            };
             // WSTATIC (one K chunk per conv: C <= 32): both convs' fragments stay in registers for the whole
             // workgroup - `wst` holds the first conv's, `wstB` the second's; nothing is re-requested
             HxWeightStream<NSLOT> wstB_static;
@@ -1039,11 +1134,14 @@ void conv_hx_kernel(const ConvParams p0) {
                 // every wave is past the previous tile's second conv (the barriers above): its tile may be overwritten
                 if (active)
                     hx_chain_store<MW, NW + 1>(accA, extra ? NW + 1 : NW, T2, T2CHUNK, lo_offB, mg, wave_n * (NW * 16),
-                                               (tile0 + tl) * NT - HB + wave_n * (NW * 16), p.T, k_mid, lane);
+                                               (tile0 + tl) * NT - HB + wave_n * (NW * 16), p.T, s_mid, cmidp, lane);
                 // the stage's residual tensor (the 1x1 conv's output) is fetched HERE, into registers the first
                 // conv's tile has just left: it lands under the second conv instead of costing the epilogue a
                 // memory round trip per item
                 f32x4 rres[EPI == EPI_RES ? NW : 1][EPI == EPI_RES ? MW : 1];
+                float kf[MW];
+                #pragma unroll
+                for (int m = 0; m < MW; ++m) kf[m] = (EPI == EPI_RANK1 || EPI == EPI_RES) ? fwd(m) : 1.f;
                 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
                     const int t = tcol0 + n * 16 + (lane >> 4) * 4;
@@ -1052,7 +1150,7 @@ void conv_hx_kernel(const ConvParams p0) {
                         const int cot = (mg * MW + m) * 16 + (lane & 15);
                         const bool ok = active && cot < p.COUT && t < p.T;
                         if constexpr (EPI == EPI_RES) rres[n][m] = act_load4(R.res, ok ? (cot * p.ldy + t) * 4 : OOB_OFF, 0);
-                        if constexpr (EPI == EPI_RANK1) acc[n][m] = rx[n] * k_r1w[m] + k_r1b[m];
+                        if constexpr (EPI == EPI_RANK1) acc[n][m] = (rx[n] * k_r1w[m] + k_r1b[m]) * kf[m];
                         else acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -1068,11 +1166,12 @@ void conv_hx_kernel(const ConvParams p0) {
                     #pragma unroll
                     for (int n = 0; n < NW; ++n)
                         #pragma unroll
-                        for (int m = 0; m < MW; ++m) acc[n][m] += rres[n][m];
+                        for (int m = 0; m < MW; ++m) acc[n][m] += rres[n][m] * kf[m];
                 }
                 #pragma unroll
                 for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
                 ws_epilogue_kind<MW, NW, EPI_PLAIN, false, 0>(p, R, acc, s1, s2, sig, mg, tcol0, active, lane, K, Ew);
+                amax_tile_flush(R);
                 stamp(8);
             }
         } else
@@ -1131,6 +1230,7 @@ void conv_hx_kernel(const ConvParams p0) {
                                 hx_last_reduce<MW, NW, PAIRS>(p, acc, k_last, b, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                         }
                     }
+                    amax_tile_flush(R);
                     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
@@ -1150,6 +1250,7 @@ void conv_hx_kernel(const ConvParams p0) {
                 stamp(6);
             }
         }
+        amax_flush(p, R, sig, b, active, lane, blockIdx.x + cw);   // (float32 storage: the next conv's split-binary16 scale)
         if (nunits & 1) __syncthreads();               // the staging waves' loop runs in pairs of units
     }
     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {   // one f64 global atomic per channel per workgroup
@@ -1161,11 +1262,12 @@ void conv_hx_kernel(const ConvParams p0) {
     }
 }
 
+constexpr size_t HX_STATIC_LDS = 2048;                  // upper bound of conv_hx_kernel's static LDS (s_inv, s_mid)
 template <auto KERNEL>
 static hipError_t hx_launch_instance(dim3 grid, size_t smem, hipStream_t stream, const ConvParams& p) {
-    if (smem > 64 * 1024) {
+    if (smem + HX_STATIC_LDS > 64 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - HX_STATIC_LDS);
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL(KERNEL, grid, dim3(512), smem, stream, p);
@@ -1195,10 +1297,10 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
                         (CHAIN ? (size_t)p.nch32b * HX_NP * (NT + 16) * HX_ROW : 0);
     const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
     if constexpr (MODE == MODE_CHAIN1) {
-        if (aff || !p.r1x || smem > 160 * 1024) return hipErrorInvalidValue;
+        if (aff || !p.r1x || smem + HX_STATIC_LDS > 160 * 1024) return hipErrorInvalidValue;
         return hx_launch_kind<MW, NW, WM, WN, MODE_CHAIN1, EPI_RANK1, 1>(grid, smem, stream, p);
     } else if constexpr (MODE == MODE_CHAIN) {
-        if (aff || smem > 160 * 1024) return hipErrorInvalidValue;
+        if (aff || smem + HX_STATIC_LDS > 160 * 1024) return hipErrorInvalidValue;
         const int kind = p.r1x ? EPI_RANK1 : p.res ? EPI_RES : EPI_PLAIN;
         // S = 2: the second conv's weights in LDS - one channel group, more than one K chunk (a single chunk stays
         // in registers), room next to the tiles, and no residual tensor: with one the phase the weights' L2 latency
@@ -1206,7 +1308,7 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
         // block the first conv's weight ring, the queue being in order) - down.1.c23: 73.8 µs either way
         const size_t wl = (size_t)p.nch32b * 3 * MW * HX_NP * HX_FRAG;
         if constexpr (WM == 1 && MW == 3) {
-            if (kind == EPI_PLAIN && p.ngroups == 1 && p.nch32b > 1 && smem + wl <= 160 * 1024)
+            if (kind == EPI_PLAIN && p.ngroups == 1 && p.nch32b > 1 && smem + wl + HX_STATIC_LDS <= 160 * 1024)
                 return hx_launch_kind<MW, NW, WM, WN, MODE_CHAIN, EPI_PLAIN, 2>(grid, smem + wl, stream, p);
         }
 #define FASTSVC_HXC(k) if (kind == k) return hx_launch_kind<MW, NW, WM, WN, MODE_CHAIN, k, 1>(grid, smem, stream, p);

@@ -95,6 +95,31 @@ struct ConvParams {
     long in1_w_sig, in1_b_sig;
     int CMID, nch32b, dil2;      // nch32b = ceil(CMID / 32); whx holds [nch32 units of A | nch32b units of B] per group
     int ngroups;                 // number of 16*MW-row groups
+    // ---- dynamic range of the split-binary16 products (float32 storage, fastsvc_hx.hip) ----
+    // binary16 has an absolute floor (2^-24) and ceiling (65504) float32 does not have, so both operands are moved
+    // into its range by EXACT power-of-two factors before the split and the factors leave again in the epilogue:
+    //   weights: per output channel, chosen by the packer (max |w| of the channel -> [2^14, 2^15)); whx_inv holds the
+    //            inverse factors: [16*MW*ngroups] floats per table; MODE_DEC2: [k=3 conv | 1x1 conv];
+    //            MODE_CHAIN: [first conv | second conv | l1_first, bmax_first, l1_in1, bmax_in1] (l1 = largest
+    //            absolute row sum of the first conv's weights, bmax = its largest |bias|: they bound the intermediate
+    //            tensor that never leaves LDS; in1: the 1 -> C conv the staging waves compute in MODE_CHAIN1)
+    //   activations: per (tensor, utterance), from the largest magnitude the PRODUCING kernel saw (amax slots in the
+    //            workspace: every epilogue keeps a running max of what it writes and every wave ends with one
+    //            atomic max; the raw inputs are scanned by amax_inputs_kernel).  Entry sig * amax_in_sig + b of
+    //            amax_in (and, with amax_in2 > 0, entry amax_in2 + b for the second signal's tensor: the larger
+    //            bound counts), 8 floats each - the value is their max; behind an InstanceNorm (F_PRE_NORM) amax_in is the row of the speaker biases p and the
+    //            bound of a normalised row, sqrt(x_T) + max |p|, is used.
+    const float* whx_inv;
+    long whx_inv_sig;            // lft -> sine stride in floats
+    const float* amax_in;
+    int amax_in_sig, amax_in2;
+    // the staged tensor is not the measured one but up to two convolutions downstream of it: bound = bound * l1 + bmax
+    // per layer on the path ((l1, bmax) pairs written by the packer; second signal bnd_sig floats further).  Keeps the
+    // number of MEASURED tensors - each costs its producer device-scope atomics - to one per stage / block.
+    const float* bnd_path[2];
+    long bnd_sig[2];
+    float* amax_out;             // [sig * amax_out_sig + b]: largest |value| of the tensor the next conv will stage
+    int amax_out_sig;            //   (y; the FiLM-affined y2 for F_AFF_OUT launches); null: not tracked
     // destination (nsig, B, COUT, T); y may be null when only the FiLM-affine output y2 is needed
     float* y;
     long y_sig, y_b;
@@ -186,7 +211,16 @@ bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN);
 //   x: signal 0 (B, T); signal 1 starts x_sig floats further (the caller's two tensors, no copy)
 //   lens / len_mul: ragged batches (valid length of utterance b = lens[b] * len_mul, rows keep pitch T)
 hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const float* bias, long w_sig, long b_sig,
-                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream);
+                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream,
+                           float* amax_out = nullptr);
+
+// Largest magnitude of every input row (float32 storage: scale of the split-binary16 staging, see ConvParams):
+//   amax_in[sig * B + b] = max |signal[sig][b][0 .. T_b)|,  amax_in[2B + b] = max |ppg[b][:, 0 .. F_b)|
+// Every (tensor, utterance) entry is AMAX_W = 8 floats wide (writers spread over the slots, readers take their max):
+// the scan stores 8 partial maxima per input row (no atomics, nothing to zero first) and zeroes the `nzero` floats
+// at `zero` - the intermediate tensors' entries, which later kernels of the forward accumulate into by atomic max.
+hipError_t launch_amax_inputs(const float* sig, long sig_stride, const float* ppg, int B, int C, int F, int hop,
+                              const int* lens, float* amax_in, float* zero, int nzero, hipStream_t stream);
 
 // conv_last: 1x1, y[b][o][t] = bias[o] + sum_c w[o][c] * x[b][c][t]
 hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
@@ -198,6 +232,7 @@ struct SpkBlock {
     const float* bias;  // (C)
     float* out;         // (B, C)
     int C;
+    float* amax;        // float32 storage: amax row of the speaker biases, (B, 8) - see ConvParams; null otherwise
 };
 hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks, int B, int E,
                            hipStream_t stream);
@@ -209,7 +244,8 @@ namespace bf16 {
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const float* bias, long w_sig, long b_sig,
-                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream);
+                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream,
+                           float* amax_out = nullptr);
 hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
                                 int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream);
 hipError_t launch_act_convert(const float* src, float* dst_bf16, long n, hipStream_t stream);

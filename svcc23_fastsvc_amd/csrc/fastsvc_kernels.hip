@@ -376,7 +376,7 @@ __device__ __forceinline__ void mfma_unit_dec2(f32x4 (&acc)[2][NW][MW], const fl
 template <int MW, int NW>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&acc)[NW][MW],
                                                    float (&s1)[MW], float (&s2)[MW],
-                                                   int sig, int b, int mg, int tcol0, bool active, int lane) {
+                                                   int sig, int b, int mg, int tcol0, bool active, int lane, float& amx) {
     const int flags = p.flags;
     if (FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)) {
         // keep the accumulators live (never true for finite data), then leave
@@ -426,7 +426,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
                     if (y2row) *reinterpret_cast<f32x4*>(y2row + t) = u;
                     s1[m] += (u.x + u.y) + (u.z + u.w);
                     s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
-                }
+                    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
+                } else amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             } else {
                 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -439,7 +440,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
                         const float u = scrow[t + r] * e + shrow[t + r];
                         if (y2row) y2row[t + r] = u;
                         s1[m] += u; s2[m] += u * u;
-                    }
+                        amx = fmaxf(amx, fabsf(u));
+                    } else amx = fmaxf(amx, fabsf(e));
                 }
             }
         }
@@ -594,7 +596,11 @@ void conv_mfma_kernel(const ConvParams p0) {
     double d1[MW], d2[MW];
     #pragma unroll
     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
-    conv_epilogue_tile<MW, NW>(p, acc, s1, s2, sig, b, mg, t0 + wave_n * (NW * 16), active, lane);
+    {
+        EpiRsrc R;                                     // (only its running max is used by this kernel)
+        conv_epilogue_tile<MW, NW>(p, acc, s1, s2, sig, b, mg, t0 + wave_n * (NW * 16), active, lane, R.amx);
+        amax_flush(p, R, sig, b, active, lane, blockIdx.x + wave);
+    }
     #pragma unroll
     for (int m = 0; m < MW; ++m) { d1[m] = (double)s1[m]; d2[m] = (double)s2[m]; }
     stats_flush<MW, WM, NTHREADS>(p, d1, d2, sstat, b, wave_m, active, tid, lane);
@@ -931,7 +937,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
         }
         };
         if constexpr (HOIST) load_consts();
-        const EpiConst<MW, HOIST> K{k_bias, k_bias2, k_r1w, k_r1b};
+        const EpiConst<MW, HOIST> K{k_bias, k_bias2, k_r1w, k_r1b, nullptr, 0};      // (no operand scales in this family)
         stamp(2);                                      // weight stream issued
         setup_shared();
         __syncthreads();                               // unit 0 staged
@@ -999,6 +1005,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                         ws_epilogue_kind<MW, NW, EPI, EST>(p, R, acc, s1, s2, sig, mg,
                                                            (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
                     }
+                    amax_tile_flush(R);
                     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
                         // fp32 partials stay short (this tile only); the running sums are f64 in LDS
                         #pragma unroll
@@ -1019,6 +1026,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                 stamp(6);
             }
         }
+        amax_flush(p, R, sig, b, active, lane, blockIdx.x + cw);   // (float32 storage: the next conv's split-binary16 scale)
     }
     // one f64 global atomic per channel per workgroup
     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
@@ -1074,7 +1082,7 @@ bool conv_poly_shape(int MW, int NW, int WM, int WN) {
 
 template <auto KERNEL>
 static hipError_t launch_instance(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const ConvParams& p) {
-    if (smem > 64 * 1024) {                                 // above the default dynamic-LDS limit: once per instance
+    if (smem > 64 * 1024) {                            // above the default dynamic-LDS limit: once per instance
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr != hipSuccess) return attr;
@@ -1241,13 +1249,14 @@ constexpr int IN1_SPT = 4;          // 16-byte float stores
 __global__ __launch_bounds__(256)
 void in1_conv_kernel(const float* __restrict__ x, long x_sig, const float* __restrict__ w,
                      const float* __restrict__ bias, long w_sig, long b_sig, float* __restrict__ y,
-                     int B, int C, int ld, const int* __restrict__ lens, int len_mul) {
+                     int B, int C, int ld, const int* __restrict__ lens, int len_mul, float* __restrict__ amax_out) {
     constexpr int SPT = IN1_SPT;
     const int z = blockIdx.z;
     const int sig = z / B;
     const int T = lens ? lens[z - sig * B] * len_mul : ld;          // valid length of this utterance (pitch ld)
     const int t = (blockIdx.x * 256 + threadIdx.x) * SPT;
-    if (t >= T) return;
+    if (blockIdx.x * 256 * SPT >= T) return;                        // (whole workgroup; lanes past T store nothing)
+    float amx = 0.f;
     const float* xr = x + (long)sig * x_sig + (long)(z - sig * B) * ld;      // the two signals are separate tensors
     float xv[SPT + 2];
     #pragma unroll
@@ -1263,7 +1272,7 @@ void in1_conv_kernel(const float* __restrict__ x, long x_sig, const float* __res
         const float w0 = ws[co * 3 + 0], w1 = ws[co * 3 + 1], w2 = ws[co * 3 + 2], bb = bs[co];
         float o[SPT];
         #pragma unroll
-        for (int i = 0; i < SPT; ++i) o[i] = bb + (w0 * xv[i] + w1 * xv[i + 1]) + w2 * xv[i + 2];
+        for (int i = 0; i < SPT; ++i) { o[i] = bb + (w0 * xv[i] + w1 * xv[i + 1]) + w2 * xv[i + 2]; amx = fmaxf(amx, fabsf(o[i])); }
         act_t* yr = yb + (long)co * ld + t;
 #ifdef FASTSVC_ACT_BF16
         if (full) {
@@ -1284,14 +1293,94 @@ void in1_conv_kernel(const float* __restrict__ x, long x_sig, const float* __res
         }
 #endif
     }
+    if (amax_out) {                                                 // largest |c1| (lanes past T: bias-sized values)
+        const unsigned a = wave_max_u32_lane63(__builtin_bit_cast(unsigned, amx));
+        if ((threadIdx.x & 63) == 63) atomicMax(reinterpret_cast<unsigned*>(amax_out) + z * AMAX_W + ((blockIdx.x + (threadIdx.x >> 6)) & (AMAX_W - 1)), a);
+    }
 }
 
 hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const float* bias, long w_sig, long b_sig,
-                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream) {
+                           float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream,
+                           float* amax_out) {
     dim3 grid((T + 256 * IN1_SPT - 1) / (256 * IN1_SPT), 1, nsig * B);
-    hipLaunchKernelGGL(in1_conv_kernel, grid, dim3(256), 0, stream, x, x_sig, w, bias, w_sig, b_sig, y, B, C, T, lens, len_mul);
+    hipLaunchKernelGGL(in1_conv_kernel, grid, dim3(256), 0, stream, x, x_sig, w, bias, w_sig, b_sig, y, B, C, T, lens, len_mul, amax_out);
     return hipGetLastError();
 }
+
+#ifndef FASTSVC_ACT_BF16
+// ---------------------------------------------------------------------------------------------
+// Largest magnitude of every input row (fastsvc_kernels.h, launch_amax_inputs): what the split-binary16 kernels
+// scale their staged activations by.  gridDim = (AMAX_W, 3 B input rows + zeroing rows): block x of an input row scans
+// the x-th part of it and STORES its max into slot x of the row's entry (no atomics, nothing to zero first); the rows
+// behind them zero the intermediate tensors' entries, which later kernels of the forward accumulate into.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float amax_span(const float* __restrict__ x, long i0, long i1, int tid) {
+    float a = 0.f;
+    if ((reinterpret_cast<size_t>(x + i0) & 15) == 0) {
+        long i = i0 + 4 * tid;
+        for (; i + 3 * 1024 + 3 < i1; i += 4096) {          // four independent 16-byte loads in flight per thread
+            f32x4 v[4];
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(x + i + 1024 * k);
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) a = fmaxf(fmaxf(a, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+        }
+        for (; i + 3 < i1; i += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+            a = fmaxf(fmaxf(a, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (long j = i0 + ((i1 - i0) & ~3L) + tid; j < i1; j += 256) a = fmaxf(a, fabsf(x[j]));
+    } else {
+        for (long j = i0 + tid; j < i1; j += 256) a = fmaxf(a, fabsf(x[j]));
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256)
+void amax_inputs_kernel(const float* __restrict__ sig, long sig_stride, const float* __restrict__ ppg, int B, int C, int F,
+                        int hop, const int* __restrict__ lens, float* __restrict__ amax_in, float* __restrict__ zero, int nzero) {
+    const int row = blockIdx.y;
+    const int part = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ float red[4];
+    if (row >= 3 * B) {
+        for (int i = ((row - 3 * B) * AMAX_W + part) * 1024 + 4 * tid; i < nzero; i += (gridDim.y - 3 * B) * AMAX_W * 1024)
+            *reinterpret_cast<f32x4*>(zero + i) = f32x4{0.f, 0.f, 0.f, 0.f};      // (nzero is a multiple of 4)
+        return;
+    }
+    float a = 0.f;
+    if (row < 2 * B) {
+        const int s = row / B, b = row - s * B;
+        const long n = (long)(lens ? lens[b] : F) * hop;
+        const long per = ((n + AMAX_W - 1) / AMAX_W + 3) & ~3L;
+        a = amax_span(sig + (long)s * sig_stride + (long)b * F * hop, min(n, part * per), min(n, (part + 1) * per), tid);
+    } else {
+        const int b = row - 2 * B;
+        const int nf = lens ? lens[b] : F;
+        const float* x = ppg + (long)b * C * F;
+        if (nf == F) {
+            const long n = (long)C * F;
+            const long per = ((n + AMAX_W - 1) / AMAX_W + 3) & ~3L;
+            a = amax_span(x, min(n, part * per), min(n, (part + 1) * per), tid);
+        } else {
+            for (int c = part; c < C; c += AMAX_W)                   // ragged: the valid frames of each channel row
+                for (int i = tid; i < nf; i += 256) a = fmaxf(a, fabsf(x[(long)c * F + i]));
+        }
+    }
+    const unsigned m = wave_max_u32_lane63(__builtin_bit_cast(unsigned, a));
+    if ((tid & 63) == 63) red[tid >> 6] = __builtin_bit_cast(float, m);
+    __syncthreads();
+    if (tid == 0) amax_in[row * AMAX_W + part] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+hipError_t launch_amax_inputs(const float* sig, long sig_stride, const float* ppg, int B, int C, int F, int hop,
+                              const int* lens, float* amax_in, float* zero, int nzero, hipStream_t stream) {
+    const int zrows = (nzero + AMAX_W * 1024 * 4 - 1) / (AMAX_W * 1024 * 4);
+    hipLaunchKernelGGL(amax_inputs_kernel, dim3(AMAX_W, 3 * B + (zrows < 1 ? 1 : zrows)), dim3(256), 0, stream,
+                       sig, sig_stride, ppg, B, C, F, hop, lens, amax_in, zero, nzero);
+    return hipGetLastError();
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // conv_last: 1x1 conv C -> O (fastsvc.py:301,330), HBM-read bound.
@@ -1404,7 +1493,12 @@ void spk_proj_kernel(const float* __restrict__ emb, const SpkArgs args, int E) {
     for (int i = lane; i < E; i += 64) a += wr[i] * e_s[i];
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0) blk.out[(long)b * blk.C + c] = a + blk.bias[c];
+    if (lane == 0) {
+        const float pc = a + blk.bias[c];
+        blk.out[(long)b * blk.C + c] = pc;
+        // largest |p| of the utterance: with sqrt(T) it bounds a normalised row (scale of the split-binary16 staging)
+        if (blk.amax) atomicMax(reinterpret_cast<unsigned*>(blk.amax) + b * AMAX_W + (c & (AMAX_W - 1)), __builtin_bit_cast(unsigned, fabsf(pc)));
+    }
 }
 
 hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks, int B, int E,

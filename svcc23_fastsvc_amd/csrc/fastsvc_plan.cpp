@@ -80,6 +80,16 @@ struct PackedConv {
     long hxc_pair[2] = {0, 0};
     size_t bmid_off = 0;
     long bmid_pair = 0;
+    // inverse per-output-channel weight scales of the split-binary16 fragments (ConvParams::whx_inv; float offsets,
+    // pair strides in floats): hx -> [16*MW*ngroups] (MODE_DEC2: two tables), polyphase taps, and the fused pair
+    // [first | second | l1_first, bmax_first, l1_in1, bmax_in1]
+    size_t hx_inv_off = 0, hxp_inv_off = 0, hxc_inv_off = 0;
+    long hx_inv_pair = 0, hxc_inv_pair = 0;
+    // (l1, bmax) of the layer - largest absolute row sum of its weights, largest |bias| - i.e. |conv(x)| <= l1 * max|x|
+    // + bmax: lets a kernel derive the bound of a tensor nobody measured from the measured maximum of an earlier one
+    // (ConvParams::bnd_path)
+    size_t bnd_off = 0;
+    long bnd_pair = 0;
 };
 
 // Source description used by the packer: virtual weight W[co][ci][tap] assembled from up to four
@@ -95,6 +105,7 @@ struct RawParam {            // weights kept in plain row-major layout (VALU ker
     std::string layer;
     size_t w_off = 0, b_off = 0;
     size_t w_floats = 0, b_floats = 0;
+    size_t bnd_off = 0;      // (l1, bmax) of the layer, see PackedConv
 };
 
 struct DownStage {
@@ -181,7 +192,7 @@ struct fastsvc_plan {
     RawParam last;
     size_t blob_floats = 0;
     std::vector<std::pair<PackedConv*, PackSource>> pack_jobs;
-    struct ChainJob { PackedConv* c; std::string first, second; };     // c = the SECOND conv; layer names
+    struct ChainJob { PackedConv* c; std::string first, second, in1; };     // c = the SECOND conv; layer names (in1: stage 0's 1 -> C conv)
     std::vector<ChainJob> chain_jobs;
     struct FilmChainJob { PackedConv* c; std::string conv[2]; PackSource heads; int C; };
     std::vector<FilmChainJob> film_chain_jobs;
@@ -218,6 +229,8 @@ struct fastsvc_plan {
         for (int i = 0; i < npair; ++i) plan_conv(c[i], cin, cout, ntaps, dil);
         for (int i = 0; i < npair; ++i) c[i].w_off = alloc(c[i].w_floats);
         for (int i = 0; i < npair; ++i) c[i].b_off = alloc(c[i].b_floats);
+        for (int i = 0; i < npair; ++i) c[i].bnd_off = alloc(2);
+        if (npair == 2) c[0].bnd_pair = (long)(c[1].bnd_off - c[0].bnd_off);
         for (int i = 0; i < npair; ++i) {
             if (ntaps == 3 && (dil == 1 || dil == 2 || dil == 4) && c[i].KC == 24 && c[i].MW >= 2) c[i].wino = true;
         }
@@ -240,6 +253,8 @@ struct fastsvc_plan {
                 for (int i = 0; i < npair; ++i) c[i].hx_off[prec] = alloc(fl);
                 if (npair == 2) c[0].hx_pair[prec] = (long)(c[1].hx_off[prec] - c[0].hx_off[prec]) * 4;
             }
+            for (int i = 0; i < npair; ++i) c[i].hx_inv_off = alloc(c[i].b_floats);
+            if (npair == 2) c[0].hx_inv_pair = (long)(c[1].hx_inv_off - c[0].hx_inv_off);
         }
         for (int i = 0; i < npair; ++i) pack_jobs.emplace_back(&c[i], src[i]);
     }
@@ -266,6 +281,8 @@ struct fastsvc_plan {
                 for (int i = 0; i < 2; ++i) c[i].hx_off[prec] = alloc(fl);
                 c[0].hx_pair[prec] = (long)(c[1].hx_off[prec] - c[0].hx_off[prec]) * 4;
             }
+            for (int i = 0; i < 2; ++i) c[i].hx_inv_off = alloc(2 * c[i].b_floats);       // k=3 conv | 1x1 conv
+            c[0].hx_inv_pair = (long)(c[1].hx_inv_off - c[0].hx_inv_off);
         }
         for (int i = 0; i < 2; ++i) {
             PackSource src;
@@ -277,7 +294,8 @@ struct fastsvc_plan {
 
     // c2 -> c3 of a down stage as one launch: every workgroup keeps the whole C-channel intermediate tile in LDS,
     // so the stage must fit one workgroup row of channel groups (C <= 96) and the LDS (see hx_launch_shape)
-    void add_chain(PackedConv* a, PackedConv* c, const std::string (&first)[2], const std::string (&second)[2]) {
+    void add_chain(PackedConv* a, PackedConv* c, const std::string (&first)[2], const std::string (&second)[2],
+                   const std::string* in1 = nullptr) {
         if (!a[0].hx || !c[0].hx || a[0].cout != c[0].cin || a[0].cin != c[0].cout || a[0].MW != c[0].MW ||
             c[0].ngroups > 2 || a[0].dil > 4 || c[0].dil > 4) return;
         for (int prec = 0; prec < 2; ++prec) {
@@ -287,7 +305,9 @@ struct fastsvc_plan {
         }
         for (int i = 0; i < 2; ++i) c[i].bmid_off = a[i].b_off;
         c[0].bmid_pair = (long)(a[1].b_off - a[0].b_off);
-        for (int i = 0; i < 2; ++i) chain_jobs.push_back(ChainJob{&c[i], first[i], second[i]});
+        for (int i = 0; i < 2; ++i) c[i].hxc_inv_off = alloc(2 * c[i].b_floats + 4);
+        c[0].hxc_inv_pair = (long)(c[1].hxc_inv_off - c[0].hxc_inv_off);
+        for (int i = 0; i < 2; ++i) chain_jobs.push_back(ChainJob{&c[i], first[i], second[i], in1 ? in1[i] : std::string()});
     }
 
     // the FiLM net of a stage as one launch: [lrelu(conv_lft(h_lft)) ; lrelu(conv_sine(h_sine))] is a block-diagonal
@@ -300,6 +320,7 @@ struct fastsvc_plan {
             c.hxc_off[prec] = alloc((size_t)c.ngroups * 2 * c.nch32 * 3 * c.MW * (prec == 0 ? 2 : 1) * 256);
         c.b_off = heads.b_off;
         c.bmid_off = alloc(c.b_floats);
+        c.hxc_inv_off = alloc(2 * c.b_floats + 4);
         film_chain_jobs.push_back(FilmChainJob{&c, {conv[0], conv[1]}, hsrc, C});
     }
 
@@ -307,6 +328,7 @@ struct fastsvc_plan {
         for (int i = 0; i < npair; ++i) { r[i].layer = layers[i]; r[i].w_floats = wf; r[i].b_floats = bf; }
         for (int i = 0; i < npair; ++i) r[i].w_off = alloc(wf);
         for (int i = 0; i < npair; ++i) r[i].b_off = alloc(bf);
+        for (int i = 0; i < npair; ++i) r[i].bnd_off = alloc(2);
         for (int i = 0; i < npair; ++i) raw_jobs.push_back(&r[i]);
     }
 };
@@ -357,7 +379,8 @@ int build_plan(fastsvc_plan& P) {
         {
             const std::string first[2] = {pl + ".downsample_block.4", ps + ".downsample_block.4"};
             const std::string second[2] = {pl + ".downsample_block.6", ps + ".downsample_block.6"};
-            P.add_chain(d.c2, d.c3, first, second);
+            const std::string in1[2] = {pl + ".downsample_block.2", ps + ".downsample_block.2"};
+            P.add_chain(d.c2, d.c3, first, second, k == 0 ? in1 : nullptr);
         }
         const std::string fl = "film_lft." + std::to_string(k);
         const std::string fs = "film_sine." + std::to_string(k);
@@ -393,9 +416,11 @@ int build_plan(fastsvc_plan& P) {
             if (pc->KC == 24 && (u.scale == 2 || u.scale == 4 || u.scale == 5)) {
                 pc->poly = true;
                 pc->wp_off = P.alloc(pc->w_floats);
-                if (pc->hx)
+                if (pc->hx) {
                     for (int prec = 0; prec < 2; ++prec)
                         pc->hxp_off[prec] = P.alloc((size_t)pc->ngroups * pc->nch32 * 3 * pc->MW * (prec == 0 ? 2 : 1) * 256);
+                    pc->hxp_inv_off = P.alloc(pc->b_floats);
+                }
             }
         }
         P.add_conv(&u.d3, 1, u.C, u.C, 3, 3, {single(p + ".conv_block1.1")});
@@ -497,8 +522,31 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
 
     // split-half / bf16 fragments (fastsvc_hx.hip): lane l of fragment (group, chunk, slot, tile m) holds
     // Wt[co = (group*MW + m)*16 + (l & 15)][ci = chunk*32 + 8*(l >> 4) + e][slot], e = 0..7
+    // binary16 pieces (prec 0): every output channel's weights are first multiplied by the power of two that puts
+    // the channel's largest magnitude into [2^14, 2^15) - exact, and it keeps the hi + lo split at 22 bits for every
+    // weight within 2^-17 of that maximum whatever the channel's absolute scale (weight_g) is; the inverse factors go
+    // to inv[table * n16 + co] (ConvParams::whx_inv; the epilogue's bias FMA applies them).  `table_of(ci, slot)`
+    // says which output a fragment feeds (MODE_DEC2: slot 3 = the 1x1 conv; fused pair: the second conv's units).
     auto pack_hx = [&](const PackedConv& c, const size_t (&off)[2], int nslots,
-                       const std::function<float(int, int, int)>& wt) {
+                       const std::function<float(int, int, int)>& wt, size_t inv_off = 0, int ntables = 1,
+                       const std::function<int(int, int)>& table_of = nullptr) {
+        const int n16 = c.ngroups * 16 * c.MW;
+        std::vector<int> ex((size_t)ntables * n16, 0);
+        if (inv_off) {
+            float* inv = blob + inv_off;
+            for (int t = 0; t < ntables; ++t)
+                for (int co = 0; co < n16; ++co) {
+                    float m = 0.f;
+                    if (co < c.cout)
+                        for (int ci = 0; ci < c.cin; ++ci)
+                            for (int slot = 0; slot < nslots; ++slot)
+                                if (!table_of || table_of(ci, slot) == t) m = std::max(m, std::fabs(wt(co, ci, slot)));
+                    int e = 0;
+                    if (m > 0.f && std::isfinite(m)) e = std::min(60, std::max(-60, 14 - std::ilogb(m)));
+                    ex[(size_t)t * n16 + co] = e;
+                    inv[(size_t)t * n16 + co] = std::ldexp(1.0f, -e);
+                }
+        }
         for (int prec = 0; prec < 2; ++prec) {
             const int np = prec == 0 ? 2 : 1;
             uint16_t* hp = reinterpret_cast<uint16_t*>(blob + off[prec]);
@@ -511,8 +559,9 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                                 for (int e = 0; e < 8; ++e) {
                                     const int co = (grp * c.MW + m) * 16 + (lane & 15);
                                     const int ci = ch * 32 + 8 * (lane >> 4) + e;
-                                    const float v = (co < c.cout && ci < c.cin) ? wt(co, ci, slot) : 0.f;
+                                    float v = (co < c.cout && ci < c.cin) ? wt(co, ci, slot) : 0.f;
                                     if (prec == 0) {
+                                        if (inv_off) v = std::ldexp(v, ex[(size_t)(table_of ? table_of(ci, slot) : 0) * n16 + co]);
                                         const uint16_t hi = f32_to_f16(v);
                                         frag[lane * 8 + e] = hi;
                                         frag[512 + lane * 8 + e] = f32_to_f16(v - f16_to_f32(hi));
@@ -561,7 +610,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             if (c.hx)
                 pack_hx(c, c.hx_off, 4, [&](int co, int ci, int slot) {
                     return slot < 3 ? L3.w[((size_t)co * c.cin + ci) * 3 + slot] : L1.w[(size_t)co * c.cin + ci];
-                });
+                }, c.hx_inv_off, 2, [](int, int slot) { return slot == 3 ? 1 : 0; });
             return FASTSVC_OK;
         }
         // virtual dense weight W[co][ci][tap] and bias
@@ -605,7 +654,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                         }
         };
         pack_fragments(W, blob + c.w_off, c.ntaps);
-        if (c.hx) pack_hx(c, c.hx_off, 3, [&](int co, int ci, int tap) { return W[((size_t)co * c.cin + ci) * 3 + tap]; });
+        if (c.hx) pack_hx(c, c.hx_off, 3, [&](int co, int ci, int tap) { return W[((size_t)co * c.cin + ci) * 3 + tap]; }, c.hx_inv_off);
         if (c.wino) {
             // Winograd F(2,3) weight transform G w (fastsvc_kernels.h, MODE_WINO), in f64
             std::vector<float> Ww((size_t)c.cout * c.cin * 4);
@@ -648,10 +697,21 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                 Wp[i + 2] = W[i + 2];
             }
             pack_fragments(Wp, blob + c.wp_off, c.ntaps);
-            if (c.hx) pack_hx(c, c.hxp_off, 3, [&](int co, int ci, int tap) { return Wp[((size_t)co * c.cin + ci) * 3 + tap]; });
+            if (c.hx) pack_hx(c, c.hxp_off, 3, [&](int co, int ci, int tap) { return Wp[((size_t)co * c.cin + ci) * 3 + tap]; }, c.hxp_inv_off);
         }
         float* bp = blob + c.b_off;
         for (int co = 0; co < c.cout; ++co) bp[co] = bias[co];
+        {
+            float l1 = 0.f, bmax = 0.f;
+            const size_t per = (size_t)c.cin * c.ntaps;
+            for (int co = 0; co < c.cout; ++co) {
+                double sum = 0.0;
+                for (size_t i = 0; i < per; ++i) sum += std::fabs((double)W[co * per + i]);
+                l1 = std::max(l1, (float)sum);
+                bmax = std::max(bmax, std::fabs(bias[co]));
+            }
+            blob[c.bnd_off] = l1; blob[c.bnd_off + 1] = bmax;
+        }
         return FASTSVC_OK;
     });
     for (const auto& job_ : plan->chain_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
@@ -672,7 +732,26 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             const int cj = second ? ci - nch * 32 : ci;
             if (cj >= cin) return 0.f;
             return (second ? LB.w : LA.w)[((size_t)co * cin + cj) * 3 + tap];
-        });
+        }, c.hxc_inv_off, 2, [nch](int ci, int) { return ci >= nch * 32 ? 1 : 0; });
+        // bounds of the tensors that never leave LDS: |first conv's output| <= amax_in * l1 + bmax
+        float* cst = blob + c.hxc_inv_off + 2 * (size_t)c.ngroups * 16 * c.MW;
+        auto l1_of = [](const HostLayer& L, int rows, size_t per_row, float& l1, float& bmax) {
+            l1 = 0.f; bmax = 0.f;
+            for (int r = 0; r < rows; ++r) {
+                double sum = 0.0;
+                for (size_t i = 0; i < per_row; ++i) sum += std::fabs((double)L.w[r * per_row + i]);
+                l1 = std::max(l1, (float)sum);
+                bmax = std::max(bmax, std::fabs(L.b[r]));
+            }
+        };
+        l1_of(LA, c.cin, (size_t)c.cout * 3, cst[0], cst[1]);
+        cst[2] = 0.f; cst[3] = 0.f;
+        if (!job.in1.empty()) {
+            HostLayer L1;
+            rc = fetch_layer(sd, job.in1, c.cout, 3, L1);        // stage 0's first conv: 1 -> C, k = 3
+            if (rc != FASTSVC_OK) return rc;
+            l1_of(L1, c.cout, 3, cst[2], cst[3]);
+        }
         return FASTSVC_OK;
     });
     for (const auto& job_ : plan->film_chain_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
@@ -709,7 +788,16 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             const int cj = second ? ci - nch * 32 : ci;
             if (cj >= C2) return 0.f;
             return (second ? WB : WA)[((size_t)co * C2 + cj) * 3 + tap];
-        });
+        }, c.hxc_inv_off, 2, [nch](int ci, int) { return ci >= nch * 32 ? 1 : 0; });
+        float* cst = blob + c.hxc_inv_off + 2 * (size_t)c.ngroups * 16 * c.MW;
+        float l1 = 0.f, bmax = 0.f;
+        for (int co = 0; co < C2; ++co) {
+            double sum = 0.0;
+            for (size_t i = 0; i < (size_t)C2 * 3; ++i) sum += std::fabs((double)WA[(size_t)co * C2 * 3 + i]);
+            l1 = std::max(l1, (float)sum);
+            bmax = std::max(bmax, std::fabs(blob[c.bmid_off + co]));
+        }
+        cst[0] = l1; cst[1] = bmax; cst[2] = 0.f; cst[3] = 0.f;
         return FASTSVC_OK;
     });
     for (const RawParam* r_ : plan->raw_jobs) tasks.emplace_back([&, r = r_]() -> int {
@@ -719,6 +807,17 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         if (rc != FASTSVC_OK) return rc;
         std::memcpy(blob + r->w_off, L.w.data(), r->w_floats * sizeof(float));
         std::memcpy(blob + r->b_off, L.b.data(), r->b_floats * sizeof(float));
+        {
+            float l1 = 0.f, bmax = 0.f;
+            const size_t per = r->w_floats / cout;
+            for (int co = 0; co < cout; ++co) {
+                double sum = 0.0;
+                for (size_t i = 0; i < per; ++i) sum += std::fabs((double)L.w[co * per + i]);
+                l1 = std::max(l1, (float)sum);
+                bmax = std::max(bmax, std::fabs(L.b[co]));
+            }
+            blob[r->bnd_off] = l1; blob[r->bnd_off + 1] = bmax;
+        }
         return FASTSVC_OK;
     });
     static const int env_threads = std::getenv("FASTSVC_PACK_THREADS") ? std::atoi(std::getenv("FASTSVC_PACK_THREADS")) : 0;
@@ -858,6 +957,13 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
     // InstanceNorm accumulators of all blocks side by side: ONE memset zeroes them
     for (int i = 0; i < n; ++i)
         ws.add("up." + std::to_string(i) + ".stats", 3 * B, P.up[i].C, 2, sizeof(double));
+    // float32 storage: largest magnitude per (tensor, utterance) - the scale of the split-binary16 staging
+    // (ConvParams::amax_in / amax_out); an entry is 8 floats wide (writers spread over them, readers take the max).
+    // amax_in: the caller's inputs [lft B | sine B | ppg B]; amax: one row of 2B entries per workspace tensor,
+    // indexed like `bufs` (zeroed at the start of every forward).
+    ws.add("amax_in", 3, B, 8);
+    const int64_t nrows = (int64_t)ws.bufs.size() + 1;
+    ws.add("amax", nrows, 2 * B, 8);
     return ws;
 }
 
@@ -1011,6 +1117,7 @@ hipError_t run_chain(const PackedConv& a, const PackedConv& c, const float* blob
     p.CIN = a.cin; p.CMID = a.cout; p.COUT = c.cout;
     p.nch32 = a.nch32; p.nch32b = c.nch32; p.dil = a.dil; p.dil2 = c.dil; p.ntaps = 3; p.ngroups = c.ngroups;
     p.whx = blob + c.hxc_off[prec]; p.whx_sig = c.hxc_pair[prec];
+    p.whx_inv = (prec == 0 && c.hxc_inv_off) ? blob + c.hxc_inv_off : nullptr; p.whx_inv_sig = c.hxc_inv_pair;
     p.bias = blob + c.b_off; p.bias_sig = pair_b_stride;
     p.bias_mid = blob + c.bmid_off; p.bias_mid_sig = c.bmid_pair;
     p.vec = 1; p.tpw = 1;
@@ -1245,6 +1352,8 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             if (cd.algo == 3) {
                 const int prec = act_bf16 ? 1 : 0;
                 q.whx = blob + (p.mode == MODE_POLY ? c.hxp_off[prec] : c.hx_off[prec]); q.whx_sig = c.hx_pair[prec]; q.nch32 = c.nch32;
+                const size_t inv_off = p.mode == MODE_POLY ? c.hxp_inv_off : c.hx_inv_off;
+                q.whx_inv = (prec == 0 && inv_off) ? blob + inv_off : nullptr; q.whx_inv_sig = c.hx_inv_pair;
                 static const int stagger = std::getenv("FASTSVC_STAGGER") ? std::atoi(std::getenv("FASTSVC_STAGGER")) : 2;
                 q.stagger = stagger;
                 q.xs = 0; q.ps = 0;
@@ -1481,6 +1590,17 @@ int fastsvc_workspace_tap(const fastsvc_plan* plan, int32_t B, int32_t F, const 
                           size_t* byte_offset, int64_t* numel, int64_t shape3[3]) {
     if (!plan || !tap_name || !byte_offset || !numel || !shape3) return fail(FASTSVC_E_INVALID, "null argument");
     const Workspace ws = layout_workspace(*plan, B, F);
+    if (std::strncmp(tap_name, "amax:", 5) == 0) {
+        // the amax row of a workspace tensor (float32 storage): 2B floats, [signal][utterance] for the conditioning
+        // chains' tensors, the first B otherwise
+        const BufferSpec* t = ws.find(tap_name + 5);
+        const BufferSpec* a = ws.find("amax");
+        if (!t || !a) return fail(FASTSVC_E_INVALID, std::string("unknown tap: ") + tap_name);
+        *byte_offset = a->off_bytes + (size_t)(t - ws.bufs.data()) * 2 * B * 8 * sizeof(float);
+        *numel = 2 * B * 8;
+        shape3[0] = 2 * B; shape3[1] = 8; shape3[2] = 1;
+        return FASTSVC_OK;
+    }
     const BufferSpec* b = ws.find(tap_name);
     if (!b) return fail(FASTSVC_E_INVALID, std::string("unknown tap: ") + tap_name);
     *byte_offset = b->off_bytes;
@@ -1499,7 +1619,7 @@ int fastsvc_forward_launch_count(const fastsvc_plan* plan, int32_t with_spk_emb)
     static const bool no_dec2 = std::getenv("FASTSVC_NO_DEC2") != nullptr;
     int down = 3;
     for (int k = 1; k < n; ++k) down += (plan->down[k].rc1[0].dec2 && !no_dec2) ? 3 : 4;
-    return (with_spk_emb ? 1 : 0) + down + 2 * n + 6 * n + 1;
+    return (with_spk_emb ? 1 : 0) + (plan->storage == 0 ? 1 : 0) + down + 2 * n + 6 * n + 1;     // (+ the input scan of float32 storage)
 }
 
 #define HIP_TRY(expr)                                                                          \
@@ -1579,6 +1699,12 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                                                 "(largest per-utterance tensor must stay below 2 GiB): split it");
     }
     const bool spk = spk_emb != nullptr;
+    // amax row of a workspace tensor (float32 storage; see layout_workspace)
+    float* amax_inb = buf("amax_in");
+    float* amaxb = buf("amax");
+    auto am = [&](const std::string& name) -> float* {
+        return amaxb + (size_t)(ws.find(name) - ws.bufs.data()) * 2 * B * 8;
+    };
 
     // ---- raw signals: sig 0 = lft, sig 1 = sine, read in place (the dual-signal launches address signal
     // `sig` as base + sig * stride; the stride between the caller's two tensors is whatever it is) ----
@@ -1586,6 +1712,18 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     const std::ptrdiff_t sig_bytes = reinterpret_cast<const char*>(sine) - reinterpret_cast<const char*>(lft);
     if (sig_bytes % (std::ptrdiff_t)sizeof(float) != 0) return fail(FASTSVC_E_INVALID, "sine / lft must be 4-byte aligned");
     const long sig_stride = (long)(sig_bytes / (std::ptrdiff_t)sizeof(float));
+    static const bool no_scan = std::getenv("FASTSVC_NO_AMAX_SCAN") != nullptr;    // A/B timing only: inputs then count as unit-scale
+    if (P.storage == 0 && !no_scan) {
+        // float32 storage: largest magnitudes of the inputs (scales of the split-binary16 staging) and zeroed amax
+        // rows of the intermediates - ONE small launch, first thing on the caller's stream (everything else is
+        // ordered behind it)
+        const BufferSpec* ab = ws.find("amax");
+        if (prof) HIP_TRY(prof->begin(stream, "amax_inputs", "amax_inputs", 0.0,
+                                      4.0 * ((double)P.cfg.in_channels * F + 2.0 * (double)hop * F) * B));
+        HIP_TRY(launch_amax_inputs(sigbuf, sig_stride, ppg, B, P.cfg.in_channels, F, (int)hop, lengths, amax_inb, amaxb,
+                                   (int)ab->numel, stream));
+        if (prof) HIP_TRY(prof->end());
+    }
 
     // ---- speaker bias for all blocks + zeroed InstanceNorm accumulators: first needed by up block 0, so
     // off the critical path (the down chains) on the second helper stream, joined before the up blocks ----
@@ -1603,6 +1741,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             blocks[i].bias = blob + P.up[i].emb.b_off;
             blocks[i].out = buf("up." + std::to_string(i) + ".spk");
             blocks[i].C = P.up[i].C;
+            blocks[i].amax = P.storage == 0 ? am("up." + std::to_string(i) + ".spk") : nullptr;
         }
         double spk_c = 0; for (int i = 0; i < n; ++i) spk_c += P.up[i].C;
         if (prof) HIP_TRY(prof->begin(s_pre, "spk_proj", "spk_proj", 2.0 * spk_c * P.cfg.spk_emb_size * B,
@@ -1629,6 +1768,13 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         std::memset(&base, 0, sizeof(base));
         base.B = B; base.T = (int)Tk; base.s = 1; base.mode = MODE_DIRECT;
         base.lens = lengths; base.frames_ld = F;
+        base.amax_in_sig = B; base.amax_out_sig = B;               // (2B, C, T) tensors: one amax per (signal, utterance)
+        // MEASURED: the stage's input (raw signal scan / the previous stage's output) and its output h_k; the tensors
+        // in between are bounded from the input's maximum through the layers' (l1, bmax) - ConvParams::bnd_path
+        float* am_prev = k == 0 ? amax_inb : am("down_h." + std::to_string(k - 1));
+        float* am_h = am("down_h." + s);
+        const float* bnd_c1 = blob + (k == 0 ? d.c1_raw[0].bnd_off : d.c1[0].bnd_off);
+        const long bnd_c1_sig = k == 0 ? (long)(d.c1_raw[1].bnd_off - d.c1_raw[0].bnd_off) : d.c1[0].bnd_pair;
         // the stage up to h_k without the whole-stage fusion below: first conv (+ 1x1 residual), then c2 -> c3
         auto stage_unfused = [&](Profiler* pr) -> int {
             if (k == 0) {
@@ -1637,13 +1783,14 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                 HIP_TRY((P.storage == 1 ? bf16::launch_in1_conv : launch_in1_conv)(sigbuf, sig_stride, blob + d.c1_raw[0].w_off, blob + d.c1_raw[0].b_off,
                                         (long)(d.c1_raw[1].w_off - d.c1_raw[0].w_off),
                                         (long)(d.c1_raw[1].b_off - d.c1_raw[0].b_off), c1, 2, B, d.C, (int)Tk,
-                                        lengths, (int)(Tk / F), stream));
+                                        lengths, (int)(Tk / F), stream, nullptr));     // (c1 is bounded, not measured)
                 if (pr) HIP_TRY(pr->end());
             } else {
                 float* r = buf("down_r." + s);
                 ConvParams p = base;                                   // r = conv1x1(h_{k-1}[::s])
                 p.x = hprev; p.x_sig = (long)B * Cprev * Tprev; p.x_b = (long)Cprev * Tprev; p.x_T = (int)Tprev;
                 p.mode = MODE_DECIMATE; p.s = d.scale;
+                p.amax_in = am_prev;
                 static const bool no_dec2 = std::getenv("FASTSVC_NO_DEC2") != nullptr;      // A/B switch
                 if (d.rc1[0].dec2 && !no_dec2) {
                     // both convs of the decimated input in one launch: c1 -> y, r -> y2
@@ -1665,8 +1812,9 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                 ConvParams p = base;                                   // c2 = conv3_d2(lrelu(c1))
                 p.x = c1; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
                 p.flags = F_PRE_LRELU;
+                p.amax_in = am_prev; p.bnd_path[0] = bnd_c1; p.bnd_sig[0] = bnd_c1_sig;       // |c1| <= l1 |h_{k-1}| + bmax
                 ConvParams p3 = p;                                     // h = conv3_d4(lrelu(c2)) + r
-                p3.y = h; p3.y_sig = tsig; p3.y_b = tb;
+                p3.y = h; p3.y_sig = tsig; p3.y_b = tb; p3.amax_out = am_h;
                 if (k == 0) {
                     p3.r1x = sigbuf; p3.r1x_sig = sig_stride; p3.r1x_b = T;
                     p3.r1w = blob + d.r_raw[0].w_off; p3.r1b = blob + d.r_raw[0].b_off;
@@ -1683,7 +1831,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                     p.y = c2; p.y_sig = tsig; p.y_b = tb;
                     HIP_TRY(run_conv(d.c2[0], blob, p, 2, (long)(d.c2[1].w_off - d.c2[0].w_off), (long)(d.c2[1].b_off - d.c2[0].b_off), stream, pr, n2.c_str()));
                     ConvParams q = p3;
-                    q.x = c2;
+                    q.x = c2; q.bnd_path[1] = blob + d.c2[0].bnd_off; q.bnd_sig[1] = d.c2[0].bnd_pair;   // ... and c2 behind it
                     HIP_TRY(run_conv(d.c3[0], blob, q, 2, (long)(d.c3[1].w_off - d.c3[0].w_off), b3, stream, pr, n3.c_str()));
                     return FASTSVC_OK;
                 };
@@ -1718,6 +1866,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             p3.x = sigbuf; p3.x_sig = sig_stride; p3.x_b = T; p3.x_T = (int)Tk;
             p3.flags = F_PRE_LRELU;
             p3.y = h; p3.y_sig = tsig; p3.y_b = tb;
+            p3.amax_in = amax_inb; p3.amax_out = am_h;
             p3.r1x = sigbuf; p3.r1x_sig = sig_stride; p3.r1x_b = T;
             p3.r1w = blob + d.r_raw[0].w_off; p3.r1b = blob + d.r_raw[0].b_off;
             p3.r1_sig = (long)(d.r_raw[1].w_off - d.r_raw[0].w_off);
@@ -1755,10 +1904,14 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                 p.x = h; p.x_sig = tsig; p.x_b = tb; p.x_T = (int)Tk;
                 p.flags = F_POST_LRELU;
                 p.y = u; p.y_sig = tb; p.y_b = 2 * tb;
+                p.amax_in = am_h;
                 HIP_TRY(run_conv(d.film[0], blob, p, 2, (long)(d.film[1].w_off - d.film[0].w_off), (long)(d.film[1].b_off - d.film[0].b_off), sf, pr, nconv.c_str()));
                 ConvParams q = base;                               // [scale ; shift] summed over both signals
                 q.x = u; q.x_sig = 0; q.x_b = 2 * tb; q.x_T = (int)Tk;
                 q.y = ssb; q.y_sig = 0; q.y_b = 2 * tb;
+                // u = [lrelu(conv_lft(h_lft)) ; lrelu(conv_sine(h_sine))]: the larger of the two halves' bounds
+                q.amax_in = am_h; q.amax_in_sig = 0; q.amax_in2 = B;
+                q.bnd_path[0] = blob + d.film[0].bnd_off; q.bnd_sig[0] = d.film[0].bnd_pair;
                 HIP_TRY(run_conv(d.heads, blob, q, 1, 0, 0, sf, pr, nheads.c_str()));
                 return FASTSVC_OK;
             };
@@ -1784,6 +1937,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                 ConvParams p3 = base;
                 p3.x = h; p3.x_sig = tsig; p3.x_b = tb; p3.x_T = (int)Tk; p3.xsplit = d.C;
                 p3.y = ssb; p3.y_sig = 0; p3.y_b = 2 * tb;
+                p3.amax_in = am_h; p3.amax_in2 = B;                 // channels [lft ; sine]: the larger of the two chains' maxima
                 HIP_TRY(run_chain(d.filmc, d.filmc, blob, p3, 1, 0, sf, prof, nchain.c_str(), sep_ms, film_fused));
             }
             if (!film_fused) { const int rc = film_separate(prof); if (rc != FASTSVC_OK) return rc; }
@@ -1844,27 +1998,35 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
 
         if (ss_ready[k]) HIP_TRY(hipStreamWaitEvent(stream, ss_ready[k], 0));   // scale/shift of stage k
 
+        // amax rows (float32 storage): every tensor a convolution stages WITHOUT an InstanceNorm in front
+        float* am_x = i == 0 ? amax_inb + 2 * B * 8 : am("up." + std::to_string(i - 1) + ".out");
+        float* am_p = am("up." + s + ".spk");                      // speaker biases: bound of a normalised row
         ConvParams p = base;                                       // a = conv_first(x)
         p.x = x; p.x_b = (long)Cx * Tin; p.x_T = (int)Tin;
         p.y = a; p.y_b = (long)u.C * Tin; p.T = (int)Tin;
+        p.amax_in = am_x;
         HIP_TRY(run_conv(u.first, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".conv_first").c_str()));
 
         p = base;                                                  // xr = conv_res(stretch(a))
         p.x = a; p.x_b = (long)u.C * Tin; p.x_T = (int)Tin;
         p.mode = MODE_STRETCH; p.s = u.scale;
         p.y = xr; p.y_b = cb; p.T = (int)Tout;
+        p.amax_in = am_x; p.bnd_path[0] = blob + u.first.bnd_off;  // |a| <= l1 |x| + bmax  (xr is only ever a residual: not tracked)
         HIP_TRY(order_after(stream, s_side));                      // a is ready
         HIP_TRY(run_conv(u.res, blob, p, 1, 0, 0, s_side, prof, ("up." + s + ".res_stretch").c_str()));
 
         p.flags = F_PRE_LRELU | F_POST_LRELU | aff_out;            // u1 = aff(lrelu(conv_up(stretch(lrelu(a)))))
         p.y = nullptr; p.y2 = u1; p.y2_b = cb;
         p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st;
+        p.amax_out = spk ? nullptr : am("up." + s + ".u1");        // (with a speaker u1 / u2 / u3 are staged behind the norm)
         HIP_TRY(run_conv(u.up, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".up_stretch").c_str()));
 
         p = base;                                                  // xmid = conv_d3(lrelu(norm(u1))) + xr
         p.x = u1; p.x_b = cb; p.x_T = (int)Tout; p.T = (int)Tout;
         p.flags = pre | aff_out; p.st_in = st; p.spk = pb;
         p.res = xr; p.res_b = cb;
+        p.amax_in = spk ? am_p : am("up." + s + ".u1");           // (behind the norm: sqrt(T) + max |p| bounds the row)
+        p.amax_out = spk ? nullptr : am("up." + s + ".u2"); p.bnd_path[0] = nullptr;
         HIP_TRY(order_after(s_side, stream));                      // xr is ready
         p.y = xm; p.y_b = cb; p.y2 = u2; p.y2_b = cb;              // and u2 = aff(xmid)
         p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn;
@@ -1873,12 +2035,14 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.x = u2; p.st_in = st + stn; p.res = nullptr;             // u3 = aff(conv_d9(lrelu(norm(u2))))
         p.y = nullptr; p.y2 = u3;
         p.st_out = st + 2 * stn;
+        p.amax_in = spk ? am_p : am("up." + s + ".u2"); p.amax_out = spk ? nullptr : am("up." + s + ".u3");
         HIP_TRY(run_conv(u.d9, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d9").c_str()));
 
         p.x = u3; p.st_in = st + 2 * stn;                          // out = conv_d27(lrelu(norm(u3))) + xmid
         p.flags = pre; p.ss_out = nullptr; p.st_out = nullptr; p.y2 = nullptr;
         p.res = xm; p.res_b = cb;
         p.y = xo; p.y_b = cb;
+        p.amax_in = spk ? am_p : am("up." + s + ".u3"); p.amax_out = i + 1 < n ? am("up." + s + ".out") : nullptr;
         if (i == n - 1 && P.cfg.out_channels == 1 && last_fusable) {
             // conv_last in the same launch where the launch has the variant (run_conv decides; the block's
             // C-channel output is then not materialised - a launch table with algorithm 0 under "conv_last|B|T"
