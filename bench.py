@@ -336,11 +336,11 @@ def main():
         ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
         args_dev = [torch.stack([utts[i][k] for i in mine[:B]]) for k in ("ppg", "sine", "lft", "spk_emb")]
 
-        def fwd(ppg, sine, lft, emb):
-            return plan.forward(blob, ppg, sine, lft, emb, workspace=ws)
+        def fwd(ppg, sine, lft, emb, out=None):
+            return plan.forward(blob, ppg, sine, lft, emb, workspace=ws, out=out)
 
         def step(i):
-            D.run_utterance_parallel(fwd, utts, dev, max_batch=64, n_frames=n_frames, hop=cfg.hop)
+            D.run_utterance_parallel(fwd, utts, dev, max_batch=64, n_frames=n_frames, hop=cfg.hop, forward_into=True)
 
         drain = torch.cuda.synchronize
         samples_per_step = float(n_utts) * T

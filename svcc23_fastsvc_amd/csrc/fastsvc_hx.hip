@@ -654,6 +654,8 @@ void conv_hx_kernel(const ConvParams p0) {
     constexpr int NWS = DEC2 ? 4 : 3;                                  // weight slots per unit and channel tile
     constexpr int NVAR = DEC2 ? 2 : 1;                                 // tile variants: LeakyReLU'd (+ raw)
     constexpr int NSLOT = NWS * MW * HX_NP;
+    // this instance's epilogue measures what it writes (ConvParams::amax_out): residual kinds and the fused pair
+    constexpr bool TRACKS = AMAX_TRACK && (CHAIN || (MODE == MODE_DIRECT && (EPI == EPI_RES || EPI == EPI_RANK1)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tid = threadIdx.x;
@@ -715,6 +717,7 @@ void conv_hx_kernel(const ConvParams p0) {
     float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);   // [CINp]
     unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp);             // [2][HX_NP][W rows][64 B]
     // small per-workgroup constants (static LDS; HX_STATIC_LDS bounds them for the launcher's size checks)
+    __shared__ unsigned s_amax, s_cnt;                 // workgroup's largest |value| written (ConvParams::amax_out), waves done
     __shared__ float s_inv[HX_NP == 2 ? 2 * 16 * MW * WM : 4];        // inverse operand scales [conv | second DEC2 output][channel]
     __shared__ __attribute__((aligned(16))) float s_mid[CHAIN ? 2 * (16 * MW * WM + 32) : 4];   // MODE_CHAIN: hx_chain_store's constants
     // ---- operand scales of the split-binary16 products (ConvParams, "dynamic range"; powers of two) ----
@@ -765,13 +768,40 @@ void conv_hx_kernel(const ConvParams p0) {
     const int wlbytes = WLB ? p.nch32b * NSLOT * HX_FRAG : 0;
 
     auto setup_shared = [&]() {
+        // Every global load of the set-up is ISSUED first - InstanceNorm sums and speaker bias of this thread's input
+        // channel (one channel per thread: C_in <= 512), the fused pair's bias / inverse scales of its middle channel,
+        // then the scalar loads of operand_scales() - and waited for once: written one after the other they were two
+        // to three serialised memory round trips in front of the first tile (+1.5-3 us on every fused launch).
+        const int c = tid;
+        double q1 = 0.0, q2 = 0.0;
+        float pc = 0.f;
+        if ((flags & F_PRE_NORM) && c < p.CIN) {
+            q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
+            q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
+            pc = p.spk[(long)b * p.CIN + c];
+        }
+        const int cmidp = CHAIN ? p.nch32b * HX_KC : 0;
+        float bmid = 0.f, imid = 1.f;
+        if constexpr (CHAIN) {
+            if (c < p.CMID) {
+                bmid = p.bias_mid[(long)sig * p.bias_mid_sig + c];
+                if constexpr (HX_NP == 2) { if (invtab) imid = invtab[c]; }
+            }
+        }
         operand_scales();
+        if constexpr (TRACKS) { if (tid == 0) { s_amax = 0u; s_cnt = 0u; } }
         if (flags & F_STATS) {
             for (int i = tid; i < 2 * 16 * MW * WM; i += 512) sstat[i] = 0.0;
         }
         if constexpr (CHAIN) {
             // channel padding of the intermediate tile is never written: it must read as 0, not as LDS garbage
             for (int i = tid * 16; i < t2bytes; i += 512 * 16) *reinterpret_cast<u32x4*>(T2 + i) = u32x4{0u, 0u, 0u, 0u};
+            // first conv's bias and inverse operand scales, times the intermediate tile's scale (hx_chain_store)
+            if (c < cmidp) {
+                const bool ok = c < p.CMID;
+                s_mid[c] = ok ? bmid * s_mid_scale : 0.f;
+                if constexpr (HX_NP == 2) s_mid[cmidp + c] = ok ? imid * (s_mid_scale / sx) : 0.f;
+            }
         }
         if constexpr (WLB) {
             // the second conv's fragments of this (signal, channel group 0): once per workgroup
@@ -782,35 +812,22 @@ void conv_hx_kernel(const ConvParams p0) {
         }
         // prologue coefficients of every input channel, applied by the producers as ONE FMA u * A + Bc:
         // InstanceNorm + speaker bias (u - mean) * rstd + p  ->  A = rstd, Bc = p - mean * rstd (fastsvc.py:134-139);
-        // no norm: (1, 0); channel padding: (0, 0)
-        {
-            const double inv_len = 1.0 / (double)p.x_T;
-            if constexpr (CHAIN) {
-                // first conv's bias and inverse operand scales, times the intermediate tile's scale (hx_chain_store)
-                const int cmidp = p.nch32b * HX_KC;
-                for (int c = tid; c < cmidp; c += 512) {
-                    const bool ok = c < p.CMID;
-                    s_mid[c] = ok ? p.bias_mid[(long)sig * p.bias_mid_sig + c] * s_mid_scale : 0.f;
-                    if constexpr (HX_NP == 2) s_mid[cmidp + c] = ok ? (invtab ? invtab[c] : 1.f) * (s_mid_scale / sx) : 0.f;
+        // no norm: (1, 0); channel padding: (0, 0) - all times sx, the power-of-two scale of the staged tile
+        if (c < CINp) {
+            float2 ab = make_float2(0.f, 0.f);
+            if (c < p.CIN) {
+                ab = make_float2(sx, 0.f);
+                if (flags & F_PRE_NORM) {
+                    const double inv_len = 1.0 / (double)p.x_T;
+                    const double mean = q1 * inv_len;
+                    double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
+                    var = var > 0.0 ? var : 0.0;
+                    const double rstd = 1.0 / sqrt(var + IN_EPS);
+                    ab.x = (float)rstd * sx;
+                    ab.y = (float)((double)pc - mean * rstd) * sx;
                 }
             }
-            for (int c = tid; c < CINp; c += 512) {
-                float2 ab = make_float2(0.f, 0.f);
-                if (c < p.CIN) {
-                    ab = make_float2(sx, 0.f);
-                    if (flags & F_PRE_NORM) {
-                        const double q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
-                        const double q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
-                        const double mean = q1 * inv_len;
-                        double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
-                        var = var > 0.0 ? var : 0.0;
-                        const double rstd = 1.0 / sqrt(var + IN_EPS);
-                        ab.x = (float)rstd * sx;
-                        ab.y = (float)((double)p.spk[(long)b * p.CIN + c] - mean * rstd) * sx;
-                    }
-                }
-                ncoef[c] = ab;
-            }
+            ncoef[c] = ab;
         }
         __syncthreads();
     };
@@ -1170,8 +1187,8 @@ void conv_hx_kernel(const ConvParams p0) {
                 }
                 #pragma unroll
                 for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
-                ws_epilogue_kind<MW, NW, EPI_PLAIN, false, 0>(p, R, acc, s1, s2, sig, mg, tcol0, active, lane, K, Ew);
-                amax_tile_flush(R);
+                ws_epilogue_kind<MW, NW, EPI_PLAIN, false, 0, 1>(p, R, acc, s1, s2, sig, mg, tcol0, active, lane, K, Ew);
+                if constexpr (TRACKS) { if (p.amax_out) amax_tile_flush(R); }
                 stamp(8);
             }
         } else
@@ -1223,14 +1240,14 @@ void conv_hx_kernel(const ConvParams p0) {
                                                                    (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew, Xw);
                         } else
 #endif
-                        ws_epilogue_kind<MW, NW, EPI, EST, 0>(p, R, acc, s1, s2, sig, mg,
+                        ws_epilogue_kind<MW, NW, EPI, EST, 0, -1>(p, R, acc, s1, s2, sig, mg,
                                                               (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
                         if constexpr (LAST_OK) {
                             if (p.last_w && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
                                 hx_last_reduce<MW, NW, PAIRS>(p, acc, k_last, b, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                         }
                     }
-                    amax_tile_flush(R);
+                    if constexpr (TRACKS) { if (p.amax_out) amax_tile_flush(R); }
                     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
@@ -1250,7 +1267,7 @@ void conv_hx_kernel(const ConvParams p0) {
                 stamp(6);
             }
         }
-        amax_flush(p, R, sig, b, active, lane, blockIdx.x + cw);   // (float32 storage: the next conv's split-binary16 scale)
+        if constexpr (TRACKS) amax_flush(p, R, &s_amax, &s_cnt, 4, sig, b, lane, blockIdx.x);   // (float32 storage: the next conv's split-binary16 scale)
         if (nunits & 1) __syncthreads();               // the staging waves' loop runs in pairs of units
     }
     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {   // one f64 global atomic per channel per workgroup
@@ -1339,7 +1356,7 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
 }
 
 hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream) {
-    if (p.ntaps != 3 || (p.T & 3) || !p.whx) return hipErrorInvalidValue;
+    if (p.ntaps != 3 || (p.T & 3) || !p.whx || p.nch32 * HX_KC > 512) return hipErrorInvalidValue;   // (one input channel per thread in the set-up)
 #define FASTSVC_HXS(md, mw, nw, wm, wn) \
     if (cfg.MW == mw && cfg.NW == nw && cfg.WM == wm && cfg.WN == wn) \
         return hx_launch_shape<mw, nw, wm, wn, md>(p, cfg.nsig, stream);

@@ -118,8 +118,9 @@ struct ConvParams {
     // number of MEASURED tensors - each costs its producer device-scope atomics - to one per stage / block.
     const float* bnd_path[2];
     long bnd_sig[2];
-    float* amax_out;             // [sig * amax_out_sig + b]: largest |value| of the tensor the next conv will stage
-    int amax_out_sig;            //   (y; the FiLM-affined y2 for F_AFF_OUT launches); null: not tracked
+    float* amax_out;             // entry sig * amax_out_sig + b: largest |value| of y (residual epilogues and the fused
+    int amax_out_sig;            //   pair's final one measure; null: not tracked)
+    int no_hx;                   // host side only: keep this launch on the exact f32-input MFMA kernels (run_conv)
     // destination (nsig, B, COUT, T); y may be null when only the FiLM-affine output y2 is needed
     float* y;
     long y_sig, y_b;

@@ -426,7 +426,6 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
                     if (y2row) *reinterpret_cast<f32x4*>(y2row + t) = u;
                     s1[m] += (u.x + u.y) + (u.z + u.w);
                     s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
-                    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
                 } else amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             } else {
                 #pragma unroll
@@ -440,7 +439,6 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, f32x4 (&
                         const float u = scrow[t + r] * e + shrow[t + r];
                         if (y2row) y2row[t + r] = u;
                         s1[m] += u; s2[m] += u * u;
-                        amx = fmaxf(amx, fabsf(u));
                     } else amx = fmaxf(amx, fabsf(e));
                 }
             }
@@ -535,6 +533,8 @@ void conv_mfma_kernel(const ConvParams p0) {
     float* nspk = nrstd + CINp;
     float* Xs = nspk + CINp;                                                   // [KC][XS]
 
+    __shared__ unsigned s_amax, s_cnt;                 // (zeroed here; the chunk loop's barriers separate it from the flush)
+    if (tid == 0) { s_amax = 0u; s_cnt = 0u; }
     if (p.flags & F_STATS) {
         for (int i = tid; i < 2 * 16 * MW * WM; i += NTHREADS) sstat[i] = 0.0;
     }
@@ -599,7 +599,7 @@ void conv_mfma_kernel(const ConvParams p0) {
     {
         EpiRsrc R;                                     // (only its running max is used by this kernel)
         conv_epilogue_tile<MW, NW>(p, acc, s1, s2, sig, b, mg, t0 + wave_n * (NW * 16), active, lane, R.amx);
-        amax_flush(p, R, sig, b, active, lane, blockIdx.x + wave);
+        amax_flush(p, R, &s_amax, &s_cnt, NWAVES, sig, b, lane, blockIdx.x);
     }
     #pragma unroll
     for (int m = 0; m < MW; ++m) { d1[m] = (double)s1[m]; d2[m] = (double)s2[m]; }
@@ -716,11 +716,16 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
     float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);  // [CINp]
     float* Xs0 = reinterpret_cast<float*>(ncoef + CINp);                       // [2][KC][XS]
     const int bufsz = p.KC * XS;
+    __shared__ unsigned s_amax, s_cnt;                 // workgroup's largest |value| written (ConvParams::amax_out), waves done
+    // this instance's epilogue measures what it writes: residual kinds (direct / Winograd) and the generic epilogue
+    constexpr bool TRACKS = AMAX_TRACK && (MODE == MODE_DIRECT || MODE == MODE_WINO || MODE == MODE_STRETCH || MODE == MODE_DECIMATE) &&
+                            (EPI == EPI_RES || EPI == EPI_RANK1 || EPI == EPI_GENERIC);
 
     // InstanceNorm coefficients and zeroed sums: run by ALL threads, but only after the producers
     // have their first two window loads and the consumers their weight stream in flight, so the
     // st_in round trip overlaps them instead of preceding them.
     auto setup_shared = [&]() {
+        if constexpr (TRACKS) { if (tid == 0) { s_amax = 0u; s_cnt = 0u; } }
         if (flags & F_STATS) {
             for (int i = tid; i < 2 * 16 * MW * WM; i += 512) sstat[i] = 0.0;
         }
@@ -1005,7 +1010,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                         ws_epilogue_kind<MW, NW, EPI, EST>(p, R, acc, s1, s2, sig, mg,
                                                            (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
                     }
-                    amax_tile_flush(R);
+                    if constexpr (TRACKS) { if (p.amax_out) amax_tile_flush(R); }
                     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
                         // fp32 partials stay short (this tile only); the running sums are f64 in LDS
                         #pragma unroll
@@ -1026,7 +1031,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                 stamp(6);
             }
         }
-        amax_flush(p, R, sig, b, active, lane, blockIdx.x + cw);   // (float32 storage: the next conv's split-binary16 scale)
+        if constexpr (TRACKS) amax_flush(p, R, &s_amax, &s_cnt, 4, sig, b, lane, blockIdx.x);   // (float32 storage: the next conv's split-binary16 scale)
     }
     // one f64 global atomic per channel per workgroup
     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
@@ -1084,7 +1089,7 @@ template <auto KERNEL>
 static hipError_t launch_instance(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const ConvParams& p) {
     if (smem > 64 * 1024) {                            // above the default dynamic-LDS limit: once per instance
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);   // (+ a few static bytes)
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL(KERNEL, grid, block, smem, stream, p);
@@ -1295,7 +1300,7 @@ void in1_conv_kernel(const float* __restrict__ x, long x_sig, const float* __res
     }
     if (amax_out) {                                                 // largest |c1| (lanes past T: bias-sized values)
         const unsigned a = wave_max_u32_lane63(__builtin_bit_cast(unsigned, amx));
-        if ((threadIdx.x & 63) == 63) atomicMax(reinterpret_cast<unsigned*>(amax_out) + z * AMAX_W + ((blockIdx.x + (threadIdx.x >> 6)) & (AMAX_W - 1)), a);
+        if ((threadIdx.x & 63) == 63) atomicMax(reinterpret_cast<unsigned*>(amax_out) + z * AMAX_ENTRY + ((blockIdx.x + (threadIdx.x >> 6)) & (AMAX_W - 1)) * AMAX_STRIDE, a);
     }
 }
 
@@ -1370,7 +1375,7 @@ void amax_inputs_kernel(const float* __restrict__ sig, long sig_stride, const fl
     const unsigned m = wave_max_u32_lane63(__builtin_bit_cast(unsigned, a));
     if ((tid & 63) == 63) red[tid >> 6] = __builtin_bit_cast(float, m);
     __syncthreads();
-    if (tid == 0) amax_in[row * AMAX_W + part] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (tid == 0) amax_in[row * AMAX_ENTRY + part * AMAX_STRIDE] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 hipError_t launch_amax_inputs(const float* sig, long sig_stride, const float* ppg, int B, int C, int F, int hop,
@@ -1497,7 +1502,7 @@ void spk_proj_kernel(const float* __restrict__ emb, const SpkArgs args, int E) {
         const float pc = a + blk.bias[c];
         blk.out[(long)b * blk.C + c] = pc;
         // largest |p| of the utterance: with sqrt(T) it bounds a normalised row (scale of the split-binary16 staging)
-        if (blk.amax) atomicMax(reinterpret_cast<unsigned*>(blk.amax) + b * AMAX_W + (c & (AMAX_W - 1)), __builtin_bit_cast(unsigned, fabsf(pc)));
+        if (blk.amax) atomicMax(reinterpret_cast<unsigned*>(blk.amax) + b * AMAX_ENTRY + (c & (AMAX_W - 1)) * AMAX_STRIDE, __builtin_bit_cast(unsigned, fabsf(pc)));
     }
 }
 

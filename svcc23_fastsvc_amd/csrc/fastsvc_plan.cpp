@@ -958,12 +958,13 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
     for (int i = 0; i < n; ++i)
         ws.add("up." + std::to_string(i) + ".stats", 3 * B, P.up[i].C, 2, sizeof(double));
     // float32 storage: largest magnitude per (tensor, utterance) - the scale of the split-binary16 staging
-    // (ConvParams::amax_in / amax_out); an entry is 8 floats wide (writers spread over them, readers take the max).
+    // (ConvParams::amax_in / amax_out); an entry is 8 slots in 8 different 128-byte lines = 256 floats (writers spread
+    // over the slots, readers take the max).
     // amax_in: the caller's inputs [lft B | sine B | ppg B]; amax: one row of 2B entries per workspace tensor,
     // indexed like `bufs` (zeroed at the start of every forward).
-    ws.add("amax_in", 3, B, 8);
+    ws.add("amax_in", 3, B, 256);
     const int64_t nrows = (int64_t)ws.bufs.size() + 1;
-    ws.add("amax", nrows, 2 * B, 8);
+    ws.add("amax", nrows, 2 * B, 256);
     return ws;
 }
 
@@ -1315,7 +1316,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         static const int hx_env = std::getenv("FASTSVC_HX") ? std::atoi(std::getenv("FASTSVC_HX")) : 1;
         const bool hx_mode = (p.mode == MODE_DIRECT && p.x_T == p.T) || (p.mode == MODE_POLY && c.hxp_off[0]) ||
                              (p.mode == MODE_DEC2 && (p.x_T & 3) == 0);
-        const bool hx_ok = hx_env != 0 && c.hx && hx_mode && c.ntaps == 3 && (p.T & 3) == 0 &&
+        const bool hx_ok = hx_env != 0 && !p.no_hx && c.hx && hx_mode && c.ntaps == 3 && (p.T & 3) == 0 &&
                            c.dil <= 28 && !(p.flags & F_PRE_AFFINE) &&
                            (!p.lens || ((p.len_mul & 3) == 0 && (p.xlen_mul & 3) == 0));
         if (hx_ok) {
@@ -1596,9 +1597,9 @@ int fastsvc_workspace_tap(const fastsvc_plan* plan, int32_t B, int32_t F, const 
         const BufferSpec* t = ws.find(tap_name + 5);
         const BufferSpec* a = ws.find("amax");
         if (!t || !a) return fail(FASTSVC_E_INVALID, std::string("unknown tap: ") + tap_name);
-        *byte_offset = a->off_bytes + (size_t)(t - ws.bufs.data()) * 2 * B * 8 * sizeof(float);
-        *numel = 2 * B * 8;
-        shape3[0] = 2 * B; shape3[1] = 8; shape3[2] = 1;
+        *byte_offset = a->off_bytes + (size_t)(t - ws.bufs.data()) * 2 * B * 256 * sizeof(float);
+        *numel = 2 * B * 256;
+        shape3[0] = 2 * B; shape3[1] = 256; shape3[2] = 1;
         return FASTSVC_OK;
     }
     const BufferSpec* b = ws.find(tap_name);
@@ -1703,7 +1704,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     float* amax_inb = buf("amax_in");
     float* amaxb = buf("amax");
     auto am = [&](const std::string& name) -> float* {
-        return amaxb + (size_t)(ws.find(name) - ws.bufs.data()) * 2 * B * 8;
+        return amaxb + (size_t)(ws.find(name) - ws.bufs.data()) * 2 * B * 256;
     };
 
     // ---- raw signals: sig 0 = lft, sig 1 = sine, read in place (the dual-signal launches address signal
@@ -1999,7 +2000,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         if (ss_ready[k]) HIP_TRY(hipStreamWaitEvent(stream, ss_ready[k], 0));   // scale/shift of stage k
 
         // amax rows (float32 storage): every tensor a convolution stages WITHOUT an InstanceNorm in front
-        float* am_x = i == 0 ? amax_inb + 2 * B * 8 : am("up." + std::to_string(i - 1) + ".out");
+        float* am_x = i == 0 ? amax_inb + 2 * B * 256 : am("up." + std::to_string(i - 1) + ".out");
         float* am_p = am("up." + s + ".spk");                      // speaker biases: bound of a normalised row
         ConvParams p = base;                                       // a = conv_first(x)
         p.x = x; p.x_b = (long)Cx * Tin; p.x_T = (int)Tin;
@@ -2018,15 +2019,18 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.flags = F_PRE_LRELU | F_POST_LRELU | aff_out;            // u1 = aff(lrelu(conv_up(stretch(lrelu(a)))))
         p.y = nullptr; p.y2 = u1; p.y2_b = cb;
         p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st;
-        p.amax_out = spk ? nullptr : am("up." + s + ".u1");        // (with a speaker u1 / u2 / u3 are staged behind the norm)
         HIP_TRY(run_conv(u.up, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".up_stretch").c_str()));
 
         p = base;                                                  // xmid = conv_d3(lrelu(norm(u1))) + xr
         p.x = u1; p.x_b = cb; p.x_T = (int)Tout; p.T = (int)Tout;
         p.flags = pre | aff_out; p.st_in = st; p.spk = pb;
         p.res = xr; p.res_b = cb;
-        p.amax_in = spk ? am_p : am("up." + s + ".u1");           // (behind the norm: sqrt(T) + max |p| bounds the row)
-        p.amax_out = spk ? nullptr : am("up." + s + ".u2"); p.bnd_path[0] = nullptr;
+        // Behind the norm sqrt(T) + max |p| bounds the staged row.  WITHOUT a speaker embedding there is no norm
+        // (fastsvc.py:134-140): the three FiLM affines of a block multiply unnormalised activations, nothing bounds
+        // them short of measuring every FiLM-affined tensor in the store-bound FiLM epilogues - that path keeps
+        // these three convs on the exact f32-input MFMA kernels instead (float32 storage; bf16 has float32's range)
+        p.amax_in = spk ? am_p : nullptr;
+        p.no_hx = (!spk && P.storage == 0) ? 1 : 0;
         HIP_TRY(order_after(s_side, stream));                      // xr is ready
         p.y = xm; p.y_b = cb; p.y2 = u2; p.y2_b = cb;              // and u2 = aff(xmid)
         p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn;
@@ -2035,14 +2039,14 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.x = u2; p.st_in = st + stn; p.res = nullptr;             // u3 = aff(conv_d9(lrelu(norm(u2))))
         p.y = nullptr; p.y2 = u3;
         p.st_out = st + 2 * stn;
-        p.amax_in = spk ? am_p : am("up." + s + ".u2"); p.amax_out = spk ? nullptr : am("up." + s + ".u3");
+        
         HIP_TRY(run_conv(u.d9, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d9").c_str()));
 
         p.x = u3; p.st_in = st + 2 * stn;                          // out = conv_d27(lrelu(norm(u3))) + xmid
         p.flags = pre; p.ss_out = nullptr; p.st_out = nullptr; p.y2 = nullptr;
         p.res = xm; p.res_b = cb;
         p.y = xo; p.y_b = cb;
-        p.amax_in = spk ? am_p : am("up." + s + ".u3"); p.amax_out = i + 1 < n ? am("up." + s + ".out") : nullptr;
+        p.amax_out = i + 1 < n ? am("up." + s + ".out") : nullptr;
         if (i == n - 1 && P.cfg.out_channels == 1 && last_fusable) {
             // conv_last in the same launch where the launch has the variant (run_conv decides; the block's
             // C-channel output is then not materialised - a launch table with algorithm 0 under "conv_last|B|T"

@@ -103,13 +103,20 @@ class GatherSchedule:
     per rank with rows_r / T_r the largest batch / longest utterance of that round over all ranks."""
 
     def __init__(self, n_frames: Sequence[int], hop: int, world: int, max_batch: int, ragged: bool,
-                 pad_tolerance: float):
+                 pad_tolerance: float, min_split: int = 8):
         self.world = world
         self.hop = hop
         self.n_frames = [int(f) for f in n_frames]
         self.shards = shard_utterances(self.n_frames, world)
         self.batches = [plan_batches(s, self.n_frames, max_batch, ragged, pad_tolerance) for s in self.shards]
         self.n_rounds = max((len(b) for b in self.batches), default=0)
+        if world > 1 and self.n_rounds == 1 and max(len(b[0]) for b in self.batches if b) >= 2 * min_split:
+            # one round only (e.g. BASELINE cfg4 on 8 ranks: 64 utterances each = one batch): its gather would start
+            # after ALL the compute and overlap nothing - halve every rank's batch so that the first half's
+            # waveforms travel while the second half computes
+            self.batches = [[b[0][: (len(b[0]) + 1) // 2], b[0][(len(b[0]) + 1) // 2:]] if b else [] for b in self.batches]
+            self.batches = [[c for c in b if c] for b in self.batches]
+            self.n_rounds = max((len(b) for b in self.batches), default=0)
         self.rows: List[int] = []
         self.cols: List[int] = []
         for r in range(self.n_rounds):
@@ -246,10 +253,17 @@ class _Stager:
             for j, i in enumerate(chunk):
                 hb[j] = torch.as_tensor(self.utts[i]["spk_emb"])
             host["spk_emb"] = hb
+        compute = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.copy_stream):
             dev = {k: v.to(self.device, non_blocking=True) for k, v in host.items()}
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
+        # The device batch is allocated from the COPY stream's pool but consumed by kernels on the compute stream
+        # (which only waits on `ready`): tell the caching allocator, or the blocks go back to the copy-stream pool
+        # when the caller drops the batch and a later stage() may start its H2D copy into them while batch r's
+        # kernels are still queued (the host runs ahead of the GPU) - ADVICE r2.
+        for t in dev.values():
+            t.record_stream(compute)
         self.pin_free[slot] = ready
         return dev["ppg"], dev["sine"], dev["lft"], dev.get("spk_emb"), ready
 
@@ -258,14 +272,16 @@ def run_utterance_parallel(forward_fn: Callable[..., torch.Tensor],
                            utterances: Sequence[Optional[dict]], device, max_batch: int = 64, group=None,
                            ragged: bool = False, pad_tolerance: float = 0.125,
                            out_channels: int = 1, n_frames: Optional[Sequence[int]] = None,
-                           hop: Optional[int] = None) -> List[Optional[torch.Tensor]]:
+                           hop: Optional[int] = None, forward_into: bool = False) -> List[Optional[torch.Tensor]]:
     """Shard `utterances` (dicts with 'ppg' (C,F), 'sine' (1,T), 'lft' (1,T), optional 'spk_emb'
     (E,)) over the ranks, run `forward_fn(ppg, sine, lft, emb)` on same-length batches - or, with
     `ragged`, `forward_fn(ppg, sine, lft, emb, lengths)` on zero-padded batches of similar length -
     and all-gather the waveforms ((out_channels, T) each, indexed like `utterances`).
 
     Every rank passes the same list; only its own shard is touched, so entries of other ranks'
-    utterances may be None when `n_frames` (frame count of every utterance) and `hop` are given."""
+    utterances may be None when `n_frames` (frame count of every utterance) and `hop` are given.
+    `forward_into`: `forward_fn` accepts `out=` (a (b, C, T) float32 view) and writes its result there - the
+    waveforms then land in the gather's send buffer without a copy."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     device = torch.device(device)
@@ -283,7 +299,9 @@ def run_utterance_parallel(forward_fn: Callable[..., torch.Tensor],
     staged = stager.stage(mine[0], max(sched.n_frames[i] for i in mine[0])) if mine else None
     rounds: List[Tuple[torch.Tensor, object]] = []
     for r in range(sched.n_rounds):
-        rows = torch.zeros((sched.rows[r], out_channels, sched.cols[r]), dtype=torch.float32, device=device)
+        # this rank's rows of round r's gather: (largest batch, C, longest utterance) over all ranks; what the
+        # forward does not write (fewer / shorter utterances than the round's maximum, or no batch at all) is zeroed
+        rows = torch.empty((sched.rows[r], out_channels, sched.cols[r]), dtype=torch.float32, device=device)
         if r < len(mine):
             chunk = mine[r]
             ppg, sine, lft, emb, ready = staged
@@ -291,14 +309,28 @@ def run_utterance_parallel(forward_fn: Callable[..., torch.Tensor],
                 staged = stager.stage(mine[r + 1], max(sched.n_frames[i] for i in mine[r + 1]))
             if ready is not None:
                 torch.cuda.current_stream(device).wait_event(ready)
+            nb, width = len(chunk), int(sine.shape[-1])
+            # the forward writes STRAIGHT into the send buffer when its output is a contiguous leading block of it
+            # (always, for equal-length sets such as BASELINE cfg4) and the forward function takes `out=`
+            direct = forward_into and width == sched.cols[r]
+            kw = {"out": rows[:nb]} if direct else {}
             if ragged:
                 lens = [sched.n_frames[i] for i in chunk]
-                y = forward_fn(ppg, sine, lft, emb, lens)
+                y = forward_fn(ppg, sine, lft, emb, lens, **kw)
             else:
-                y = forward_fn(ppg, sine, lft, emb)
+                y = forward_fn(ppg, sine, lft, emb, **kw)
             if y.shape[1] != out_channels:
                 raise ValueError(f"forward_fn returned {y.shape[1]} channels, out_channels={out_channels}")
-            rows[: y.shape[0], :, : y.shape[-1]] = y
+            if direct and y.data_ptr() != rows.data_ptr():
+                raise ValueError("forward_fn ignored `out=`: pass forward_into=False")
+            if not direct:
+                rows[:nb, :, :width] = y
+                if width < sched.cols[r]:
+                    rows[:nb, :, width:].zero_()
+            if nb < sched.rows[r]:
+                rows[nb:].zero_()
+        else:
+            rows.zero_()
         rounds.append(_gather_rows(rows, world, group, async_op=True))
     out: List[Optional[torch.Tensor]] = [None] * n_total
     for r, (gathered, work) in enumerate(rounds):

@@ -267,6 +267,11 @@ class Plan:
     def workspace_bytes(self, B: int, F: int) -> int:
         return int(self.lib.fastsvc_workspace_bytes(self._h, B, F))
 
+    def padded_frames(self, F: int) -> int:
+        """Frame count the library actually runs for an F-frame batch: bfloat16 storage pads to a multiple of 4
+        (and runs the batch as a ragged one), float32 storage takes any F."""
+        return F + ((-F) % 4) if self.storage == "bfloat16" else F
+
     def pack(self, state_dict: Mapping[str, object], reuse_pinned: bool = False) -> torch.Tensor:
         """Fold weight-norm and pack a state dict (either key layout) into the kernel blob.
 
@@ -362,32 +367,61 @@ class Plan:
         ppg, sine, lft = (t.to(torch.float32).contiguous() for t in (ppg, sine, lft))
         if spk_emb is not None:
             spk_emb = spk_emb.to(torch.float32).contiguous()
-        if self.storage == "bfloat16" and F % 4 != 0 and profile is None and not autotune:
+        if self.storage == "bfloat16" and F % 4 != 0 and profile is None:
             # bfloat16 storage moves 4 time steps per access at the frame rate, so the library wants F % 4 == 0
             # (three of four real utterances are not): pad to the next multiple and run the padded batch as a
-            # ragged one - `lengths` makes every utterance exactly what it would be alone at its own length
-            pad = (-F) % 4
+            # ragged one - `lengths` makes every utterance exactly what it would be alone at its own length.
+            # The caller's workspace is used when it holds the padded batch (size it with
+            # `workspace_bytes(B, padded_frames(F))`); the padded inputs live in one reused staging set.
+            if autotune:
+                raise ValueError("bfloat16 storage: autotune needs a frame count that is a multiple of 4 "
+                                 "(tune the padded length: launch shapes are keyed by the padded row lengths)")
+            Fp = self.padded_frames(F)
             hop = cfg.hop
-            fpad = torch.nn.functional.pad
-            y = self.forward(blob, fpad(ppg, (0, pad)), fpad(sine, (0, pad * hop)), fpad(lft, (0, pad * hop)), spk_emb,
-                             workspace=None, lengths=[F] * B if lengths is None else lengths)[..., :T]
-            if out is not None:
-                out.copy_(y)
-                return out
-            return y.contiguous()
+            key = (B, Fp, str(dev))
+            if getattr(self, "_pad_key", None) != key:
+                self._pad_bufs = (torch.zeros((B, cfg.in_channels, Fp), dtype=torch.float32, device=dev),
+                                  torch.zeros((B, 1, Fp * hop), dtype=torch.float32, device=dev),
+                                  torch.zeros((B, 1, Fp * hop), dtype=torch.float32, device=dev),
+                                  torch.empty((B, cfg.out_channels, Fp * hop), dtype=torch.float32, device=dev))
+                self._pad_key = key
+            pp, ps, pl, py = self._pad_bufs
+            pp[..., :F].copy_(ppg); ps[..., :T].copy_(sine); pl[..., :T].copy_(lft)      # (the padding stays zero)
+            ok_ws = workspace is not None and workspace.numel() >= self.workspace_bytes(B, Fp)
+            self.forward(blob, pp, ps, pl, spk_emb, out=py, workspace=workspace if ok_ws else None,
+                         lengths=[F] * B if lengths is None else lengths)
+            if out is None:
+                return py[..., :T].contiguous()
+            out.copy_(py[..., :T])
+            return out
         lens_dev = None
         if lengths is not None:
-            lens_host = torch.as_tensor(lengths, dtype=torch.int64, device="cpu").reshape(-1)
-            if lens_host.numel() != B or int(lens_host.min()) < 1 or int(lens_host.max()) > F:
-                raise ValueError(f"lengths must hold {B} frame counts in [1, {F}]")
             if autotune:
                 raise ValueError("autotune times full-length batches: call it without lengths")
-            lens_dev = lens_host.to(torch.int32).to(dev)
+            if isinstance(lengths, torch.Tensor) and lengths.is_cuda:
+                # already on the device: used as is (int32, B entries; range checked by the caller - reading it back
+                # here would synchronise)
+                if lengths.device != dev or lengths.numel() != B:
+                    raise ValueError(f"lengths must hold {B} frame counts on {dev}")
+                lens_dev = lengths.reshape(-1).to(torch.int32).contiguous()
+            else:
+                lens_host = torch.as_tensor(lengths, dtype=torch.int64, device="cpu").reshape(-1)
+                if lens_host.numel() != B or int(lens_host.min()) < 1 or int(lens_host.max()) > F:
+                    raise ValueError(f"lengths must hold {B} frame counts in [1, {F}]")
+                # through page-locked memory: a pageable source makes the copy block the host until it is done
+                # (the header promises a forward that never synchronises)
+                pinned = torch.empty(B, dtype=torch.int32, pin_memory=True)
+                pinned.copy_(lens_host)
+                lens_dev = pinned.to(dev, non_blocking=True)
+                self._last_lens_host = pinned                       # alive until the copy has run
         need = self.workspace_bytes(B, F)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         if out is None:
             out = torch.empty((B, cfg.out_channels, T), dtype=torch.float32, device=dev)
+        elif out.dtype != torch.float32 or tuple(out.shape) != (B, cfg.out_channels, T) or out.device != dev or \
+                not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous float32 {(B, cfg.out_channels, T)} tensor on {dev}")
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             common = (

@@ -252,14 +252,19 @@ class FastSVCGenerator(nn.Module):
         return self._plan
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, s, l, spk_emb=None, *, lengths=None):
+    def forward(self, x, s, l, spk_emb=None, *, lengths=None, out=None):
         """x (B, in_channels, F) PPG - s (B, 1, T) sine - l (B, 1, T) loudness -
         spk_emb (B, spk_emb_size) or None  ->  (B, out_channels, T), T = F * prod(scales).
         Same contract as fastsvc.py:305-332 (raw conv_last output, no tanh).
 
         Extension (keyword only, not in the reference): ``lengths`` = per-utterance frame counts of
         a padded ragged batch; utterance b is computed as if run alone with lengths[b] frames and
-        the padding of the output is zero."""
+        the padding of the output is zero.  ``out`` (inference only): a contiguous float32 (B, out_channels, T)
+        tensor the waveform is written into (e.g. a collective's send buffer).
+
+        Autograd: the route that saves inputs / parameters for a backward pass is taken in training mode
+        (``model.train()``), or when an INPUT requires grad; ``model.eval()`` always runs the plain HIP forward, with
+        or without ``torch.no_grad()`` - as inference code expects (no graph retained, ``lengths`` allowed)."""
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise FastSVCError("FastSVCGenerator (HIP) needs GPU tensors; there is no CPU fallback "
                                "(the CPU oracle lives in oracle/ and is test infrastructure only)")
@@ -270,34 +275,37 @@ class FastSVCGenerator(nn.Module):
         if spk_emb is not None and not self.use_spk_emb:
             raise ValueError("spk_emb given but the generator was built with use_spk_emb=False")
         needs_grad = torch.is_grad_enabled() and (
-            any(p.requires_grad for p in self.parameters()) or
+            (self.training and any(p.requires_grad for p in self.parameters())) or
             any(isinstance(t, torch.Tensor) and t.requires_grad for t in (x, s, l, spk_emb)))
         if needs_grad:
             # training (train_fastsvc.py:157-240 calls the module under autograd): HIP forward, PyTorch-ROCm
             # autograd backward over a restatement of the same dataflow - see autograd.py (first slice)
             if lengths is not None:
                 raise NotImplementedError("ragged batches (`lengths`) are an inference extension: no backward")
+            if out is not None:
+                raise ValueError("`out=` is an inference extension: no backward through it")
             from .autograd import forward_with_grad
             return forward_with_grad(self, x, s, l, spk_emb)
-        return self._forward_device(x, s, l, spk_emb, lengths)
+        return self._forward_device(x, s, l, spk_emb, lengths, out)
 
-    def _forward_device(self, x, s, l, spk_emb, lengths):
+    def _forward_device(self, x, s, l, spk_emb, lengths, out=None):
         """The HIP forward proper (no autograd): packed weights, workspace sub-batching, C-ABI call."""
         hop = self._cfg.hop
         blob = self.packed_weights(x.device)
         plan = self.plan
         B, _, F = x.shape
         step = B
-        while step > 1 and plan.workspace_bytes(step, F) > self.max_workspace_bytes:
+        Fw = plan.padded_frames(F)                 # (bfloat16 storage runs frame counts padded to a multiple of 4)
+        while step > 1 and plan.workspace_bytes(step, Fw) > self.max_workspace_bytes:
             step = (step + 1) // 2
         if step == B:
             tune = bool(self.autotune) and lengths is None and (B, F, str(x.device)) not in self._tuned_shapes
-            y = plan.forward(blob, x, s, l, spk_emb, autotune=tune, lengths=lengths)
+            y = plan.forward(blob, x, s, l, spk_emb, autotune=tune, lengths=lengths, out=out)
             if tune:
                 self._tuned_shapes.add((B, F, str(x.device)))
         else:
-            y = torch.empty((B, self.out_channels, F * hop), dtype=torch.float32, device=x.device)
-            ws = torch.empty(plan.workspace_bytes(step, F), dtype=torch.uint8, device=x.device)
+            y = out if out is not None else torch.empty((B, self.out_channels, F * hop), dtype=torch.float32, device=x.device)
+            ws = torch.empty(plan.workspace_bytes(step, Fw), dtype=torch.uint8, device=x.device)
             for b0 in range(0, B, step):
                 b1 = min(B, b0 + step)
                 plan.forward(blob, x[b0:b1], s[b0:b1], l[b0:b1],

@@ -68,8 +68,26 @@ def _worker(rank, world, port, q):
         y1 = D.run_utterance_parallel(_fake_forward, utts[:1], torch.device("cpu"), max_batch=2)
         # ad-hoc gather without a shared schedule: rank 1 passes nothing, device and channels explicit
         adhoc = D.all_gather_waveforms([(0, ys[3].clone())] if rank == 0 else [], 2, device=torch.device("cpu"), channels=1)
+        # an equal-length set that is ONE batch per rank (the shape of BASELINE cfg4 on 8 ranks): the schedule splits
+        # the lone round in two so that the first half's gather overlaps the second half's compute, and a forward
+        # that takes `out=` writes straight into the gather's send buffer
+        cfg = S.TINY_CONFIG
+        eq = []
+        for i in range(32):
+            b = S.synth_batch(cfg, 1, 6, 500 + i)
+            eq.append(dict(ppg=b.ppg[0], sine=b.sine[0], lft=b.lft[0], spk_emb=b.spk_emb[0]))
+        calls = []
+
+        def fwd_into(ppg, sine, lft, emb, out=None):
+            calls.append((int(ppg.shape[0]), out is not None))
+            y = _fake_forward(ppg, sine, lft, emb)
+            out.copy_(y)
+            return out
+
+        yq = D.run_utterance_parallel(fwd_into, eq, torch.device("cpu"), max_batch=64, forward_into=True)
         q.put((rank, blob.numpy().copy(), [y.numpy().copy() for y in ys], [y.numpy().copy() for y in yr],
-               [y.numpy().copy() for y in y1], [None if y is None else y.numpy().copy() for y in adhoc]))
+               [y.numpy().copy() for y in y1], [None if y is None else y.numpy().copy() for y in adhoc],
+               [y.numpy().copy() for y in yq], calls))
     finally:
         dist.destroy_process_group()
 
@@ -94,8 +112,8 @@ def test_two_ranks_broadcast_shard_gather():
         p.start()
     res = {}
     for _ in range(world):
-        rank, blob, ys, yr, y1, adhoc = q.get(timeout=120)
-        res[rank] = (blob, ys, yr, y1, adhoc)
+        rank, blob, ys, yr, y1, adhoc, yq, calls = q.get(timeout=120)
+        res[rank] = (blob, ys, yr, y1, adhoc, yq, calls)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -112,6 +130,14 @@ def test_two_ranks_broadcast_shard_gather():
             for got in (res[r][1][i], res[r][2][i]):      # same-length buckets, and padded ragged batches
                 assert got.shape == want.shape
                 assert np.allclose(got, want, atol=1e-6)
+    # the one-batch-per-rank set: two rounds of 8 utterances per rank, every forward wrote into the send buffer
+    cfg = S.TINY_CONFIG
+    for r in range(world):
+        assert res[r][6] == [(8, True), (8, True)]
+        for i in range(32):
+            b = S.synth_batch(cfg, 1, 6, 500 + i)
+            want = _fake_forward(*(torch.from_numpy(a) for a in (b.ppg, b.sine, b.lft, b.spk_emb)))[0].numpy()
+            assert np.allclose(res[r][5][i], want, atol=1e-6)
     # the one-utterance set (empty shard on rank 1) and the schedule-free gather
     for r in range(world):
         assert len(res[r][3]) == 1 and np.allclose(res[r][3][0], res[0][1][0], atol=1e-6)
@@ -131,6 +157,12 @@ def test_gather_schedule_is_rank_independent_and_covers_everything():
                 assert all(frames[i] * 160 <= s.cols[r] for i in b)
     empty = D.GatherSchedule([4], 160, 8, max_batch=64, ragged=False, pad_tolerance=0.125)
     assert empty.n_rounds == 1 and sum(len(empty.batch(rk, 0)) for rk in range(8)) == 1
+    # BASELINE cfg4 on 8 ranks: 64 utterances per rank would be ONE round; it is split so the gather overlaps compute
+    c4 = D.GatherSchedule([1500] * 512, 160, 8, max_batch=64, ragged=False, pad_tolerance=0.125)
+    assert c4.n_rounds == 2 and all(len(c4.batch(rk, r)) == 32 for rk in range(8) for r in range(2))
+    assert sorted(i for rk in range(8) for r in range(2) for i in c4.batch(rk, r)) == list(range(512))
+    # a single rank has nothing to overlap with: one round of 64
+    assert D.GatherSchedule([1500] * 64, 160, 1, max_batch=64, ragged=False, pad_tolerance=0.125).n_rounds == 1
 
 
 def test_ragged_buckets_bound_the_padding():
