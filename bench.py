@@ -180,11 +180,15 @@ def roofline(plan, blob, args_dev, ms_per_step, n_prof=3, lengths=None):
     peak_tf = kernel_peak_tflops(kern)
     t_mfma = a["flops"] / (peak_tf * 1e12)
     t_hbm = a["bytes"] / (PEAK_HBM_GBS * 1e9)
-    traffic = None
+    # HBM bytes per launch from the PMC counters: they need separate rocprofv3 --pmc passes (tools/pmc.sh), so the
+    # figure comes from the committed summary of the same command, not from this run - `traffic_source` says which
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get(kern)
+            traffic_source = ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of `bench.py`, tools/pmc.sh + "
+                              "tools/pmc_summary.py; regenerated whenever a kernel changes) - not measured by this run")
         except Exception:
             traffic = None
     if t_mfma >= t_hbm:
@@ -193,7 +197,8 @@ def roofline(plan, blob, args_dev, ms_per_step, n_prof=3, lengths=None):
         out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
     roof_step = roof_ms_total / n_prof
     out.update({
-        "traffic": traffic, "kernel": kern, "kernel_choice": "largest time lost against its own roofline",
+        "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+        "kernel": kern, "kernel_choice": "largest time lost against its own roofline",
         "avg_launch_us": a["ms"] * 1e3 / a["launches"], "launches_per_step": a["launches"] // n_prof,
         "share_of_step": a["ms"] / total_ms, "lost_ms_per_step": (a["ms"] - a["roof_ms"]) / n_prof,
         "alg_flops_per_launch": a["flops"] / a["launches"], "alg_bytes_per_launch": a["bytes"] / a["launches"],
@@ -268,6 +273,70 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
     del ws, out, args_dev, blob
     torch.cuda.empty_cache()
     return res
+
+
+def run_cfg4_single_gpu(cfg, dev, steps=3, warmup=1):
+    """BASELINE config 4's single-GPU leg: the 512 x 10 s set through `run_utterance_parallel` (the multi-GPU code
+    path) on a 1-rank RCCL group, inputs resident in HBM, waveforms gathered into the result list."""
+    import torch.distributed as dist1
+    from svcc23_fastsvc_amd import distributed as D
+    wl = S.WORKLOADS["cfg4"]
+    n_utts, F = wl["B"], wl["F"]
+    T = F * cfg.hop
+    own_group = not dist1.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
+        dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        plan = A.Plan(cfg, compact_workspace=True)
+        blob = plan.pack(S.synth_state_dict(cfg, WEIGHT_SEED)).to(dev)
+        utts = []
+        for c0 in range(0, n_utts, 64):
+            ppg, sine, lft, emb = S.device_batch(cfg, 64, F, wl["seed"] + c0, dev)
+            utts += [dict(ppg=ppg[j], sine=sine[j], lft=lft[j], spk_emb=emb[j]) for j in range(64)]
+        ws = torch.empty(plan.workspace_bytes(64, F), dtype=torch.uint8, device=dev)
+
+        def fwd(ppg, sine, lft, emb, out=None):
+            return plan.forward(blob, ppg, sine, lft, emb, workspace=ws, out=out)
+
+        def step(i):
+            D.run_utterance_parallel(fwd, utts, dev, max_batch=64, n_frames=[F] * n_utts, hop=cfg.hop, forward_into=True)
+
+        elapsed = time_steps(step, torch.cuda.synchronize, steps, warmup, None, dev)
+        ms = elapsed / steps * 1e3
+        res = {"workload": f"cfg4: {wl['desc']} on ONE GPU (8 batches of 64 through run_utterance_parallel, 1-rank RCCL group)",
+               "ms_per_step": ms, "value": n_utts * T * steps / elapsed, "unit": "samples/s", "steps": steps, "warmup": warmup,
+               "dtype": plan.arithmetic, "data": "synthetic (generated on the device)"}
+        del ws, utts, blob
+        torch.cuda.empty_cache()
+        return res
+    finally:
+        if own_group:
+            dist1.destroy_process_group()
+
+
+def run_off_table_shape(cfg, dev, B=5, F=731, steps=50, warmup=10):
+    """A shape the shipped launch table has no entries for (real decode batches never are on it): the static cost
+    model's launch shapes against on-device autotuning of the same (B, F)."""
+    T = F * cfg.hop
+    args_dev = list(S.device_batch(cfg, B, F, 4711, dev))
+    out = {"workload": f"off-table: {B} x {F} frames ({T} samples each), float32 storage"}
+    for mode in ("cost_model", "autotuned"):
+        plan = A.Plan(cfg, compact_workspace=True)
+        blob = plan.pack(S.synth_state_dict(cfg, WEIGHT_SEED)).to(dev)
+        ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+        n_entries = sum(1 for k in plan.tuned_shapes() if k.split("|")[1] == str(B))
+        if mode == "autotuned":
+            plan.forward(blob, *args_dev, workspace=ws, autotune=True)
+        elapsed = time_steps(lambda i: plan.forward(blob, *args_dev, workspace=ws), torch.cuda.synchronize, steps, warmup, None, dev)
+        out[mode] = {"ms_per_step": elapsed / steps * 1e3, "value": B * T * steps / elapsed, "unit": "samples/s",
+                     "table_entries_for_this_batch_size_before": n_entries,
+                     "autotune_trials": plan.last_autotune_trials if mode == "autotuned" else 0}
+        del ws, blob
+    out["cost_model_over_autotuned"] = out["cost_model"]["ms_per_step"] / out["autotuned"]["ms_per_step"]
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -393,6 +462,14 @@ def main():
                                                                              use_table=not args.no_table)
                 except Exception as e:        # an extra block must never take the headline line down
                     secondary[f"{name}_{storage}"] = {"error": repr(e)}
+            for key, fn in (("cfg1_float32", lambda: run_single_gpu_workload(cfg, "cfg1", "float32", dev, steps=200, warmup=50,
+                                                                               use_table=not args.no_table)),
+                            ("cfg4_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev)),
+                            ("off_table_shape", lambda: run_off_table_shape(cfg, dev))):
+                try:
+                    secondary[key] = fn()
+                except Exception as e:
+                    secondary[key] = {"error": repr(e)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_seconds)

@@ -241,8 +241,10 @@ class Plan:
         half-precision MFMA kernels of csrc/fastsvc_hx.hip)."""
         hx = os.environ.get("FASTSVC_HX", "1") != "0"
         if self.storage == "float32":
-            return ("f32 (conv products as exact split-binary16 pairs on the f16 MFMA, x*w = xh*wh + xh*wl + xl*wh, "
-                    "f32 accumulate: fp32-class, 4e-6 of the f32-MFMA path)") if hx else "f32"
+            return ("f32 (conv products as split-binary16 pairs on the f16 MFMA, x*w = xh*wh + xh*wl + xl*wh with f32 "
+                    "accumulation; weights scaled per output channel and activations per tensor and utterance by exact "
+                    "powers of two into binary16's range, undone in the epilogue: fp32-class, 4e-6 of the f32-MFMA path, "
+                    "held over 2^-20..2^8 input / weight scales by tests/test_dynamic_range_gpu.py)") if hx else "f32"
         return ("bf16 (bf16 MFMA products, f32 accumulate, bf16 activation storage)" if hx
                 else "f32 arithmetic, bf16 activation storage")
 

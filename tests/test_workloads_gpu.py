@@ -129,6 +129,85 @@ def test_utterance_parallel_path_on_the_nccl_backend(dev):
     finally:
         dist.destroy_process_group()
 
+def test_cfg4_single_gpu_leg_512_utterances_through_the_sharded_path(dev):
+    """BASELINE config 4 at N = 1: the 512 x 10 s set through `run_utterance_parallel` (the multi-GPU code path:
+    LPT shard, batches of 64, forward straight into the gather's send buffer, RCCL all-gather) on a 1-rank nccl
+    group with the compact workspace.  Full size: shape / finiteness / every utterance present; utterances 0 and 511
+    against the oracle; and the same utterance at two positions of the set gives the same waveform."""
+    import torch.distributed as dist
+    from svcc23_fastsvc_amd import distributed as D
+    cfg = S.FULL_CONFIG
+    wl = S.WORKLOADS["cfg4"]
+    n_utts, F = wl["B"], wl["F"]
+    T = F * cfg.hop
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sd = S.synth_state_dict(cfg, 201)
+        plan = A.Plan(cfg, compact_workspace=True)
+        blob = plan.pack(sd).to(dev)
+        utts = []
+        for c0 in range(0, n_utts, 64):
+            ppg, sine, lft, emb = S.device_batch(cfg, 64, F, wl["seed"] + c0, dev)
+            utts += [dict(ppg=ppg[j], sine=sine[j], lft=lft[j], spk_emb=emb[j]) for j in range(64)]
+        utts[300] = utts[7]                               # the same utterance twice, in different batches
+        ws = torch.empty(plan.workspace_bytes(64, F), dtype=torch.uint8, device=dev)
+        calls = []
+
+        def fwd(ppg, sine, lft, emb, out=None):
+            calls.append((int(ppg.shape[0]), out is not None))
+            return plan.forward(blob, ppg, sine, lft, emb, workspace=ws, out=out)
+
+        ys = D.run_utterance_parallel(fwd, utts, dev, max_batch=64, n_frames=[F] * n_utts, hop=cfg.hop, forward_into=True)
+        torch.cuda.synchronize()
+        assert calls == [(64, True)] * 8                  # eight batches of 64, each written into its send buffer
+        assert len(ys) == n_utts and all(tuple(y.shape) == (1, T) for y in ys)
+        stack = torch.stack(ys)
+        assert bool(torch.isfinite(stack).all())
+        rms = stack.pow(2).mean(dim=(1, 2)).sqrt()
+        assert float(rms.min()) > 0.05 and float(rms.max()) < 10.0
+        assert float((ys[300] - ys[7]).abs().max()) <= 1e-5
+        wf = S.fold_weight_norm(sd)
+        for i in (0, n_utts - 1):
+            ins = [utts[i][k][None] for k in ("ppg", "sine", "lft", "spk_emb")]
+            ref = _oracle_alone(wf, cfg, ins, 0)
+            assert float((ys[i][None].cpu() - ref).abs().max()) <= TIGHT * max(1.0, float(ref.abs().max()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_staged_host_batches_survive_many_rounds(dev):
+    """host-resident utterances go through pinned staging sets and a copy stream; the device batch is
+    allocated on the copy stream but consumed on the compute stream.  Many rounds of EQUAL shapes (so the caching
+    allocator hands the same blocks out again) with a forward that is slow on the GPU and a host that runs ahead:
+    every gathered waveform must still be the function of ITS utterance."""
+    import torch.distributed as dist
+    from svcc23_fastsvc_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        C, F, hop, n = 8, 64, 160, 48
+        g = torch.Generator().manual_seed(5)
+        utts = [dict(ppg=torch.randn((C, F), generator=g), sine=torch.randn((1, F * hop), generator=g),
+                     lft=torch.randn((1, F * hop), generator=g), spk_emb=torch.randn((4,), generator=g)) for _ in range(n)]
+        spin = torch.zeros(1 << 22, device=dev)
+
+        def slow_forward(ppg, sine, lft, emb):
+            for _ in range(20):                           # keeps the GPU busy while the host stages ahead
+                spin.add_(1.0)
+            return sine * 2.0 + lft + ppg.sum(dim=(1, 2), keepdim=True) + emb.sum(dim=1)[:, None, None]
+
+        ys = D.run_utterance_parallel(slow_forward, utts, dev, max_batch=2)
+        torch.cuda.synchronize()
+        for i, u in enumerate(utts):
+            want = u["sine"] * 2.0 + u["lft"] + u["ppg"].sum() + u["spk_emb"].sum()
+            assert float((ys[i].cpu() - want).abs().max()) <= 1e-4, i
+    finally:
+        dist.destroy_process_group()
+
+
 def test_compact_workspace_same_waveform_less_memory(dev):
     """The compact layout (intermediates of different stages share buffers; what the nn.Module mirror and bench.py
     use) gives the same waveform as the one-buffer-per-tensor layout, at 64 x 10 s in about 60 % of the memory;
