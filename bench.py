@@ -55,7 +55,9 @@ def parse():
     # slower than 200 after 50); the large workloads scale them down below
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg5: one full training step (generator fwd/bwd, MelGAN MSD, MR-STFT + adversarial losses, RAdam; "
+                         "recipe batch 32 x 16000 samples per GPU, data-parallel gradient all-reduce)")
     ap.add_argument("--storage", default="float32", choices=["float32", "bfloat16"],
                     help="workspace tensor storage: float32 = the parity path (default, what `value` is quoted "
                          "on); bfloat16 = BASELINE config 3's dtype (bf16-activation accuracy)")
@@ -339,9 +341,57 @@ def run_off_table_shape(cfg, dev, B=5, F=731, steps=50, warmup=10):
     return out
 
 
+def run_cfg5(args, dist, world, rank, dev):
+    """BASELINE config 5: the recipe's training step (train_fastsvc.py:157-240) per GPU on a batch of 32 crops of
+    16000 samples (fastsvc.yaml:71-72), both sub-networks training, gradients averaged over the ranks (RCCL).
+    Generator forward = HIP kernels (twice per step: the trainer's second, no-grad forward feeds the
+    discriminator); generator backward, discriminator and losses = PyTorch-ROCm (svcc23_fastsvc_amd/training.py)."""
+    from svcc23_fastsvc_amd import training as TRN
+    cfg = S.FULL_CONFIG
+    B, F = TRN.RECIPE["batch_size"], TRN.RECIPE["batch_length"] // cfg.hop
+    T = F * cfg.hop
+    torch.manual_seed(1234)                                  # same initial weights on every rank
+    gen = A.FastSVCGenerator(in_channels=cfg.in_channels, mid_channels=list(cfg.mid_channels),
+                             upsampling_scales=list(cfg.upsampling_scales), out_channels=1,
+                             spk_emb_size=cfg.spk_emb_size, use_spk_emb=True)
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in S.synth_state_dict(cfg, WEIGHT_SEED).items()})
+    gen.activation_storage = args.storage
+    gen = gen.to(dev).train()
+    disc = TRN.MelGANMultiScaleDiscriminator(**TRN.RECIPE["discriminator_params"]).to(dev).train()
+    trainer = TRN.TrainStep(gen, disc, dict(discriminator_train_start_steps=0), steps=1)
+    ppg, sine, lft, emb = S.device_batch(cfg, B, F, 5000 + rank, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77 + rank)
+    target = torch.randn((B, 1, T), generator=g, device=dev) * 0.3
+    batch = ((ppg, sine, lft, emb), target)
+    step = lambda i: trainer.step(batch, log=False)
+    elapsed = time_steps(step, torch.cuda.synchronize, args.steps, args.warmup, dist if world > 1 else None, dev)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    n_g = sum(p.numel() for p in gen.parameters())
+    n_d = sum(p.numel() for p in disc.parameters())
+    return {
+        "metric": "audio samples/sec (24 kHz) FastSVC training step", "value": world * B * T * args.steps / elapsed,
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": f"generator forward: {gen.plan.arithmetic}; backward / discriminator / losses: f32 PyTorch-ROCm",
+        "data": "synthetic",
+        "config": {"workload": f"cfg5: full train step (generator fwd + bwd, MelGAN multi-scale discriminator, MR-STFT x6 + adversarial "
+                               f"losses, RAdam), batch {B} x {T} samples per GPU, data-parallel x{world} with a flat-bucket gradient all-reduce",
+                   "global_batch": world * B, "utterance_samples": T, "parallelism": f"data-parallel x{world}",
+                   "generator_params": n_g, "discriminator_params": n_d,
+                   "hip_path": "generator forward only (two per step); hand-written backward kernels are not built"},
+        "roofline": None, "cpu_baseline": None,
+    }
+
+
 def main():
     args = parse()
     big = args.workload in ("cfg3", "cfg4")
+    if args.workload == "cfg5":
+        args.steps = args.steps or 10
+        args.warmup = args.warmup if args.warmup is not None else 3
     if args.steps is None:
         args.steps = 10 if args.workload == "cfg4" else 40 if big else 200
     if args.warmup is None:
@@ -367,6 +417,16 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+
+    if args.workload == "cfg5":
+        line = run_cfg5(args, dist, world, rank, dev)
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     cfg = S.FULL_CONFIG
     wl = S.WORKLOADS[args.workload]

@@ -19,6 +19,9 @@ Fixtures written:
   weight_norm_fold.npz  torch ``remove_weight_norm`` result for three layers (g, v -> w)
   tiny_grads.npz        autograd of the reference generator in train() mode (tiny width): d sum(r*y) / d every
                         parameter (weight_g / weight_v / bias) and input, with / without speaker embedding
+  train_step.npz        MR-STFT / adversarial loss values, a small MelGAN multi-scale discriminator's outputs, eight
+                        RAdam steps, and two full Trainer._train_step calls (train_fastsvc.py:157-240): every
+                        generator / discriminator parameter after each step
   decode_chain.npz      decode_fastsvc.py:160-189 per utterance for three utterances of different
                         length: F0Statistics.estimate / .convert (features.py:41-108, std forced to 1),
                         then ``inference()`` with the converted F0 (noise_amp=0)
@@ -37,6 +40,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle.refimport import import_reference, import_reference_signal_generator  # noqa: E402
+from oracle.refimport import REFERENCE_ROOT as ROOT_REF  # noqa: E402
 from svcc23_fastsvc_amd import synth as S  # noqa: E402
 
 warnings.filterwarnings("ignore")
@@ -203,6 +207,105 @@ def grads(M):
     print("tiny_grads.npz:", len(out), "arrays")
 
 
+def train(M):
+    """train_step.npz: the reference's losses, discriminator, RAdam and two full `_train_step`s (train_fastsvc.py:157-240)
+    on the tiny-width generator and a small MelGAN multi-scale discriminator, both sub-networks training from the
+    first step (discriminator_train_start_steps = 0, steps start at 1)."""
+    import types
+    from harana.losses import MultiResolutionSTFTLoss, GeneratorAdversarialLoss, DiscriminatorAdversarialLoss
+    from harana.optimizers import RAdam
+    import yaml
+    with open(os.path.join(ROOT_REF, "egs/svcc23/fastsvc1/conf/fastsvc.yaml")) as f:
+        recipe = yaml.safe_load(f)
+    out = {}
+    cfg = S.TINY_CONFIG
+    B, F = 2, 25
+    T = F * cfg.hop
+    # (1) losses on fixed signals
+    gsig = torch.Generator().manual_seed(11)
+    y = torch.randn((B, 1, T), generator=gsig) * 0.3
+    y_hat = y + torch.randn((B, 1, T), generator=gsig) * 0.1
+    stft = MultiResolutionSTFTLoss(**recipe["stft_loss_params"])
+    sc, mag = stft(y_hat, y)
+    out.update({"loss/y": y.numpy(), "loss/y_hat": y_hat.numpy(), "loss/sc": np.float64(sc), "loss/mag": np.float64(mag)})
+    # (2) small discriminator: state dict, final outputs, adversarial losses
+    dparams = dict(recipe["discriminator_params"])
+    dparams.update(scales=2, channels=4, max_downsample_channels=32, downsample_scales=[4, 4])
+    torch.manual_seed(12)
+    D = M.MelGANMultiScaleDiscriminator(**dparams)
+    for k, v in D.state_dict().items():
+        out["dsd/" + k] = v.numpy().copy()
+    outs, outs_hat = D(y), D(y_hat)
+    for i, (o, oh) in enumerate(zip(outs, outs_hat)):
+        out[f"d/real.{i}"] = o[-1].detach().numpy()
+        out[f"d/fake.{i}"] = oh[-1].detach().numpy()
+        out[f"d/nlayers.{i}"] = np.int64(len(o))
+    out["loss/gen_adv"] = np.float64(GeneratorAdversarialLoss()(outs_hat))
+    real, fake = DiscriminatorAdversarialLoss()(outs_hat, outs)
+    out["loss/dis_real"], out["loss/dis_fake"] = np.float64(real), np.float64(fake)
+    # (3) RAdam: 8 steps on two tensors with given gradients (rectification switches on at step 6)
+    gr = torch.Generator().manual_seed(13)
+    ps = [torch.nn.Parameter(torch.randn((5, 3), generator=gr)), torch.nn.Parameter(torch.randn((7,), generator=gr))]
+    opt = RAdam(ps, lr=1e-2, eps=1e-6, weight_decay=1e-3)
+    out["radam/p0.0"], out["radam/p1.0"] = ps[0].detach().numpy().copy(), ps[1].detach().numpy().copy()
+    for t in range(1, 9):
+        for i, p_ in enumerate(ps):
+            p_.grad = torch.randn(p_.shape, generator=gr)
+            out[f"radam/g{i}.{t}"] = p_.grad.numpy().copy()
+        opt.step()
+        for i, p_ in enumerate(ps):
+            out[f"radam/p{i}.{t}"] = p_.detach().numpy().copy()
+    # (4) two full train steps through the reference Trainer's _train_step
+    # (the trainer module imports two off-path packages that are not installed here: placeholders, test tooling only)
+    from oracle.refimport import _placeholder
+    for name in ("tensorboardX", "soundfile"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                _placeholder(name)
+    if not hasattr(sys.modules["tensorboardX"], "SummaryWriter"):
+        sys.modules["tensorboardX"].SummaryWriter = lambda *a, **k: None
+    from harana.bin import train_fastsvc as TR
+    g, sd = build_reference(M, cfg, 21)
+    g.train()
+    torch.manual_seed(14)
+    D2 = M.MelGANMultiScaleDiscriminator(**dparams)
+    for k, v in D2.state_dict().items():
+        out["step/dsd0/" + k] = v.numpy().copy()
+    conf = dict(recipe)
+    conf.update(discriminator_train_start_steps=0, use_stft_loss=True, lambda_aux=1.0, outdir="/tmp",
+                train_max_steps=10 ** 9, log_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, save_interval_steps=10 ** 9)
+    crit = {"gen_adv": GeneratorAdversarialLoss(), "dis_adv": DiscriminatorAdversarialLoss(),
+            "stft": MultiResolutionSTFTLoss(**recipe["stft_loss_params"])}
+    opt = {"generator": RAdam(g.parameters(), **recipe["generator_optimizer_params"]),
+           "discriminator": RAdam(D2.parameters(), **recipe["discriminator_optimizer_params"])}
+    sch = {k: torch.optim.lr_scheduler.StepLR(opt[k], **recipe[k + "_scheduler_params"]) for k in opt}
+    tr = TR.Trainer(steps=1, epochs=0, data_loader={}, sampler={"train": None}, model={"generator": g, "discriminator": D2},
+                    criterion=crit, optimizer=opt, scheduler=sch, config=conf, device=torch.device("cpu"))
+    tr.tqdm = types.SimpleNamespace(update=lambda n: None)
+    tr._check_train_finish = lambda: None
+    b = S.synth_batch(cfg, B, F, 22)
+    gy = torch.Generator().manual_seed(15)
+    target = torch.randn((B, 1, T), generator=gy) * 0.3
+    out["step/target"] = target.numpy()
+    x = tuple(torch.from_numpy(a) for a in (b.ppg, b.sine, b.lft, b.spk_emb))
+    for it in (1, 2):
+        tr.total_train_loss.clear()
+        tr._train_step((x, target))
+        for k, v in tr.total_train_loss.items():
+            out[f"step/loss{it}/{k.split('/')[-1]}"] = np.float64(v)
+        for k, v in g.state_dict().items():
+            out[f"step/g{it}/{k}"] = v.numpy().copy()
+        for k, v in D2.state_dict().items():
+            out[f"step/d{it}/{k}"] = v.numpy().copy()
+    out["meta"] = np.array([21, 22, B, F], dtype=np.int64)
+    out["dparams"] = np.array([dparams["scales"], dparams["channels"], dparams["max_downsample_channels"],
+                               len(dparams["downsample_scales"])], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **out)
+    print("train_step.npz:", len(out), "arrays")
+
+
 def fold(M):
     cfg = S.TINY_CONFIG
     g, sd = build_reference(M, cfg, 101)
@@ -219,9 +322,10 @@ def fold(M):
 
 if __name__ == "__main__":
     M = import_reference()
-    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain", "grads"]
+    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain", "grads", "train"]
     for name in todo:
-        {"tiny": tiny, "full": full, "inference": inference, "fold": fold, "decode_chain": decode_chain, "grads": grads}[name](M)
+        {"tiny": tiny, "full": full, "inference": inference, "fold": fold, "decode_chain": decode_chain, "grads": grads,
+         "train": train}[name](M)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
