@@ -299,10 +299,11 @@ typedef hx_t hx4 __attribute__((ext_vector_type(4)));
 // smid (LDS): [bias of the first conv | its inverse operand scales], per channel, both already multiplied by the
 // intermediate tile's own scale (LeakyReLU commutes with a positive factor): v = acc * kinv + kb.  Read here, once
 // per tile, instead of living in 8 MW registers across the tile loop.
-template <int MW, int NA>
+// RAW_TOO (MODE_UPHEAD): the tile is also stored WITHOUT the LeakyReLU, `raw_bytes` further.
+template <int MW, int NA, bool RAW_TOO = false>
 __device__ __forceinline__ void hx_chain_store(const f32x4 (&acc)[NA][MW], int ntl, unsigned char* T2, int chunk_bytes,
                                                int lo_off, int mg, int row0, int col0, int T, const float* smid,
-                                               int cmidp, int lane) {
+                                               int cmidp, int lane, int raw_bytes = 0) {
     const int l15 = lane & 15, g = lane >> 4;
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
@@ -318,10 +319,15 @@ __device__ __forceinline__ void hx_chain_store(const f32x4 (&acc)[NA][MW], int n
             f32x4 v;
             if constexpr (HX_NP == 2) v = acc[n][m] * kinv + kb; else v = acc[n][m] + kb;
             #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = fmaxf(v[e], v[e] * LRELU_SLOPE);
-                v[e] = inside ? v[e] : 0.f;                  // (|v| < 2^15 by construction: s_mid comes from a bound of this tensor)
+            for (int e = 0; e < 4; ++e) v[e] = inside ? v[e] : 0.f;      // (|v| < 2^15 by construction: s_mid comes from a bound of this tensor)
+            if constexpr (RAW_TOO) {
+                const hx4 hr = __builtin_convertvector(v, hx4);
+                *reinterpret_cast<hx4*>(base + raw_bytes + n * 16 * HX_ROW) = hr;
+                if constexpr (HX_NP == 2)
+                    *reinterpret_cast<hx4*>(base + raw_bytes + lo_off + n * 16 * HX_ROW) = __builtin_convertvector(v - __builtin_convertvector(hr, f32x4), hx4);
             }
+            #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * LRELU_SLOPE);
             const hx4 h = __builtin_convertvector(v, hx4);
             *reinterpret_cast<hx4*>(base + n * 16 * HX_ROW) = h;
             if constexpr (HX_NP == 2) {
@@ -633,9 +639,10 @@ __device__ __forceinline__ void hx_last_reduce(const ConvParams& p, const f32x4 
 template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S, bool WSTATIC>
 __global__ __launch_bounds__(512, (hx_min_waves<MW, NW, MODE, EPI>()))
 void conv_hx_kernel(const ConvParams p0) {
-    constexpr bool POLY = MODE == MODE_POLY, DEC2 = MODE == MODE_DEC2, CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1;
+    constexpr bool UPH = MODE == MODE_UPHEAD;                          // conv_first -> {stretched residual conv, stretched up conv + FiLM affine}
+    constexpr bool POLY = MODE == MODE_POLY, DEC2 = MODE == MODE_DEC2, CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1 || UPH;
     constexpr bool IN1 = MODE == MODE_CHAIN1;                          // the staging waves compute the stage's first conv
-    constexpr bool WLB = CHAIN && S == 2;                              // the second conv's weights live in LDS (one channel group)
+    constexpr bool WLB = MODE == MODE_CHAIN && S == 2;                 // the second conv's weights live in LDS (one channel group)
     constexpr int NT = 16 * NW * WN;                                   // (input-rate) columns per workgroup tile
     // MODE_CHAIN: the first conv also produces the second one's halo (<= 4 columns per side): its tile starts 4
     // columns early and is one 16-column MFMA tile longer (computed by the last wave along time)
@@ -648,7 +655,7 @@ void conv_hx_kernel(const ConvParams p0) {
     constexpr int NVAR = DEC2 ? 2 : 1;                                 // tile variants: LeakyReLU'd (+ raw)
     constexpr int NSLOT = NWS * MW * HX_NP;
     // this instance's epilogue measures what it writes (ConvParams::amax_out): residual kinds and the fused pair
-    constexpr bool TRACKS = AMAX_TRACK && (CHAIN || (MODE == MODE_DIRECT && (EPI == EPI_RES || EPI == EPI_RANK1)));
+    constexpr bool TRACKS = AMAX_TRACK && ((CHAIN && MODE != MODE_UPHEAD) || (MODE == MODE_DIRECT && (EPI == EPI_RES || EPI == EPI_RANK1)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tid = threadIdx.x;
@@ -739,7 +746,7 @@ void conv_hx_kernel(const ConvParams p0) {
                 if (flags & F_PRE_NORM) bound += sqrtf((float)p.x_T);
                 if constexpr (CHAIN) {
                     if (invtab) {
-                        const float* cst = invtab + 2 * ninv;      // l1 / largest |bias| of the first conv (and of the 1 -> C conv)
+                        const float* cst = invtab + (UPH ? 3 : 2) * ninv;      // l1 / largest |bias| of the first conv (and of the 1 -> C conv)
                         if constexpr (IN1) bound = bound * cst[2] + cst[3];
                         s_mid_scale = hx_scale_for(bound * cst[0] + cst[1]);
                     }
@@ -756,7 +763,8 @@ void conv_hx_kernel(const ConvParams p0) {
     constexpr int T2ROWS = NT + 16;
     constexpr int T2CHUNK = HX_NP * T2ROWS * HX_ROW;
     unsigned char* T2 = tiles + 2 * bufsz;
-    const int t2bytes = CHAIN ? p.nch32b * T2CHUNK : 0;
+    const int t2one = CHAIN ? p.nch32b * T2CHUNK : 0;                   // one copy of the intermediate tile
+    const int t2bytes = UPH ? 2 * t2one : t2one;                       // MODE_UPHEAD: LeakyReLU'd copy, then the raw one
     unsigned char* Wl = T2 + t2bytes;                                  // WLB: [K chunk][tap][m][piece] fragments of the second conv
     const int wlbytes = WLB ? p.nch32b * NSLOT * HX_FRAG : 0;
 
@@ -1004,12 +1012,12 @@ void conv_hx_kernel(const ConvParams p0) {
         }
     } else {
         // ================================ CONSUMER WAVES ================================
-        f32x4 acc[(POLY || DEC2) ? 1 : NW][MW];
-        f32x4 acc3[3][POLY ? NW : 1][MW];             // polyphase: a / z / c accumulator sets
+        f32x4 acc[(POLY || DEC2 || UPH) ? 1 : NW][MW];
+        f32x4 acc3[3][(POLY || UPH) ? NW : 1][MW];    // polyphase: a / z / c accumulator sets
         f32x4 acc2[2][DEC2 ? NW : 1][MW];             // decimating pair: k=3 / 1x1
         float s1[MW], s2[MW];
         HxWeightStream<NSLOT> wst;
-        const int wunits = CHAIN ? nch + p.nch32b : nch;    // weight units per tile (CHAIN: first conv's, then the second's)
+        const int wunits = UPH ? nch + 2 * p.nch32b : CHAIN ? nch + p.nch32b : nch;    // weight units per tile (CHAIN: first conv's, then the second's)
         wst.init(reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
                      (long)(active ? mg : 0) * wunits * NSLOT * HX_FRAG, WLB ? nch : wunits, lane);
         int aoff[3];
@@ -1021,7 +1029,7 @@ void conv_hx_kernel(const ConvParams p0) {
             const long ct = (long)p.COUT * p.ldy;
             const float* nul = p.bias;
             R.y = act_rsrc(p.y ? p.y : nul, p.y ? (long)sig * p.y_sig + (long)b * p.y_b : 0, p.y ? ct : 0);
-            const bool has_y2 = DEC2 || (flags & F_AFF_OUT) != 0;
+            const bool has_y2 = DEC2 || (flags & F_AFF_OUT) != 0;                     // (MODE_UPHEAD: y = xr, y2 = u1)
             R.y2 = act_rsrc(has_y2 ? p.y2 : nul, has_y2 ? (long)sig * p.y2_sig + (long)b * p.y2_b : 0, has_y2 ? ct : 0);
             R.res = act_rsrc(p.res ? p.res : nul, p.res ? (long)sig * p.res_sig + (long)b * p.res_b : 0, p.res ? ct : 0);
             const bool has_ss = (flags & (F_STATS | F_AFF_OUT)) != 0;
@@ -1036,7 +1044,7 @@ void conv_hx_kernel(const ConvParams p0) {
             const bool cok = active && cot < p.COUT;
             k_bias[m] = cok ? p.bias[(long)sig * p.bias_sig + co] : 0.f;
             k_bias2[m] = 0.f; k_r1w[m] = 0.f; k_r1b[m] = 0.f;
-            if constexpr (DEC2) k_bias2[m] = cok ? p.bias2[(long)sig * p.bias2_sig + co] : 0.f;
+            if constexpr (DEC2 || UPH) k_bias2[m] = cok ? p.bias2[(long)sig * p.bias2_sig + co] : 0.f;
             if constexpr (EPI == EPI_RANK1) {
                 k_r1w[m] = cok ? p.r1w[(long)sig * p.r1_sig + co] : 0.f;
                 k_r1b[m] = cok ? p.r1b[(long)sig * p.r1_sig + co] : 0.f;
@@ -1055,6 +1063,7 @@ void conv_hx_kernel(const ConvParams p0) {
                 if (invtab) {
                     t_inv[m] = cok ? invtab[(CHAIN ? ninv : 0) + cot] : 0.f;
                     if constexpr (DEC2) t_inv2[m] = cok ? invtab[ninv + cot] : 0.f;
+                    if constexpr (UPH) t_inv2[m] = cok ? invtab[2 * ninv + cot] : 0.f;
                 }
             }
         }
@@ -1084,7 +1093,7 @@ void conv_hx_kernel(const ConvParams p0) {
                 for (int m = 0; m < MW; ++m) {
                     const int li = (wave_m * MW + m) * 16 + lane;
                     s_inv[li] = t_inv[m] * isx;
-                    if constexpr (DEC2) s_inv[16 * MW * WM + li] = t_inv2[m] * isx;
+                    if constexpr (DEC2 || UPH) s_inv[16 * MW * WM + li] = t_inv2[m] * isx;
                 }
             }
         }
@@ -1143,8 +1152,57 @@ void conv_hx_kernel(const ConvParams p0) {
                 } while (++ch < nch);
                 // every wave is past the previous tile's second conv (the barriers above): its tile may be overwritten
                 if (active)
-                    hx_chain_store<MW, NW + 1>(accA, extra ? NW + 1 : NW, T2, T2CHUNK, lo_offB, mg, wave_n * (NW * 16),
-                                               (tile0 + tl) * NT - HB + wave_n * (NW * 16), p.T, s_mid, cmidp, lane);
+                    hx_chain_store<MW, NW + 1, UPH>(accA, extra ? NW + 1 : NW, T2, T2CHUNK, lo_offB, mg, wave_n * (NW * 16),
+                                                    (tile0 + tl) * NT - HB + wave_n * (NW * 16), p.T, s_mid, cmidp, lane, t2one);
+                if constexpr (UPH) {
+                    __syncthreads();                   // intermediate tiles complete
+                    stamp(5);
+                    // residual branch: xr = poly(a) + bias  (plain epilogue, no LeakyReLU, no FiLM)
+                    ConvParams pr = p;
+                    pr.flags = 0;
+                    EpiRsrc Rr = R;
+                    Rr.y2 = R.res;                     // (absent: zero-length descriptor)
+                    #pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        #pragma unroll
+                        for (int n = 0; n < NW; ++n)
+                            #pragma unroll
+                            for (int m = 0; m < MW; ++m) acc3[k][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    int cb = 0;
+                    do { hx_unit_poly<MW, NW, true>(acc3, T2 + t2one + cb * T2CHUNK, aoffB, lo_offB, wst); } while (++cb < p.nch32b);
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
+                    ws_epilogue_poly<MW, NW, EPI_PLAIN, S, 0>(pr, Rr, acc3, s1, s2, mg, tcol0, active, lane, K);
+                    // up branch: u1 = scale * lrelu(poly(lrelu(a)) + bias2) + shift, InstanceNorm partial sums
+                    EpiRsrc Ru = R;
+                    Ru.y = R.res;                      // (the pre-affine tensor is not written)
+                    const EpiConst<MW, true, HX_NP == 2> K2{k_bias2, k_bias2, k_r1w, k_r1b,
+                                                            s_inv + 16 * MW * WM + wave_m * (MW * 16) + (lane & 15), 0};
+                    #pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        #pragma unroll
+                        for (int n = 0; n < NW; ++n)
+                            #pragma unroll
+                            for (int m = 0; m < MW; ++m) acc3[k][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    cb = 0;
+                    do { hx_unit_poly<MW, NW, true>(acc3, T2 + cb * T2CHUNK, aoffB, lo_offB, wst); } while (++cb < p.nch32b);
+                    stamp(7);
+                    ws_epilogue_poly<MW, NW, EPI_AFF, S, 0>(p, Ru, acc3, s1, s2, mg, tcol0, active, lane, K2);
+                    if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
+                        #pragma unroll
+                        for (int m = 0; m < MW; ++m) {
+                            float a1 = s1[m], a2 = s2[m];
+                            a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+                            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                            if (active && lane < 16) {
+                                const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
+                                atomicAdd(&sstat[slot + 0], (double)a1);
+                                atomicAdd(&sstat[slot + 1], (double)a2);
+                            }
+                        }
+                    }
+                    stamp(8);
+                } else {
                 // the stage's residual tensor (the 1x1 conv's output) is fetched HERE, into registers the first
                 // conv's tile has just left: it lands under the second conv instead of costing the epilogue a
                 // memory round trip per item
@@ -1183,6 +1241,7 @@ void conv_hx_kernel(const ConvParams p0) {
                 ws_epilogue_kind<MW, NW, EPI_PLAIN, false, 0, 1>(p, R, acc, s1, s2, sig, mg, tcol0, active, lane, K, Ew);
                 if constexpr (TRACKS) { if (p.amax_out) amax_tile_flush(R); }
                 stamp(8);
+                }
             }
         } else
         for (int tl = 0; tl < ntiles; ++tl) {
@@ -1272,7 +1331,7 @@ void conv_hx_kernel(const ConvParams p0) {
     }
 }
 
-constexpr size_t HX_STATIC_LDS = 2048;                  // upper bound of conv_hx_kernel's static LDS (s_inv, s_mid)
+constexpr size_t HX_STATIC_LDS = 4096;                  // upper bound of conv_hx_kernel's static LDS (s_inv, s_mid)
 template <auto KERNEL>
 static hipError_t hx_launch_instance(dim3 grid, size_t smem, hipStream_t stream, const ConvParams& p) {
     if (smem + HX_STATIC_LDS > 64 * 1024) {
@@ -1287,7 +1346,7 @@ static hipError_t hx_launch_instance(dim3 grid, size_t smem, hipStream_t stream,
 template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S>
 static hipError_t hx_launch_kind(dim3 grid, size_t smem, hipStream_t stream, const ConvParams& p) {
     // the ring holds the whole layer when there is a single K chunk: nothing to re-request (MW = 2 layers: C_in <= 32)
-    if constexpr (MW == 2) {
+    if constexpr (MW == 2 && MODE != MODE_UPHEAD) {
         if (p.nch32 == 1 && ((MODE != MODE_CHAIN && MODE != MODE_CHAIN1) || p.nch32b == 1)) return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, true>>(grid, smem, stream, p);
     }
     return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, false>>(grid, smem, stream, p);
@@ -1299,14 +1358,22 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
     const int ntx = (p.T + NT - 1) / NT;
     const int tpw = p.tpw > 0 ? p.tpw : 1;
     dim3 grid((ntx + tpw - 1) / tpw, (p.ngroups + WM - 1) / WM, nsig * p.B);
-    constexpr bool CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1;
+    constexpr bool CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1 || MODE == MODE_UPHEAD;
     const int halo_al = (MODE == MODE_DIRECT || CHAIN) ? ((p.dil + 3) & ~3) : 4;
     const int W = NT + (CHAIN ? 16 : 0) + 2 * halo_al;
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM + sizeof(float) * 2 * (size_t)p.nch32 * HX_KC +
                         (size_t)2 * (MODE == MODE_DEC2 ? 2 : 1) * HX_NP * (W + 4) * HX_ROW +
-                        (CHAIN ? (size_t)p.nch32b * HX_NP * (NT + 16) * HX_ROW : 0);
+                        (CHAIN ? (size_t)(MODE == MODE_UPHEAD ? 2 : 1) * p.nch32b * HX_NP * (NT + 16) * HX_ROW : 0);
     const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
-    if constexpr (MODE == MODE_CHAIN1) {
+    if constexpr (MODE == MODE_UPHEAD) {
+#ifndef FASTSVC_ACT_BF16
+        if (!(p.flags & F_AFF_OUT) || !p.y || !p.y2 || !p.bias2 || smem + HX_STATIC_LDS > 160 * 1024) return hipErrorInvalidValue;
+#define FASTSVC_HXU(sv) if (p.s == sv) return hx_launch_kind<MW, NW, WM, WN, MODE_UPHEAD, EPI_AFF, sv>(grid, smem, stream, p);
+        FASTSVC_HXU(2) FASTSVC_HXU(4) FASTSVC_HXU(5)
+#undef FASTSVC_HXU
+#endif
+        return hipErrorInvalidValue;
+    } else if constexpr (MODE == MODE_CHAIN1) {
         if (aff || !p.r1x || smem + HX_STATIC_LDS > 160 * 1024) return hipErrorInvalidValue;
         return hx_launch_kind<MW, NW, WM, WN, MODE_CHAIN1, EPI_RANK1, 1>(grid, smem, stream, p);
     } else if constexpr (MODE == MODE_CHAIN) {
@@ -1372,6 +1439,11 @@ hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_
         FASTSVC_HXS(MODE_CHAIN, 2, 2, 1, 4) FASTSVC_HXS(MODE_CHAIN, 2, 3, 1, 4)
         FASTSVC_HXS(MODE_CHAIN, 3, 2, 1, 4) FASTSVC_HXS(MODE_CHAIN, 3, 3, 1, 4)
         FASTSVC_HXS(MODE_CHAIN, 3, 4, 2, 2) FASTSVC_HXS(MODE_CHAIN, 3, 6, 2, 2)
+    } else if (p.mode == MODE_UPHEAD) {
+        // (every workgroup holds the whole C-channel intermediate tile, twice: one workgroup row of channel groups)
+        if (p.dil != 1 || p.dil2 != 1 || !p.bias_mid || p.CMID != p.COUT || p.ngroups > cfg.WM) return hipErrorInvalidValue;
+        FASTSVC_HXS(MODE_UPHEAD, 3, 4, 4, 1) FASTSVC_HXS(MODE_UPHEAD, 3, 2, 2, 2)
+        FASTSVC_HXS(MODE_UPHEAD, 3, 2, 1, 4) FASTSVC_HXS(MODE_UPHEAD, 2, 2, 1, 4)
     } else if (p.mode == MODE_CHAIN1) {
         // (tiles of <= 192 columns: one staging item per thread, which the first conv's per-thread taps rely on)
         if (p.dil < 1 || p.dil > 4 || p.dil2 < 1 || p.dil2 > 4 || !p.bias_mid || p.CMID != p.COUT || p.CIN > 32 ||
@@ -1393,6 +1465,9 @@ bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN) {
     if (mode == MODE_DEC2)
         return MW == 3 && ((WM == 1 && WN == 4 && (NW == 2 || NW == 3)) || (WM == 2 && WN == 2 && NW == 2));
     if (mode == MODE_CHAIN1) return MW == 2 && WM == 1 && WN == 4 && (NW == 2 || NW == 3);
+    if (mode == MODE_UPHEAD)
+        return (MW == 3 && ((NW == 4 && WM == 4 && WN == 1) || (NW == 2 && WM == 2 && WN == 2) || (NW == 2 && WM == 1 && WN == 4))) ||
+               (MW == 2 && NW == 2 && WM == 1 && WN == 4);
     if (mode == MODE_CHAIN)
         return (WM == 1 && WN == 4 && (MW == 2 || MW == 3) && (NW == 2 || NW == 3)) ||
                (MW == 3 && WM == 2 && WN == 2 && (NW == 4 || NW == 6));

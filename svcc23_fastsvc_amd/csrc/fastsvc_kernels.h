@@ -41,7 +41,16 @@ enum : int {
     // MODE_CHAIN behind the FIRST conv of down stage 0 (k=3, 1 input channel, fastsvc.py:172-173): x is the raw
     // 1-channel signal (always float32) and the staging waves compute lrelu(conv3(lrelu(x)) + b1) on the fly
     // instead of loading a C-channel tensor - the whole stage is one launch that only writes its output.
-    MODE_CHAIN1 = 7
+    MODE_CHAIN1 = 7,
+    // The head of an up block in ONE launch (half-precision MFMA kernels, float32 storage; fastsvc.py:92-97):
+    //     a  = conv_first(x)                       k=3, d=1, C_in -> C at the block's INPUT rate - never leaves LDS
+    //     y  = Conv3(Stretch_s(a))        + bias   the stretched residual conv (polyphase, MODE_POLY)      -> xr
+    //     y2 = scale * lrelu(Conv3(Stretch_s(lrelu(a))) + bias2) + shift   (+ InstanceNorm partial sums)    -> u1
+    // Two copies of the intermediate tile (raw, LeakyReLU'd) serve the two polyphase convs; three launches and the
+    // write + two reads of `a` less.  whx: [conv_first units | residual conv's polyphase units | up conv's];
+    // whx_inv: [first | residual | up | l1_first, bmax_first, 0, 0]; bias = residual conv's, bias2 = up conv's,
+    // bias_mid = conv_first's; T = x_T = input columns, ldy = output pitch, s = stretch factor.
+    MODE_UPHEAD = 8
 };
 
 enum : int {

@@ -122,6 +122,7 @@ struct DownStage {
 struct UpStage {
     int C = 0, Cin = 0, scale = 1;
     PackedConv first, res, up, d3, d9, d27;
+    PackedConv head;             // conv_first -> {res, up} as ONE launch (MODE_UPHEAD): hxc_off[0] / hxc_inv_off only
     RawParam emb;
 };
 
@@ -196,6 +197,8 @@ struct fastsvc_plan {
     std::vector<ChainJob> chain_jobs;
     struct FilmChainJob { PackedConv* c; std::string conv[2]; PackSource heads; int C; };
     std::vector<FilmChainJob> film_chain_jobs;
+    struct UpHeadJob { PackedConv* c; std::string first, res, up; int cin, C; };
+    std::vector<UpHeadJob> up_head_jobs;
     std::vector<RawParam*> raw_jobs;
     double flops_per_sample = 0.0;
     int storage = 0;                    // activation storage in the workspace: 0 float32, 1 bfloat16
@@ -324,6 +327,24 @@ struct fastsvc_plan {
         film_chain_jobs.push_back(FilmChainJob{&c, {conv[0], conv[1]}, hsrc, C});
     }
 
+    // the head of an up block as one launch (fastsvc_kernels.h, MODE_UPHEAD): per channel group
+    // [conv_first's units | residual conv's polyphase units | up conv's], float32 storage (split-binary16) only
+    void add_up_head(UpStage& u, const std::string& prefix) {
+        PackedConv& c = u.head;
+        if (!u.first.hx || !u.res.hx || !u.up.hx || !u.res.poly || !u.up.poly || u.first.MW != u.res.MW) return;
+        c = u.res;                                     // geometry of the C -> C convs (MW, ngroups, biases of the residual conv)
+        c.hx_off[0] = c.hx_off[1] = 0; c.hxp_off[0] = c.hxp_off[1] = 0; c.hx_inv_off = c.hxp_inv_off = 0;
+        if (c.ngroups > 4) return;
+        c.nch32 = u.first.nch32;                       // units of the first conv; the polyphase convs have ceil(C / 32) each
+        const int nchb = (u.C + 31) / 32;
+        c.hxc_off[0] = alloc((size_t)c.ngroups * (c.nch32 + 2 * nchb) * 3 * c.MW * 2 * 256);
+        c.hxc_inv_off = alloc(3 * c.b_floats + 4);
+        c.bmid_off = u.first.b_off;
+        c.b2_off = u.up.b_off;
+        up_head_jobs.push_back(UpHeadJob{&c, prefix + ".conv_first", prefix + ".residual_block.1", prefix + ".upsample_block0.2",
+                                         u.Cin, u.C});
+    }
+
     void add_raw(RawParam* r, int npair, const std::vector<std::string>& layers, size_t wf, size_t bf) {
         for (int i = 0; i < npair; ++i) { r[i].layer = layers[i]; r[i].w_floats = wf; r[i].b_floats = bf; }
         for (int i = 0; i < npair; ++i) r[i].w_off = alloc(wf);
@@ -423,6 +444,7 @@ int build_plan(fastsvc_plan& P) {
                 }
             }
         }
+        P.add_up_head(u, p);
         P.add_conv(&u.d3, 1, u.C, u.C, 3, 3, {single(p + ".conv_block1.1")});
         P.add_conv(&u.d9, 1, u.C, u.C, 3, 9, {single(p + ".conv_block2.1")});
         P.add_conv(&u.d27, 1, u.C, u.C, 3, 27, {single(p + ".conv_block3.1")});
@@ -548,6 +570,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                 }
         }
         for (int prec = 0; prec < 2; ++prec) {
+            if (!off[prec]) continue;                        // (a fragment set that exists for one storage type only)
             const int np = prec == 0 ? 2 : 1;
             uint16_t* hp = reinterpret_cast<uint16_t*>(blob + off[prec]);
             for (int grp = 0; grp < c.ngroups; ++grp)
@@ -796,6 +819,44 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             for (size_t i = 0; i < (size_t)C2 * 3; ++i) sum += std::fabs((double)WA[(size_t)co * C2 * 3 + i]);
             l1 = std::max(l1, (float)sum);
             bmax = std::max(bmax, std::fabs(blob[c.bmid_off + co]));
+        }
+        cst[0] = l1; cst[1] = bmax; cst[2] = 0.f; cst[3] = 0.f;
+        return FASTSVC_OK;
+    });
+    for (const auto& job_ : plan->up_head_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
+        const auto& job = *pj;
+        const PackedConv& c = *job.c;
+        const int cin = job.cin, C = job.C;
+        HostLayer LF, LR, LU;
+        int rc = fetch_layer(sd, job.first, C, (size_t)cin * 3, LF);
+        if (rc != FASTSVC_OK) return rc;
+        rc = fetch_layer(sd, job.res, C, (size_t)C * 3, LR);
+        if (rc != FASTSVC_OK) return rc;
+        rc = fetch_layer(sd, job.up, C, (size_t)C * 3, LU);
+        if (rc != FASTSVC_OK) return rc;
+        const int nchA = c.nch32, nchB = (C + 31) / 32;
+        PackedConv v = c;
+        v.nch32 = nchA + 2 * nchB;
+        v.cin = v.nch32 * 32;                               // virtual channel axis: [first | residual | up] units
+        auto poly_tap = [](const HostLayer& L, size_t base, int slot) -> float {    // W0 | W0+W1+W2 | W2 (MODE_POLY)
+            if (slot == 1) return (float)((double)L.w[base] + (double)L.w[base + 1] + (double)L.w[base + 2]);
+            return L.w[base + slot];
+        };
+        pack_hx(v, c.hxc_off, 3, [&](int co, int ci, int slot) -> float {
+            if (ci < nchA * 32) return ci < cin ? LF.w[((size_t)co * cin + ci) * 3 + slot] : 0.f;
+            const int cj = ci - nchA * 32;
+            const bool up = cj >= nchB * 32;
+            const int ck = up ? cj - nchB * 32 : cj;
+            if (ck >= C) return 0.f;
+            return poly_tap(up ? LU : LR, ((size_t)co * C + ck) * 3, slot);
+        }, c.hxc_inv_off, 3, [nchA, nchB](int ci, int) { return ci < nchA * 32 ? 0 : (ci - nchA * 32 < nchB * 32 ? 1 : 2); });
+        float* cst = blob + c.hxc_inv_off + 3 * (size_t)c.ngroups * 16 * c.MW;
+        float l1 = 0.f, bmax = 0.f;
+        for (int co = 0; co < C; ++co) {
+            double sum = 0.0;
+            for (size_t i = 0; i < (size_t)cin * 3; ++i) sum += std::fabs((double)LF.w[(size_t)co * cin * 3 + i]);
+            l1 = std::max(l1, (float)sum);
+            bmax = std::max(bmax, std::fabs(LF.b[co]));
         }
         cst[0] = l1; cst[1] = bmax; cst[2] = 0.f; cst[3] = 0.f;
         return FASTSVC_OK;
@@ -1227,6 +1288,70 @@ hipError_t run_chain(const PackedConv& a, const PackedConv& c, const float* blob
     }
 #endif
     return launch(p, L);
+}
+
+// The head of an up block as ONE launch (fastsvc_hx.hip, MODE_UPHEAD): p describes the input x (T = x_T = input
+// columns), y = xr, y2 = u1 with ss_out / st_out; `done` = false when this call has no fused variant (float32 storage,
+// rows a multiple of 4 long, table entry "<layer>|B|T" not 0).
+hipError_t run_uphead(const UpStage& u, const float* blob, ConvParams p, hipStream_t stream, Profiler* prof, const char* layer,
+                      bool& done) {
+    done = false;
+    static const int hx_env = std::getenv("FASTSVC_HX") ? std::atoi(std::getenv("FASTSVC_HX")) : 1;
+    static const int head_env = std::getenv("FASTSVC_UPHEAD") ? std::atoi(std::getenv("FASTSVC_UPHEAD")) : 1;
+    const PackedConv& c = u.head;
+    const bool act_bf16 = g_tune.plan && g_tune.plan->storage == 1;
+    if (!hx_env || !head_env || act_bf16 || !c.hxc_off[0] || (p.x_T & 3) || g_tune.tuning) return hipSuccess;
+    p.T = p.x_T;
+    p.ldx = p.x_T; p.ldy = p.x_T * u.scale;
+    if (p.lens) { p.len_mul = p.T / p.frames_ld; p.xlen_mul = p.x_T / p.frames_ld; if ((p.len_mul & 3) != 0) return hipSuccess; }
+    p.mode = MODE_UPHEAD;
+    p.CIN = u.Cin; p.CMID = u.C; p.COUT = u.C;
+    p.nch32 = c.nch32; p.nch32b = (u.C + 31) / 32; p.dil = 1; p.dil2 = 1; p.ntaps = 3; p.ngroups = c.ngroups; p.s = u.scale;
+    p.whx = blob + c.hxc_off[0]; p.whx_sig = 0;
+    p.whx_inv = blob + c.hxc_inv_off; p.whx_inv_sig = 0;
+    p.bias = blob + c.b_off; p.bias2 = blob + c.b2_off; p.bias_mid = blob + c.bmid_off;
+    p.vec = 1; p.tpw = 1;
+    // one shape per channel count: the workgroup holds every channel of its tile (twice)
+    ConvLaunch L{c.MW, 2, 1, 4, 1, 2};
+    if (c.MW == 3 && c.ngroups == 4) { L.NW = 4; L.WM = 4; L.WN = 1; }
+    else if (c.MW == 3 && c.ngroups == 2) { L.NW = 2; L.WM = 2; L.WN = 2; }
+    else if (c.ngroups != 1) return hipSuccess;
+    if (!conv_hx_shape(MODE_UPHEAD, L.MW, L.NW, L.WM, L.WN)) return hipSuccess;
+    const int NT = 16 * L.NW * L.WN;
+    const size_t lds = (size_t)2 * 2 * (NT + 16 + 8 + 4) * 64 + (size_t)2 * p.nch32b * 2 * (NT + 16) * 64 + 8192;
+    if (lds > 160 * 1024) return hipSuccess;
+    char key[96];
+    std::snprintf(key, sizeof(key), "%s|%d|%d", layer, p.B, p.T);
+    // Measured (profiles/r3_layers_*): the fused head costs about what the three launches cost (its consumer waves
+    // run conv_first, two polyphase convs and two epilogues back to back while the separate launches spread over more
+    // workgroups), so it only runs where the launch table says it won for this (B, T): algorithm 3; FASTSVC_UPHEAD=2
+    // forces it (A/B).
+    bool fused = head_env == 2;
+    if (g_tune.plan) {
+        std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
+        auto it = g_tune.plan->tuned.find(key);
+        if (it != g_tune.plan->tuned.end()) {
+            fused = it->second.algo == 3 || (head_env == 2 && it->second.algo != 0);
+            if (it->second.algo == 0) fused = false;                     // table says: separate launches
+            if (it->second.tpw >= 1 && it->second.tpw <= 64) p.tpw = it->second.tpw;
+        }
+    }
+    if (!fused) return hipSuccess;
+    done = true;
+    if (prof) {
+        const double cin = u.Cin, C = u.C, Ti = (double)p.x_T, To = Ti * u.scale;
+        const double flops = (2.0 * 3.0 * cin * C * Ti + 2.0 * 2.0 * 3.0 * C * C * To) * p.B;
+        const double bytes = 4.0 * (cin * Ti + 4.0 * C * To) * p.B +
+                             4.0 * (double)(u.first.w_floats + u.res.w_floats + u.up.w_floats + 3 * u.res.b_floats);
+        char kname[48];
+        std::snprintf(kname, sizeof(kname), "conv_hx<%d,%d,%d,%d,8,4,%d,x3>", L.MW, L.NW, L.WM, L.WN, u.scale);
+        hipError_t e = prof->begin(stream, layer, kname, flops, bytes);
+        if (e != hipSuccess) return e;
+        e = launch_conv_hx(p, L, stream);
+        if (e != hipSuccess) return e;
+        return prof->end();
+    }
+    return launch_conv_hx(p, L, stream);
 }
 
 hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int nsig, long pair_w_stride,
@@ -2002,7 +2127,20 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         // amax rows (float32 storage): every tensor a convolution stages WITHOUT an InstanceNorm in front
         float* am_x = i == 0 ? amax_inb + 2 * B * 256 : am("up." + std::to_string(i - 1) + ".out");
         float* am_p = am("up." + s + ".spk");                      // speaker biases: bound of a normalised row
-        ConvParams p = base;                                       // a = conv_first(x)
+        // the block's head - conv_first and the two stretched convs behind it - as ONE launch where it has the variant
+        bool head_fused = false;
+        {
+            ConvParams ph = base;
+            ph.x = x; ph.x_b = (long)Cx * Tin; ph.x_T = (int)Tin;
+            ph.y = xr; ph.y_b = cb; ph.y2 = u1; ph.y2_b = cb;
+            ph.flags = F_POST_LRELU | aff_out;
+            ph.ss_out = ss; ph.ss_out_b = 2 * cb; ph.st_out = st;
+            ph.amax_in = am_x;
+            HIP_TRY(run_uphead(u, blob, ph, stream, prof, ("up." + s + ".head").c_str(), head_fused));
+        }
+        ConvParams p = base;
+        if (!head_fused) {
+        p = base;                                                  // a = conv_first(x)
         p.x = x; p.x_b = (long)Cx * Tin; p.x_T = (int)Tin;
         p.y = a; p.y_b = (long)u.C * Tin; p.T = (int)Tin;
         p.amax_in = am_x;
@@ -2020,6 +2158,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.y = nullptr; p.y2 = u1; p.y2_b = cb;
         p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st;
         HIP_TRY(run_conv(u.up, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".up_stretch").c_str()));
+        }
 
         p = base;                                                  // xmid = conv_d3(lrelu(norm(u1))) + xr
         p.x = u1; p.x_b = cb; p.x_T = (int)Tout; p.T = (int)Tout;

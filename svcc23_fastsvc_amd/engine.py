@@ -218,6 +218,22 @@ class Plan:
             T *= int(sc)
         self.load_tuned({f"conv_last|{B}|{T}": [1, 1, 4, 1, 0], f"conv_last|{B}|{T}|b": [1, 1, 4, 1, 0]})
 
+    def fuse_block_heads(self, B: int, F: int, fused: bool = True) -> None:
+        """The head of an up block - ``conv_first`` and the two stretched convs behind it - can run as ONE launch
+        (kernel mode 8, float32 storage, rows a multiple of 4 long: the tensor ``a`` between them never leaves LDS).
+        It costs about what the three launches cost, so it runs only where the launch table holds algorithm 3 under
+        ``up.<i>.head|B|T_in``; this sets those entries for a batch shape (``fused=False``: algorithm 0, the three
+        launches whatever a loaded table says - the ``up.<i>.a`` taps then hold the tensor)."""
+        T = F
+        table = {}
+        for i, sc in enumerate(self.cfg.upsampling_scales):
+            table[f"up.{i}.head|{B}|{T}"] = [2, 1, 4, 1, 3 if fused else 0]
+            T *= int(sc)
+        self.load_tuned(table)
+
+    def keep_block_heads_separate(self, B: int, F: int) -> None:
+        self.fuse_block_heads(B, F, fused=False)
+
     def load_tuned_file(self, path: str, missing_ok: bool = False) -> int:
         """Load this configuration's section of a tuned-shape JSON file (tools/tune_shapes.py)."""
         if not os.path.exists(path):

@@ -174,6 +174,7 @@ def test_frame_counts_not_multiple_of_four_stay_on_the_fast_path(dev, F):
     b = S.synth_batch(cfg, B, F, 62)
     plan = A.Plan(cfg)
     plan.keep_last_block_output(B, F)                  # the `up.3.out` tap below (else conv_last rides on up.3.d27)
+    plan.keep_block_heads_separate(B, F)               # the `up.k.a` taps (else conv_first is fused with the stretched convs)
     blob = plan.pack(sd).to(dev)
     ws = torch.zeros(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
     recs = []
@@ -441,6 +442,7 @@ def test_polyphase_stretch_convs_taps_and_fallback(dev, F, expect_poly):
     B = 2
     b = S.synth_batch(cfg, B, F, 42)
     plan = A.Plan(cfg)
+    plan.keep_block_heads_separate(B, F)               # (the stretched convs as launches of their own)
     blob = plan.pack(sd).to(dev)
     ws = torch.zeros(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
     recs = []
@@ -460,6 +462,54 @@ def test_polyphase_stretch_convs_taps_and_fallback(dev, F, expect_poly):
             got = plan.tap(f"up.{i}.{name}", B, F, ws).cpu()
             want = taps[f"up.{i}.{name}"]
             assert float((got - want).abs().max()) <= TIGHT * max(1.0, float(want.abs().max())), (i, name)
+
+
+@pytest.mark.parametrize("spk", [True, False])
+def test_fused_block_heads_match_the_separate_launches_and_the_oracle(dev, spk):
+    """The head of every up block - conv_first, the stretched residual conv and the stretched up conv with its FiLM
+    affine (fastsvc.py:92-97) - runs as ONE launch (kernel mode 8: the tensor `a` stays in LDS, twice: raw and
+    LeakyReLU'd): xr / u1 taps, the InstanceNorm sums and the waveform against the oracle and against the three
+    separate launches; ragged batch included."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 71)
+    B, F = 3, 44
+    b = S.synth_batch(cfg, B, F, 72)
+    emb = b.spk_emb if spk else None
+    ins = _to(dev, b.ppg, b.sine, b.lft, emb)
+    fused, sep = A.Plan(cfg), A.Plan(cfg)
+    fused.fuse_block_heads(B, F)                       # (table-controlled: algorithm 3 under up.<i>.head|B|T_in)
+    fused.load_tuned({f"up.{i}.head|1|{t}": [2, 1, 4, 1, 3] for i, t in enumerate((F, 2 * F, 8 * F, 32 * F))})   # the runs alone below
+    sep.keep_block_heads_separate(B, F)
+    blob = fused.pack(sd).to(dev)
+    ref, taps = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft, emb, return_taps=True)
+    ws_f = torch.zeros(fused.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    ws_s = torch.zeros(sep.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    recs = []
+    y_f = fused.forward(blob, *ins, workspace=ws_f, profile=recs)
+    y_s = sep.forward(blob, *ins, workspace=ws_s)
+    torch.cuda.synchronize()
+    layers = {r["layer"]: r["kernel"] for r in recs}
+    for i in range(cfg.n_stages):
+        assert f"up.{i}.head" in layers and layers[f"up.{i}.head"].split(",")[4] == "8", sorted(layers)
+        assert f"up.{i}.conv_first" not in layers
+    assert float((y_f.cpu() - ref).abs().max()) <= TIGHT * max(1.0, float(ref.abs().max()))
+    assert float((y_f - y_s).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    for i in range(cfg.n_stages):
+        for name in ("xr", "u1"):
+            got, want = fused.tap(f"up.{i}.{name}", B, F, ws_f).cpu(), taps[f"up.{i}.{name}"]
+            assert float((got - want).abs().max()) <= TIGHT * max(1.0, float(want.abs().max())), (i, name)
+        if spk:
+            st_f = fused.tap(f"up.{i}.stats", B, F, ws_f)[:B].cpu()
+            st_s = sep.tap(f"up.{i}.stats", B, F, ws_s)[:B].cpu()
+            assert float(((st_f - st_s).abs() / (st_s.abs() + 1.0)).max()) <= 1e-5
+    # ragged: every utterance exactly what it is alone
+    lengths = [44, 28, 12]
+    y_r = fused.forward(blob, *ins, lengths=lengths)
+    for j, n in enumerate(lengths):
+        alone = fused.forward(blob, ins[0][j:j + 1, :, :n].contiguous(), ins[1][j:j + 1, :, :n * cfg.hop].contiguous(),
+                              ins[2][j:j + 1, :, :n * cfg.hop].contiguous(), None if ins[3] is None else ins[3][j:j + 1])
+        assert float((y_r[j:j + 1, :, :n * cfg.hop] - alone).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_stale_launch_shape_entries_are_ignored(dev):
@@ -508,6 +558,7 @@ def test_winograd_time_convs_match_oracle_taps(dev, algo):
     table[f"film.0.chain|{B}|{rates[0]}"] = [3, 1, 4, 1, 0]
     for i, t_in in enumerate((F, 2 * F, 8 * F)):
         table[f"up.{i}.conv_first|{B}|{t_in}"] = [1, 1, 4, 1, algo]
+    plan.keep_block_heads_separate(B, F)               # (conv_first as a launch of its own: a Winograd candidate)
     plan.load_tuned(table)
     ws = torch.zeros(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
     recs = []
