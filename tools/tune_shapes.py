@@ -16,7 +16,7 @@ from svcc23_fastsvc_amd import synth as S
 from svcc23_fastsvc_amd.engine import TUNED_TABLE_PATH
 
 REPS = int(os.environ.get("TUNE_REPS", "3"))
-names = sys.argv[1:] or ["cfg1", "cfg2"]          # "cfg3:bf16" tunes the bfloat16-storage entries (keys end in "|b")
+names = sys.argv[1:] or ["cfg1", "cfg2"]          # "cfg3:bf16" tunes the bfloat16-storage entries (keys end in "|b"); "32x1500": B x F
 cfg = S.FULL_CONFIG
 dev = torch.device("cuda:0")
 ROUNDS = int(os.environ.get("TUNE_ROUNDS", "3"))          # independent tunings per workload; the table that runs the whole forward fastest is kept
@@ -39,9 +39,15 @@ def time_forward(plan, blob, ins, ws, n=30):
 for name in names:
     name, _, st = name.partition(":")
     storage = "bfloat16" if st == "bf16" else "float32"
-    wl = S.WORKLOADS[name]
-    b = S.synth_batch(cfg, wl["B"], wl["F"], wl["seed"])
-    ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
+    if "x" in name and name.split("x")[0].isdigit():          # "32x1500": any batch size x frame count
+        wl = {"B": int(name.split("x")[0]), "F": int(name.split("x")[1]), "seed": 99}
+    else:
+        wl = S.WORKLOADS[name]
+    if wl["B"] * wl["F"] > 20000:
+        ins = list(S.device_batch(cfg, wl["B"], wl["F"], wl["seed"], dev))
+    else:
+        b = S.synth_batch(cfg, wl["B"], wl["F"], wl["seed"])
+        ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
     best = (1e30, None)
     for rnd in range(ROUNDS):
         votes = collections.defaultdict(collections.Counter)
