@@ -21,7 +21,8 @@
  *     path run on helper streams forked from and joined back into it with events); no hidden
  *     synchronisation.  The helper streams / events of a (device, stream) pair are created by the
  *     FIRST forward on that pair, or ahead of time by fastsvc_stream_prepare(); after that a forward
- *     allocates nothing.  Concurrent forwards on DIFFERENT streams are independent; forwards issued
+ *     allocates nothing; fastsvc_stream_release() frees them (streams handed to forward must outlive
+ *     their context).  Concurrent forwards on DIFFERENT streams are independent; forwards issued
  *     from several host threads on the SAME stream are serialised while they enqueue.
  *   - return value 0 = success; negative = FASTSVC_E_*; fastsvc_last_error() gives the text.
  */
@@ -130,6 +131,13 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
  * that the forward itself allocates nothing (call once per stream, e.g. before graph capture or
  * a latency-critical first call).  Idempotent. */
 int fastsvc_stream_prepare(void* stream);
+
+/* Frees the helper streams / events held for `stream` on the current device (after waiting for whatever
+ * they still run).  Call it BEFORE destroying a stream that forwards were issued on: contexts are keyed by
+ * the stream handle, are otherwise kept for the life of the process, and a new stream that reuses the
+ * handle value would inherit the old one's.  No forward may be in flight on `stream` from another host
+ * thread.  Returns 1 if a context was freed, 0 if there was none. */
+int fastsvc_stream_release(void* stream);
 
 /* Host-side number formats of the half-precision-MFMA kernels (csrc/fastsvc_hx.hip), exported so that the
  * packer's conversions can be pinned against an independent implementation (tests/test_boundary.py):

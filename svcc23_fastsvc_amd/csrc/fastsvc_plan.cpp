@@ -1082,15 +1082,16 @@ struct ExecCtx {
 // streams enabled (2 per down stage + 2 per up block + 1 ss_ready per stage, with slack), so the
 // ring never wraps inside one call.  Created on first use: the call that creates it allocates
 // streams/events and is therefore not graph-capturable - fastsvc_forward_prepare() does it ahead.
+std::mutex g_ctx_mu;
+std::map<std::pair<int, hipStream_t>, ExecCtx*> g_ctxs;
+
 ExecCtx* exec_ctx_for(hipStream_t stream) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, ExecCtx*> ctxs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
     const auto key = std::make_pair(dev, stream);
-    auto it = ctxs.find(key);
-    if (it != ctxs.end()) return it->second;
+    auto it = g_ctxs.find(key);
+    if (it != g_ctxs.end()) return it->second;
     ExecCtx* c = new ExecCtx();
     // the FiLM helper stream runs at the LOWEST priority: its kernels only fill the CUs the
     // critical-path kernels leave idle; the residual-conv stream keeps the default priority
@@ -1102,8 +1103,34 @@ ExecCtx* exec_ctx_for(hipStream_t stream) {
     c->ev.resize(nev);
     for (int i = 0; i < nev; ++i)
         if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
-    ctxs[key] = c;
+    g_ctxs[key] = c;
     return c;
+}
+
+// fastsvc_stream_release: the context of (current device, stream) is drained and destroyed.  The helper
+// streams are synchronised first - they may still hold work forked from a forward on `stream` - so a later
+// stream that happens to get the same handle value starts from a fresh context with nothing pending.
+// Returns 1 when a context existed, 0 when there was none.
+int exec_ctx_release(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    ExecCtx* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        auto it = g_ctxs.find(std::make_pair(dev, stream));
+        if (it == g_ctxs.end()) return 0;
+        c = it->second;
+        g_ctxs.erase(it);
+    }
+    {
+        std::lock_guard<std::mutex> busy(c->busy);          // a forward still enqueueing through it finishes first
+        for (hipStream_t a : c->aux)
+            if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+        for (hipEvent_t e : c->ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    delete c;
+    return 1;
 }
 
 // Autotuning state of one forward call (fastsvc_autotune): when `tuning` every pipelined conv
@@ -2224,6 +2251,8 @@ int fastsvc_stream_prepare(void* stream) {
     return exec_ctx_for(static_cast<hipStream_t>(stream)) ? FASTSVC_OK
                                                           : fail(FASTSVC_E_HIP, "could not create the helper streams / events");
 }
+
+int fastsvc_stream_release(void* stream) { return exec_ctx_release(static_cast<hipStream_t>(stream)); }
 
 int fastsvc_plan_set_storage(fastsvc_plan* plan, int32_t dtype) {
     if (!plan || (dtype != 0 && dtype != 1)) return fail(FASTSVC_E_INVALID, "storage dtype must be 0 (float32) or 1 (bfloat16)");

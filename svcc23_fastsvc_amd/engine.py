@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "fastsvc_forward", "fastsvc_autotune", "fastsvc_tuned_count", "fastsvc_tuned_get", "fastsvc_tuned_set",
     "fastsvc_forward_profile", "fastsvc_workspace_tap", "fastsvc_forward_launch_count",
     "fastsvc_flops_per_sample", "fastsvc_signal_scratch_bytes", "fastsvc_signal_generate",
-    "fastsvc_stream_prepare", "fastsvc_split_half", "fastsvc_plan_set_workspace_mode",
+    "fastsvc_stream_prepare", "fastsvc_stream_release", "fastsvc_split_half", "fastsvc_plan_set_workspace_mode",
     "fastsvc_loudness_frames", "fastsvc_loudness_scratch_bytes", "fastsvc_loudness_extract",
 )
 
@@ -107,6 +107,8 @@ def load_library():
     lib.fastsvc_split_half.restype = None
     lib.fastsvc_stream_prepare.argtypes = [vp]
     lib.fastsvc_stream_prepare.restype = ctypes.c_int
+    lib.fastsvc_stream_release.argtypes = [vp]
+    lib.fastsvc_stream_release.restype = ctypes.c_int
     lib.fastsvc_autotune.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, ctypes.POINTER(i32)]
     lib.fastsvc_autotune.restype = ctypes.c_int
     lib.fastsvc_tuned_count.argtypes = [vp]
@@ -281,6 +283,13 @@ class Plan:
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _check(self.lib, self.lib.fastsvc_stream_prepare(ctypes.c_void_p(stream)), "fastsvc_stream_prepare")
+
+    def release_stream(self, stream=None, device=None) -> bool:
+        """Free the helper streams / events the library holds for `stream` (a torch.cuda.Stream; default: the
+        current one) - to be called before a short-lived stream that ran forwards is dropped."""
+        with torch.cuda.device(device):
+            st = (stream or torch.cuda.current_stream(device)).cuda_stream
+            return bool(self.lib.fastsvc_stream_release(ctypes.c_void_p(st)))
 
     def workspace_bytes(self, B: int, F: int) -> int:
         return int(self.lib.fastsvc_workspace_bytes(self._h, B, F))

@@ -228,3 +228,26 @@ def test_compact_workspace_same_waveform_less_memory(dev):
     y0 = full.forward(blob, *ins[:3], None)
     y1 = compact.forward(blob, *ins[:3], None)
     assert float((y0 - y1).abs().max()) <= 2e-5
+
+
+def test_short_lived_streams_release_their_helper_streams(dev):
+    """A caller that makes a stream per request: forward on it, release the library's context for it before the
+    stream goes away (include/fastsvc_hip.h, fastsvc_stream_release); same waveform every time, the context is
+    there exactly once per stream, and the default stream's context is untouched."""
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 35)
+    plan = A.Plan(cfg)
+    blob = plan.pack(sd).to(dev)
+    ins = list(S.device_batch(cfg, 2, 40, 36, dev))
+    want = plan.forward(blob, *ins)
+    torch.cuda.synchronize()
+    for _ in range(6):
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            y = plan.forward(blob, *ins)
+        assert plan.release_stream(st) is True            # waits for the helper streams, frees them
+        assert plan.release_stream(st) is False
+        st.synchronize()
+        assert float((y - want).abs().max()) <= 2e-5      # (InstanceNorm sums are accumulated with atomics)
+    assert float((plan.forward(blob, *ins) - want).abs().max()) <= 2e-5
