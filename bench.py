@@ -13,6 +13,7 @@ resident in HBM.  Workloads (BASELINE.json `configs`):
                   packs the weights and broadcasts the blob over RCCL, each step's waveforms are
                   all-gathered over xGMI asynchronously (overlapping the next step).
   cfg1 / cfg3     1 x 2 s / 64 x 10 s per GPU, same scheme.
+  cfg4var         cfg4's variable-length variant (2 - 10 s, ragged length-bucketed batches)
   cfg4            the 512-utterance set (10 s each), utterance-parallel STRONG scaling: the set is
                   sharded over the ranks (svcc23_fastsvc_amd.distributed.run_utterance_parallel:
                   LPT shards, batches of 64, round-wise asynchronous all-gather); a step is one pass
@@ -55,7 +56,7 @@ def parse():
     # slower than 200 after 50); the large workloads scale them down below
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4var", "cfg5"],
                     help="cfg5: one full training step (generator fwd/bwd, MelGAN MSD, MR-STFT + adversarial losses, RAdam; "
                          "recipe batch 32 x 16000 samples per GPU, data-parallel gradient all-reduce)")
     ap.add_argument("--storage", default="float32", choices=["float32", "bfloat16"],
@@ -388,14 +389,14 @@ def run_cfg5(args, dist, world, rank, dev):
 
 def main():
     args = parse()
-    big = args.workload in ("cfg3", "cfg4")
+    big = args.workload in ("cfg3", "cfg4", "cfg4var")
     if args.workload == "cfg5":
         args.steps = args.steps or 10
         args.warmup = args.warmup if args.warmup is not None else 3
     if args.steps is None:
-        args.steps = 10 if args.workload == "cfg4" else 40 if big else 200
+        args.steps = 10 if args.workload.startswith("cfg4") else 40 if big else 200
     if args.warmup is None:
-        args.warmup = 2 if args.workload == "cfg4" else 10 if big else 50
+        args.warmup = 2 if args.workload.startswith("cfg4") else 10 if big else 50
     # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL's version banner on the first
     # collective, for one) goes to stderr - fd 1 is pointed at fd 2 until the line is written
     sys.stdout.flush()
@@ -430,7 +431,8 @@ def main():
 
     cfg = S.FULL_CONFIG
     wl = S.WORKLOADS[args.workload]
-    strong = args.workload == "cfg4"
+    strong = args.workload in ("cfg4", "cfg4var")
+    ragged = args.workload == "cfg4var"
     B, F = (64, wl["F"]) if strong else (wl["B"], wl["F"])      # cfg4 runs in batches of 64
     T = F * cfg.hop
     plan = A.Plan(cfg, load_shipped_table=not args.no_table, storage=args.storage, compact_workspace=True)
@@ -454,25 +456,32 @@ def main():
             dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
             dist = dist1
         n_utts = wl["B"]
-        n_frames = [F] * n_utts
+        n_frames = S.workload_frames(args.workload)
         mine = D.shard_utterances(n_frames, world)[rank]
         utts = [None] * n_utts
         for c0 in range(0, len(mine), 64):
             chunk = mine[c0: c0 + 64]
             ppg, sine, lft, emb = S.device_batch(cfg, len(chunk), F, wl["seed"] + 7919 * rank + c0, dev)
             for j, i in enumerate(chunk):
-                utts[i] = dict(ppg=ppg[j], sine=sine[j], lft=lft[j], spk_emb=emb[j])
+                f = n_frames[i]
+                utts[i] = dict(ppg=ppg[j, :, :f], sine=sine[j, :, : f * cfg.hop], lft=lft[j, :, : f * cfg.hop], spk_emb=emb[j])
         ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
-        args_dev = [torch.stack([utts[i][k] for i in mine[:B]]) for k in ("ppg", "sine", "lft", "spk_emb")]
+        first = sorted(mine, key=lambda i: -n_frames[i])[:B]
+        args_dev = [torch.stack([torch.nn.functional.pad(utts[i][k], (0, (F - n_frames[i]) * (1 if k == "ppg" else cfg.hop)))
+                                 if k != "spk_emb" else utts[i][k] for i in first]) for k in ("ppg", "sine", "lft", "spk_emb")]
 
-        def fwd(ppg, sine, lft, emb, out=None):
-            return plan.forward(blob, ppg, sine, lft, emb, workspace=ws, out=out)
+        if ragged:
+            def fwd(ppg, sine, lft, emb, lens, out=None):
+                return plan.forward(blob, ppg, sine, lft, emb, lengths=lens, workspace=ws, out=out)
+        else:
+            def fwd(ppg, sine, lft, emb, out=None):
+                return plan.forward(blob, ppg, sine, lft, emb, workspace=ws, out=out)
 
         def step(i):
-            D.run_utterance_parallel(fwd, utts, dev, max_batch=64, n_frames=n_frames, hop=cfg.hop, forward_into=True)
+            D.run_utterance_parallel(fwd, utts, dev, max_batch=64, n_frames=n_frames, hop=cfg.hop, forward_into=True, ragged=ragged)
 
         drain = torch.cuda.synchronize
-        samples_per_step = float(n_utts) * T
+        samples_per_step = float(sum(n_frames)) * cfg.hop            # real samples only: padding is not output
     else:
         if args.workload == "cfg3":
             args_dev = list(S.device_batch(cfg, B, F, wl["seed"] + 1000 * rank, dev))
@@ -509,8 +518,10 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     if rank == 0:
-        batches_per_step = (len(mine) + B - 1) // B if strong else 1
-        roof = roofline(plan, blob, args_dev, ms_per_step / batches_per_step)
+        # per-batch time for the end-to-end fraction: the step's time scaled to one full B x F batch of samples
+        # (cfg4: 1 / batches per step; cfg4var: by the samples of this rank's shard - its batches differ in size)
+        batch_share = B * T / (float(sum(n_frames[i] for i in mine)) * cfg.hop) if strong else 1.0
+        roof = roofline(plan, blob, args_dev, ms_per_step * batch_share)
         secondary = None
         if world == 1 and not args.no_secondary and args.workload == "cfg2":
             del ws
@@ -544,10 +555,11 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": plan.arithmetic,
             "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: {wl['desc']}, sharded over {world} GPU(s) in batches of {B}, "
+            "config": {"workload": (f"{args.workload}: {wl['desc']}, sharded over {world} GPU(s) in batches of <= {B}, "
                                     if strong else f"{args.workload}: {wl['desc']} per GPU, ") +
                                    f"F={F} frames, T={T} samples, generator fastsvc.yaml (144->[192,96,48,24], x[2,4,4,5]), spk_emb on",
-                       "global_batch": wl["B"] if strong else world * B, "utterance_samples": T,
+                       "global_batch": wl["B"] if strong else world * B, "utterance_samples": T if not ragged else
+                       f"{wl['Fmin'] * cfg.hop} - {T} (value counts real samples only; padded batches, pad <= 12.5 %)",
                        "parallelism": f"utterance-parallel x{world}" + (" + all-gather of waveforms" if (world > 1 or strong) else "")},
             "rtf_24k": 24000.0 / value,
             "alg_gflop_per_step": flops_step / 1e9,

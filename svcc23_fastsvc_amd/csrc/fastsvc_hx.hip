@@ -636,7 +636,12 @@ __device__ __forceinline__ void hx_last_reduce(const ConvParams& p, const f32x4 
 
 // MODE: MODE_DIRECT (any dilation <= 28), MODE_POLY (S = stretch factor; tiles walk the INPUT columns) or
 // MODE_DEC2 (p.s = decimation; two outputs).  EPI: epilogue kind (DEC2: ignored).
-template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S, bool WSTATIC>
+// TAILK: instance for ragged batches whose rows run at the frame rate or twice it - an utterance's own row length
+// need not be a multiple of 4 then (the pitch is).  The staging waves zero what lies past the row end AFTER the
+// prologue (the conv's zero padding), the epilogue keeps it out of the InstanceNorm sums and the running max and
+// stores the straddling float4 whole (between the row end and the pitch lies nobody's data).  Its own instances:
+// folded into the others it cost the 128-register variants their spill-free allocation.
+template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S, bool WSTATIC, bool TAILK = false>
 __global__ __launch_bounds__(512, (hx_min_waves<MW, NW, MODE, EPI>()))
 void conv_hx_kernel(const ConvParams p0) {
     constexpr bool UPH = MODE == MODE_UPHEAD;                          // conv_first -> {stretched residual conv, stretched up conv + FiLM affine}
@@ -854,6 +859,7 @@ void conv_hx_kernel(const ConvParams p0) {
             it_q[i] = it_in[i] ? (idx >> 2) : (W >> 2);
         }
         const float slope = (DEC2 || (flags & F_PRE_LRELU)) ? LRELU_SLOPE : 1.0f;     // max(v, slope * v): identity for 1
+        const bool tail_rows = TAILK && (p.T & 3) != 0;    // this utterance's rows end inside a float4 (ragged batch)
         // MODE_CHAIN1: taps and bias of the first conv for the 8 channels of this thread's item(s) (one octet per
         // thread when ITEMS == 1, which the launcher guarantees)
         float i1w[IN1 ? 8 : 1][3], i1b[IN1 ? 8 : 1];
@@ -880,7 +886,10 @@ void conv_hx_kernel(const ConvParams p0) {
             for (int i = 0; i < ITEMS; ++i) {
                 const int t = t_start + 4 * it_q[i];
                 const bool tok = it_in[i] && (unsigned)t < (unsigned)p.T && un < nunits && !(FASTSVC_DBG_ON(p, DBG_NO_LOAD));
-                tokmask |= (tok ? 1u : 0u) << i;
+                // how many of the item's 4 time steps lie inside the row (a ragged batch's own row lengths need not
+                // be a multiple of 4: the float4 that straddles the row end also holds whatever the pitch holds)
+                if constexpr (TAILK) tokmask |= (tok ? (unsigned)min(4, p.T - t) : 0u) << (3 * i);
+                else tokmask |= (tok ? 1u : 0u) << i;
                 if constexpr (IN1) {
                     // six signal samples t-1 .. t+4 (a negative offset is out of range like any other: 0 = the
                     // first conv's own zero padding)
@@ -946,7 +955,8 @@ void conv_hx_kernel(const ConvParams p0) {
                 float Bc[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
                 // rows outside the utterance are the conv's zero padding AFTER the prologue: their loads
                 // returned 0, so only the additive term has to go
-                const bool tok = (tokmask >> i) & 1u;
+                const int nvi = TAILK ? (int)((tokmask >> (3 * i)) & 7u) : (int)((tokmask >> i) & 1u);
+                const bool tok = nvi != 0;
                 #pragma unroll
                 for (int c = 0; c < 8; ++c) Bc[c] = tok ? Bc[c] : 0.f;
                 // one time step (= one 16-byte slot of 8 channels per piece) at a time: the transformed values
@@ -956,6 +966,10 @@ void conv_hx_kernel(const ConvParams p0) {
                     float e[8];
                     #pragma unroll
                     for (int c = 0; c < 8; ++c) e[c] = px[i][c][j] * A[c] + Bc[c];
+                    if (TAILK && tail_rows) {                  // (wave-uniform; rows a multiple of 4 long skip it)
+                        #pragma unroll
+                        for (int c = 0; c < 8; ++c) e[c] = j < nvi ? e[c] : 0.f;
+                    }
                     // the raw copy for the 1x1 residual conv: no prologue at all, i.e. (A, Bc) = (sx, 0) and the FMA's
                     // result IS the scaled raw value (a decimating stage never sits behind a norm); committed first,
                     // the LeakyReLU then runs in place
@@ -1279,7 +1293,7 @@ void conv_hx_kernel(const ConvParams p0) {
 #ifdef FASTSVC_ACT_BF16
                         hx_epilogue_poly8<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
 #else
-                        ws_epilogue_poly<MW, NW, EPI, S, 0>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
+                        ws_epilogue_poly<MW, NW, EPI, S, TAILK ? 2 : 0>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
 #endif
                     }
                     else if constexpr (DEC2)
@@ -1292,7 +1306,7 @@ void conv_hx_kernel(const ConvParams p0) {
                                                                    (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew, Xw);
                         } else
 #endif
-                        ws_epilogue_kind<MW, NW, EPI, EST, 0, -1>(p, R, acc, s1, s2, sig, mg,
+                        ws_epilogue_kind<MW, NW, EPI, EST, TAILK ? 2 : 0, -1>(p, R, acc, s1, s2, sig, mg,
                                                               (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
                         if constexpr (LAST_OK) {
                             if (p.last_w && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
@@ -1343,8 +1357,23 @@ static hipError_t hx_launch_instance(dim3 grid, size_t smem, hipStream_t stream,
     return hipGetLastError();
 }
 
+// instances compiled with the row-end handling (TAILK): the layers that run at the frame rate or twice it - C >= 96
+// in the recipe's configuration, i.e. MW = 3 - in float32 storage
+constexpr bool hx_tail_instance(int MW, int MODE, int EPI, int S) {
+#ifdef FASTSVC_ACT_BF16
+    return false;
+#else
+    return MW == 3 && ((MODE == MODE_DIRECT && EPI != EPI_RANK1) || (MODE == MODE_POLY && S != 5) || MODE == MODE_DEC2);
+#endif
+}
+
 template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S>
 static hipError_t hx_launch_kind(dim3 grid, size_t smem, hipStream_t stream, const ConvParams& p) {
+    if (p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0)) {
+        if constexpr (hx_tail_instance(MW, MODE, EPI, S))
+            return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, false, true>>(grid, smem, stream, p);
+        else return hipErrorInvalidValue;              // (run_conv asks conv_hx_tail_ok first)
+    }
     // the ring holds the whole layer when there is a single K chunk: nothing to re-request (MW = 2 layers: C_in <= 32)
     if constexpr (MW == 2 && MODE != MODE_UPHEAD) {
         if (p.nch32 == 1 && ((MODE != MODE_CHAIN && MODE != MODE_CHAIN1) || p.nch32b == 1)) return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE, EPI, S, true>>(grid, smem, stream, p);
@@ -1458,6 +1487,8 @@ hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_
 }
 
 #ifndef FASTSVC_ACT_BF16      // storage-independent host query: defined once
+bool conv_hx_tail_ok(int mode, int MW, int epi_kind, int S) { return hx_tail_instance(MW, mode, epi_kind, S); }
+
 bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN) {
     if (mode == MODE_POLY)
         return (MW == 2 && WM == 1 && WN == 4 && (NW == 2 || NW == 3)) ||

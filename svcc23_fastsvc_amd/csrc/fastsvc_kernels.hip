@@ -516,6 +516,9 @@ void conv_mfma_kernel(const ConvParams p0) {
         const int frames = p0.lens[b];
         p.T = frames * p0.len_mul;
         p.x_T = frames * p0.xlen_mul;
+        // the float4 epilogue needs THIS utterance's rows to be a multiple of 4 long, not the padded maximum: the
+        // straddling float4 would store, and sum into the InstanceNorm statistics, what lies past the row end
+        if (p.T & 3) p.vec = 0;
     }
     const int t0 = blockIdx.x * NT;
     if (t0 >= p.T) return;

@@ -207,6 +207,28 @@ struct fastsvc_plan {
     struct Choice { int NW, WM, WN, tpw, algo; };    // algo: 0 direct / as launched, 1 Winograd F(2,3)
     mutable std::mutex tune_mu;
     mutable std::map<std::string, Choice> tuned;
+    // Off-table shapes: the (NW, WM, WN, algorithm) of the table entry of the SAME layer whose problem size is
+    // nearest (cached per key; algo < 0 = the table has nothing for the layer); cleared whenever `tuned` changes.
+    mutable std::map<std::string, Choice> priors;
+
+    // |ln work ratio| + a quarter of |ln row-length ratio|: what a launch shape trades off (workgroups against tiles
+    // per workgroup against columns per tile) depends on B * T first and on the row length second
+    bool prior_for(const char* layer, int B, int T, bool bf16, Choice& out) const {     // tune_mu held
+        const size_t ln = std::strlen(layer);
+        double best = 1e30;
+        bool found = false;
+        for (const auto& kv : tuned) {
+            const std::string& k = kv.first;
+            if (k.size() <= ln + 1 || k.compare(0, ln, layer) != 0 || k[ln] != '|') continue;
+            int b = 0, t = 0;
+            char tail = 0;
+            const int n = std::sscanf(k.c_str() + ln + 1, "%d|%d|%c", &b, &t, &tail);
+            if (n < 2 || b <= 0 || t <= 0 || (n == 3) != bf16) continue;
+            const double d = std::fabs(std::log((double)b * t / ((double)B * T))) + 0.25 * std::fabs(std::log((double)t / T));
+            if (d < best) { best = d; out = kv.second; found = true; }
+        }
+        return found;
+    }
 
     size_t alloc(size_t nfloats) {
         size_t off = blob_floats;
@@ -1270,6 +1292,7 @@ hipError_t run_chain(const PackedConv& a, const PackedConv& c, const float* blob
         fused = sep_ms <= 0.0 || best_ms / 3.0 < sep_ms;
         std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
         g_tune.plan->tuned[key] = fastsvc_plan::Choice{best.NW, best.WM, best.WN, p.tpw, fused ? 3 : 0};
+        g_tune.plan->priors.clear();
         have = true;
     }
     if (!have) {
@@ -1468,9 +1491,15 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         static const int hx_env = std::getenv("FASTSVC_HX") ? std::atoi(std::getenv("FASTSVC_HX")) : 1;
         const bool hx_mode = (p.mode == MODE_DIRECT && p.x_T == p.T) || (p.mode == MODE_POLY && c.hxp_off[0]) ||
                              (p.mode == MODE_DEC2 && (p.x_T & 3) == 0);
+        // ragged batch whose rows run at the frame rate or twice it (len_mul 1 or 2): an utterance's own row length
+        // need not be a multiple of 4.  The float32-storage instances handle that (producers zero what lies past the
+        // row end after the prologue, epilogues keep it out of the sums) as long as the row PITCHES are a multiple
+        // of 4; the bfloat16 ones do not
+        const bool ragged_tail = p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0);
+        const bool hx_tail_ok = !ragged_tail || (!act_bf16 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 &&
+                                                 conv_hx_tail_ok(p.mode, c.MW, epi_kind, poly ? p.s : 1));
         const bool hx_ok = hx_env != 0 && !p.no_hx && c.hx && hx_mode && c.ntaps == 3 && (p.T & 3) == 0 &&
-                           c.dil <= 28 && !(p.flags & F_PRE_AFFINE) &&
-                           (!p.lens || ((p.len_mul & 3) == 0 && (p.xlen_mul & 3) == 0));
+                           c.dil <= 28 && !(p.flags & F_PRE_AFFINE) && hx_tail_ok;
         if (hx_ok) {
             static const int shapes[][3] = {{8, 4, 1}, {6, 2, 2}, {4, 2, 2}, {2, 2, 2}, {3, 1, 4}, {2, 1, 4}};
             for (const auto& sh : shapes)
@@ -1493,7 +1522,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             // whatever the padded maximum is): only the variants compiled with the row-end handling
             std::vector<Cand> keep;
             for (const Cand& cd : cands)
-                if (cd.algo != 3 &&
+                if (cd.algo == 3 ? (p.T & 3) == 0 :            // (hx candidates are only there when hx_tail_ok)
                     conv_ws_tail_ok(cd.algo == 2 ? 2 : c.MW, cd.NW, is_wino(cd.algo) ? (int)MODE_WINO : p.mode, epi_kind,
                                     poly ? p.s : 1)) keep.push_back(cd);
             if (!keep.empty()) cands.swap(keep);       // (never empty: NW <= 2 variants always have it)
@@ -1578,7 +1607,34 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             hipEventDestroy(e0); hipEventDestroy(e1);
             std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
             g_tune.plan->tuned[key] = fastsvc_plan::Choice{best.NW, best.WM, best.WN, p.tpw, best.algo};
+            g_tune.plan->priors.clear();
             have = true;
+        }
+        // No entry for this (B, T): the tile shape and algorithm of the table entry of this layer with the nearest
+        // problem size, where one exists and this launch is compiled for it - a layer's best shape moves slowly with
+        // the size (the tuned tables agree on it across batch shapes far more often than the model below finds it:
+        // tools/costmodel_gap.py) - and only the tiles per workgroup from the model.
+        bool prior_pick = false;
+        static const int prior_env = std::getenv("FASTSVC_PRIOR") ? std::atoi(std::getenv("FASTSVC_PRIOR")) : 1;
+        if (!have && g_tune.plan && prior_env) {
+            fastsvc_plan::Choice pr{0, 0, 0, 0, -1};
+            {
+                std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
+                auto it = g_tune.plan->priors.find(key);
+                if (it != g_tune.plan->priors.end()) pr = it->second;
+                else {
+                    if (!g_tune.plan->prior_for(layer, p.B, p.T, act_bf16, pr)) pr.algo = -1;
+                    g_tune.plan->priors[key] = pr;
+                }
+            }
+            if (pr.algo >= 0)
+                for (const Cand& cd : cands)
+                    if (cd.NW == pr.NW && cd.WM == pr.WM && cd.WN == pr.WN && cd.algo == pr.algo) {
+                        const Cand only = cd;
+                        cands.assign(1, only);
+                        prior_pick = true;
+                        break;
+                    }
         }
         if (!have) {
         // Tile shape and tiles-per-workgroup from a small cost model: a workgroup costs a fixed
@@ -1594,7 +1650,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             // Winograd variant loses to the scalar phase-plane staging.  FASTSVC_WINO = 0 / 1 / 2
             // forces direct / layer grouping / 32-channel grouping.
             const int wino_pref = wino_env >= 0 ? wino_env : (c.MW == 2 ? 0 : 2);
-            if (hx_ok != (cd.algo == 3)) continue;          // the half-precision MFMA variant wherever the layer has one
+            if (!prior_pick && hx_ok != (cd.algo == 3)) continue;          // the half-precision MFMA variant wherever the layer has one
             if (cd.algo == 3) {
                 // data-movement model: one workgroup per CU; a unit moves its window in and (per tile) its
                 // outputs; the matrix work (3 taps x NW x MW x 1|3 products of 16 cycles) hides under it
@@ -1609,7 +1665,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 const double mem_us = bytes_unit / (4.5e6 / 256.0);
                 const double mfma_us = (poly ? 5.0 : p.mode == MODE_DEC2 ? 4.0 : 3.0) * cd.NW * c.MW * (act_bf16 ? 1 : 3) * 17.0 / 2.0e3;
                 const double unit_us = mem_us > mfma_us ? mem_us : mfma_us;
-                for (int tpw = 1; tpw <= 16; ++tpw) {
+                for (int tpw = 1; tpw <= 24; ++tpw) {
                     const long wgs = ((ntx + tpw - 1) / tpw) * gy * zb;
                     const long rounds = (wgs + 255) / 256;
                     const double t = rounds * (startup_us + tpw * c.nch32 * unit_us);
@@ -1617,8 +1673,10 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 }
                 continue;
             }
-            if ((cd.algo >= 1) != (wino_ok && wino_pref >= 1)) continue;
-            if (wino_pref >= 1 && wino_ok && c.wino2 && (cd.algo == 2) != (wino_pref == 2)) continue;
+            if (!prior_pick) {
+                if ((cd.algo >= 1) != (wino_ok && wino_pref >= 1)) continue;
+                if (wino_pref >= 1 && wino_ok && c.wino2 && (cd.algo == 2) != (wino_pref == 2)) continue;
+            }
             const int NT = (cd.algo >= 1 ? 32 : 16) * cd.NW * cd.WN;
             const int cMW = cd.algo == 2 ? 2 : c.MW;
             const long ntx = (p.T + NT - 1) / NT;
@@ -2285,6 +2343,7 @@ int fastsvc_tuned_set(const fastsvc_plan* plan, const char* key, const int32_t s
     if (std::strlen(key) >= 96) return fail(FASTSVC_E_INVALID, "key too long");
     std::lock_guard<std::mutex> lock(plan->tune_mu);
     plan->tuned[key] = fastsvc_plan::Choice{shape[0], shape[1], shape[2], shape[3], shape[4]};
+    plan->priors.clear();
     return FASTSVC_OK;
 }
 

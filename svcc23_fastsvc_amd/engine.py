@@ -184,6 +184,7 @@ class Plan:
         if compact_workspace:
             _check(self.lib, self.lib.fastsvc_plan_set_workspace_mode(handle, 1), "fastsvc_plan_set_workspace_mode")
         self.last_autotune_trials = 0
+        self.pad_odd_lengths = True          # float32 storage: run F % 4 != 0 batches padded (see padded_frames)
         if load_shipped_table:
             self.load_tuned_file(TUNED_TABLE_PATH, missing_ok=True)
 
@@ -295,9 +296,11 @@ class Plan:
         return int(self.lib.fastsvc_workspace_bytes(self._h, B, F))
 
     def padded_frames(self, F: int) -> int:
-        """Frame count the library actually runs for an F-frame batch: bfloat16 storage pads to a multiple of 4
-        (and runs the batch as a ragged one), float32 storage takes any F."""
-        return F + ((-F) % 4) if self.storage == "bfloat16" else F
+        """Frame count the library actually runs for an F-frame batch: the next multiple of 4 (the padded batch is run
+        as a ragged one).  bfloat16 storage needs it; float32 storage takes any F, but rows that are not a multiple of
+        4 long (F-rate and 2F-rate tensors) send their layers to the slower gathered kernels - 64 x 1499 frames took
+        27.0 ms against 22.5 ms for 64 x 1500 (tools/ragged_check.py) - so `Plan.forward` pads there too."""
+        return F + ((-F) % 4)
 
     def pack(self, state_dict: Mapping[str, object], reuse_pinned: bool = False) -> torch.Tensor:
         """Fold weight-norm and pack a state dict (either key layout) into the kernel blob.
@@ -394,15 +397,13 @@ class Plan:
         ppg, sine, lft = (t.to(torch.float32).contiguous() for t in (ppg, sine, lft))
         if spk_emb is not None:
             spk_emb = spk_emb.to(torch.float32).contiguous()
-        if self.storage == "bfloat16" and F % 4 != 0 and profile is None:
+        if F % 4 != 0 and profile is None and (self.storage == "bfloat16" or self.pad_odd_lengths):
             # bfloat16 storage moves 4 time steps per access at the frame rate, so the library wants F % 4 == 0
-            # (three of four real utterances are not): pad to the next multiple and run the padded batch as a
-            # ragged one - `lengths` makes every utterance exactly what it would be alone at its own length.
-            # The caller's workspace is used when it holds the padded batch (size it with
-            # `workspace_bytes(B, padded_frames(F))`); the padded inputs live in one reused staging set.
-            if autotune:
-                raise ValueError("bfloat16 storage: autotune needs a frame count that is a multiple of 4 "
-                                 "(tune the padded length: launch shapes are keyed by the padded row lengths)")
+            # (three of four real utterances are not); float32 storage runs such rows on its slower kernels.  Pad to
+            # the next multiple and run the padded batch as a ragged one - `lengths` makes every utterance exactly
+            # what it would be alone at its own length.  The caller's workspace is used when it holds the padded
+            # batch (size it with `workspace_bytes(B, padded_frames(F))`); the padded inputs live in one reused
+            # staging set.  Autotuning tunes the padded shape (launch shapes are keyed by the padded row lengths).
             Fp = self.padded_frames(F)
             hop = cfg.hop
             key = (B, Fp, str(dev))
@@ -415,6 +416,10 @@ class Plan:
             pp, ps, pl, py = self._pad_bufs
             pp[..., :F].copy_(ppg); ps[..., :T].copy_(sine); pl[..., :T].copy_(lft)      # (the padding stays zero)
             ok_ws = workspace is not None and workspace.numel() >= self.workspace_bytes(B, Fp)
+            if autotune:
+                if lengths is not None:
+                    raise ValueError("autotune times full-length batches: call it without lengths")
+                self.forward(blob, pp, ps, pl, spk_emb, out=py, workspace=workspace if ok_ws else None, autotune=True)
             self.forward(blob, pp, ps, pl, spk_emb, out=py, workspace=workspace if ok_ws else None,
                          lengths=[F] * B if lengths is None else lengths)
             if out is None:

@@ -317,7 +317,18 @@ WORKLOADS = {
     "cfg2": dict(B=8, F=600, seed=1236, desc="8 x 4 s utterances"),
     "cfg3": dict(B=64, F=1500, seed=1237, desc="64 x 10 s utterances"),
     "cfg4": dict(B=512, F=1500, seed=1238, desc="512 x 10 s utterances (sharded)"),
+    # SURVEY 8(d)'s optional variant of cfg4: lengths uniform in 2 - 10 s, run as ragged length-bucketed batches
+    "cfg4var": dict(B=512, F=1500, Fmin=300, seed=1239, desc="512 utterances of 2 - 10 s (uniform), ragged batches (sharded)"),
 }
+
+
+def workload_frames(name: str):
+    """Frame count of every utterance of a sharded workload (deterministic)."""
+    wl = WORKLOADS[name]
+    if "Fmin" not in wl:
+        return [wl["F"]] * wl["B"]
+    rng = np.random.default_rng(wl["seed"])
+    return [int(v) for v in rng.integers(wl["Fmin"], wl["F"] + 1, size=wl["B"])]
 
 
 def device_batch(cfg: GeneratorConfig, B: int, F: int, seed: int, device, sample_rate: int = 24000):

@@ -763,3 +763,41 @@ def test_ragged_batch_on_a_non_default_configuration(dev):
                               b.lft[j:j + 1, :, : n * hop], b.spk_emb[j:j + 1])
         assert float((y[j:j + 1, :, : n * hop] - ref).abs().max()) <= TIGHT * max(1.0, float(ref.abs().max())), j
         assert float(y[j, :, n * hop:].abs().max() if n < F else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("width,storage", [("tiny", "float32"), ("full", "float32"), ("full", "bfloat16")])
+def test_ragged_batch_with_odd_lengths_equals_every_utterance_alone(dev, width, storage):
+    """A padded batch with per-utterance lengths: utterance b is what it would be alone at lengths[b] frames, for
+    lengths that are odd, = 2 mod 4 and multiples of 4 (rows at the frame rate and twice it then end inside a
+    float4 - float32 storage runs them on the row-end instances of the split-binary16 kernels, narrow
+    configurations on the gathered kernel), with a POISONED workspace and garbage in the inputs' padding: nothing
+    past an utterance's end may reach its output or its InstanceNorm statistics."""
+    cfg = S.TINY_CONFIG if width == "tiny" else S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 41)
+    lens = [25, 22, 23, 7, 28, 9]
+    B, Fp = len(lens), 28
+    b = S.synth_batch(cfg, B, Fp, 42)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ppg, sine, lft = b.ppg.copy(), b.sine.copy(), b.lft.copy()
+    for i, n in enumerate(lens):                        # garbage past the end of every utterance
+        ppg[i, :, n:] = 1e3; sine[i, :, n * cfg.hop:] = -1e3; lft[i, :, n * cfg.hop:] = 1e3
+    plan = A.Plan(cfg, storage=storage)
+    blob = plan.pack(sd).to(dev)
+    ws = torch.empty(plan.workspace_bytes(B, Fp) // 4 * 4 + 4, dtype=torch.uint8, device=dev)
+    ws[: ws.numel() // 4 * 4].view(torch.float32).fill_(1000.0)
+    y = plan.forward(blob, t(ppg), t(sine), t(lft), t(b.spk_emb), lengths=lens, workspace=ws).cpu().numpy()
+    ws.fill_(0xFF)                                      # and once more over NaN patterns
+    y2 = plan.forward(blob, t(ppg), t(sine), t(lft), t(b.spk_emb), lengths=lens, workspace=ws).cpu().numpy()
+    assert np.isfinite(y2).all()
+    alone = A.Plan(cfg, storage=storage)
+    alone.pad_odd_lengths = False
+    for i, n in enumerate(lens):
+        T = n * cfg.hop
+        if storage == "bfloat16" and n % 4:
+            alone.pad_odd_lengths = True                # (bfloat16 storage has no unpadded route for such lengths)
+        yi = alone.forward(blob, t(b.ppg[i:i + 1, :, :n]), t(b.sine[i:i + 1, :, :T]), t(b.lft[i:i + 1, :, :T]),
+                           t(b.spk_emb[i:i + 1])).cpu().numpy()[0]
+        tol = 2e-5 if storage == "float32" else 0.15
+        for got in (y, y2):
+            assert float(np.abs(got[i, :, :T] - yi).max()) <= tol, (i, n, float(np.abs(got[i, :, :T] - yi).max()))
+            assert not got[i, :, T:].any()
