@@ -215,6 +215,15 @@ int fastsvc_signal_generate(const float* f0, float* out, void* scratch, int32_t 
                             float sample_rate, float sine_amp, float noise_amp,
                             const int32_t* types, int32_t ntypes, uint64_t seed, void* stream);
 
+/* Batch assembly for ragged batches (csrc/fastsvc_stage.hip; the reference decodes one utterance at a time,
+ * decode_fastsvc.py:160-200, and has no counterpart): utterance b's tensor is a (C, lens[b]) float32 block at
+ * src[b] ON THE DEVICE whose rows are pitches[b] elements apart; dst (B, C, width) receives them zero-padded to
+ * `width` columns (lens[b] <= width).  `src`, `lens`, `pitches` are HOST arrays of B entries, read during the call
+ * (their values travel in the kernel arguments: nothing to keep alive, no table upload).  One launch per 64
+ * utterances on `stream`. */
+int fastsvc_gather_padded(const float* const* src, const int32_t* lens, const int32_t* pitches, float* dst,
+                          int32_t B, int32_t C, int32_t width, void* stream);
+
 /* ---- the producer of the generator's loudness input ----
  * Replaces loudness_extract(audio, sampling_rate, hop_length) (harana/bin/preprocess_fastsvc.py:60-75; librosa
  * 0.8.1 stft n_fft 2048 / periodic Hann / reflect padding, perceptual (A) weighting with the 80 dB floor below

@@ -47,6 +47,7 @@ UNITS = [
     ("fastsvc_plan.cpp", [], "plan.o"),
     ("fastsvc_signal.hip", [], "signal.o"),
     ("fastsvc_loudness.hip", [], "loudness.o"),
+    ("fastsvc_stage.hip", [], "stage.o"),
 ]
 
 

@@ -228,9 +228,14 @@ class _Stager:
                 if all(t.shape[-1] == width for t in ts):
                     out.append(torch.stack(ts).to(self.device))
                     continue
-                # ragged: ONE zeroed batch, every row copied into its place (padding each row and stacking the
-                # results moved every byte twice and launched three kernels per utterance)
-                batch = torch.zeros((len(ts),) + tuple(ts[0].shape[:-1]) + (width,), dtype=ts[0].dtype, device=self.device)
+                if self.cuda:
+                    # ragged, on the device: one gather launch per tensor (csrc/fastsvc_stage.hip) - 64 separate copies
+                    # queue at ~15 us apiece behind a busy stream: 42 ms of the 185 ms pass over the 2 - 10 s set
+                    # (tools/ragged_check.py)
+                    from .engine import gather_padded
+                    out.append(gather_padded([t.to(torch.float32) for t in ts], width))
+                    continue
+                batch = torch.zeros((len(ts),) + tuple(ts[0].shape[:-1]) + (width,), dtype=ts[0].dtype)
                 for j, t in enumerate(ts):
                     batch[j, ..., : t.shape[-1]].copy_(t)
                 out.append(batch)

@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "fastsvc_flops_per_sample", "fastsvc_signal_scratch_bytes", "fastsvc_signal_generate",
     "fastsvc_stream_prepare", "fastsvc_stream_release", "fastsvc_split_half", "fastsvc_plan_set_workspace_mode",
     "fastsvc_loudness_frames", "fastsvc_loudness_scratch_bytes", "fastsvc_loudness_extract",
+    "fastsvc_gather_padded",
 )
 
 
@@ -109,6 +110,8 @@ def load_library():
     lib.fastsvc_stream_prepare.restype = ctypes.c_int
     lib.fastsvc_stream_release.argtypes = [vp]
     lib.fastsvc_stream_release.restype = ctypes.c_int
+    lib.fastsvc_gather_padded.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32), vp, i32, i32, i32, vp]
+    lib.fastsvc_gather_padded.restype = ctypes.c_int
     lib.fastsvc_autotune.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, ctypes.POINTER(i32)]
     lib.fastsvc_autotune.restype = ctypes.c_int
     lib.fastsvc_tuned_count.argtypes = [vp]
@@ -138,6 +141,37 @@ def load_library():
         raise FastSVCError("libfastsvc_hip.so ABI version mismatch")
     _LIB = lib
     return lib
+
+
+def gather_padded(rows: Sequence[torch.Tensor], width: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Assemble a zero-padded batch from B device tensors of shape (C, len_b) (len_b <= width; float32, unit stride
+    along time, any row pitch - views of larger tensors are fine): -> (B, C, width).  One HIP launch per 64
+    utterances on the current stream (fastsvc_gather_padded, csrc/fastsvc_stage.hip); fails loudly off the GPU."""
+    lib = load_library()
+    B = len(rows)
+    if B == 0:
+        raise ValueError("gather_padded needs at least one utterance")
+    first = rows[0]
+    if not first.is_cuda:
+        raise FastSVCError("gather_padded needs GPU tensors (no CPU fallback); got " + str(first.device))
+    C = int(first.shape[0])
+    for t in rows:
+        if t.dim() != 2 or t.shape[0] != C or t.dtype != torch.float32 or t.device != first.device or \
+                (t.shape[1] > 1 and t.stride(1) != 1) or t.shape[1] > width:
+            raise ValueError(f"gather_padded: every utterance must be a float32 (C={C}, len <= {width}) tensor with unit "
+                             f"time stride on {first.device}; got {tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    if out is None:
+        out = torch.empty((B, C, width), dtype=torch.float32, device=first.device)
+    elif tuple(out.shape) != (B, C, width) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != first.device:
+        raise ValueError(f"out must be a contiguous float32 {(B, C, width)} tensor on {first.device}")
+    src = (ctypes.c_void_p * B)(*[t.data_ptr() for t in rows])
+    lens = (ctypes.c_int32 * B)(*[int(t.shape[1]) for t in rows])
+    pitches = (ctypes.c_int32 * B)(*[int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[1]), 1) for t in rows])
+    with torch.cuda.device(first.device):
+        stream = torch.cuda.current_stream(first.device).cuda_stream
+        _check(lib, lib.fastsvc_gather_padded(src, lens, pitches, ctypes.c_void_p(out.data_ptr()), B, C, width,
+                                              ctypes.c_void_p(stream)), "fastsvc_gather_padded")
+    return out
 
 
 def _check(lib, rc: int, what: str):
@@ -364,6 +398,31 @@ class Plan:
             return workspace[off: off + numel * 2].view(torch.bfloat16).view(shape)
         return workspace[off: off + numel * 4].view(torch.float32).view(shape)
 
+    _LENS_SLOTS = 32
+
+    def _stage_lengths(self, lens_host: torch.Tensor, B: int, dev) -> torch.Tensor:
+        """Frame counts -> device through a RING of page-locked slots owned by the plan.  A fresh pinned tensor per
+        call looked harmless, but the host runs many batches ahead of the GPU: the pinned allocator cannot recycle a
+        block whose copy has not run yet, so every forward of a pass over ragged batches paid a hipHostMalloc
+        (≈ 3 ms each, serialised with the device: 187 ms instead of 145 ms for the 13 batches of cfg4var).  A slot is
+        reused only after its copy has completed (event; the host waits only if it is 32 batches ahead)."""
+        ring = getattr(self, "_lens_ring", None)
+        if ring is None or ring["buf"].shape[1] < B:
+            ring = {"buf": torch.empty((self._LENS_SLOTS, max(64, B)), dtype=torch.int32, pin_memory=True),
+                    "ev": [None] * self._LENS_SLOTS, "i": 0}
+            self._lens_ring = ring
+        slot = ring["i"] % self._LENS_SLOTS
+        ring["i"] += 1
+        if ring["ev"][slot] is not None:
+            ring["ev"][slot].synchronize()
+        src = ring["buf"][slot, :B]
+        src.copy_(lens_host)
+        out = src.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        ring["ev"][slot] = ev
+        return out
+
     def forward(self, blob: torch.Tensor, ppg: torch.Tensor, sine: torch.Tensor, lft: torch.Tensor,
                 spk_emb: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
                 workspace: Optional[torch.Tensor] = None, profile: Optional[list] = None,
@@ -442,10 +501,7 @@ class Plan:
                     raise ValueError(f"lengths must hold {B} frame counts in [1, {F}]")
                 # through page-locked memory: a pageable source makes the copy block the host until it is done
                 # (the header promises a forward that never synchronises)
-                pinned = torch.empty(B, dtype=torch.int32, pin_memory=True)
-                pinned.copy_(lens_host)
-                lens_dev = pinned.to(dev, non_blocking=True)
-                self._last_lens_host = pinned                       # alive until the copy has run
+                lens_dev = self._stage_lengths(lens_host, B, dev)
         need = self.workspace_bytes(B, F)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=dev)

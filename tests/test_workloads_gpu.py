@@ -290,3 +290,29 @@ def test_off_table_shapes_run_close_to_their_autotuned_time(dev):
     t_tuned = median_ms(tuned, blob, ws)
     assert float((y_model - y_tuned).abs().max()) <= 5e-5          # whatever the launch shapes, the same waveform
     assert t_model <= 1.12 * t_tuned, (t_model, t_tuned)
+
+
+def test_gather_padded_assembles_ragged_batches(dev):
+    """csrc/fastsvc_stage.hip: utterances of different lengths (contiguous blocks and views with a row pitch,
+    unaligned starts, one channel and many, more than 64 of them, widths that are not a multiple of 4) into one
+    zero-padded batch - bit-exact data movement, against torch's own copies."""
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for C, width, B in ((144, 37, 5), (1, 1003, 70), (8, 64, 64), (3, 5, 2)):
+        big = torch.randn((B, C, width + 9), generator=g).to(dev)
+        lens = [int(v) for v in torch.randint(0 if C > 1 else 1, width + 1, (B,), generator=g)]
+        rows = []
+        for b, n in enumerate(lens):
+            if b % 2:
+                rows.append(big[b, :, 3: 3 + n])                      # a view: pitch width + 9, unaligned start
+            else:
+                rows.append(big[b, :, :n].contiguous())                # its own block: pitch n
+        want = torch.zeros((B, C, width), device=dev)
+        for b, r in enumerate(rows):
+            want[b, :, : r.shape[1]] = r
+        out = torch.full((B, C, width), float("nan"), device=dev)
+        got = A.gather_padded(rows, width, out=out)
+        assert got.data_ptr() == out.data_ptr() and torch.equal(got, want), (C, width, B)
+    with pytest.raises(ValueError):
+        A.gather_padded([torch.zeros((2, 9), device=dev)], 8)          # longer than the batch is wide
+    with pytest.raises(A.FastSVCError):
+        A.gather_padded([torch.zeros((2, 4))], 8)                      # CPU tensors: no fallback

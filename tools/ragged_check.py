@@ -100,7 +100,29 @@ def one_pass(sync):
     return {k: round(v * 1e3, 1) for k, v in T.items()}
 
 
+def gpu_timeline():
+    """The asynchronous pass with events on the compute stream around every phase: where the DEVICE spends the pass."""
+    evs = []
+    mark = lambda tag: (evs.append((tag, torch.cuda.Event(enable_timing=True))), evs[-1][1].record())
+    keep = []
+    mark("start")
+    for chunk in mine:
+        ppg, sine, lft, emb, _ = stager.stage(chunk, max(frames[i] for i in chunk)); mark("stage")
+        rows = torch.empty((len(chunk), 1, sine.shape[-1]), device=dev)
+        plan.forward(blob, ppg, sine, lft, emb, lengths=[frames[i] for i in chunk], workspace=ws, out=rows); mark("forward")
+        keep.append(D._gather_rows(rows, 1, None, async_op=True)); mark("gather")
+    for g, w in keep:
+        w.wait()
+    mark("wait")
+    torch.cuda.synchronize()
+    T = {}
+    for (t0, e0), (t1, e1) in zip(evs, evs[1:]):
+        T[t1] = T.get(t1, 0.0) + e0.elapsed_time(e1)
+    return {k: round(v, 1) for k, v in T.items()}
+
+
 one_pass(False)
+print("asynchronous pass, device time between events on the compute stream (ms):", gpu_timeline())
 print("phases, device-synchronised between them (ms):", one_pass(True))
 t0 = time.perf_counter()
 h = one_pass(False)
