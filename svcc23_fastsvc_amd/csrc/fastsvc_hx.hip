@@ -381,6 +381,11 @@ __device__ __forceinline__ void act_store8(__amdgpu_buffer_rsrc_t r, int boff, c
         __builtin_amdgcn_raw_buffer_store_b64(b, r, nv >= 8 ? boff + 8 : OOB_OFF, 0, 0);
     }
 }
+__device__ __forceinline__ f32x8 keep8_exact(f32x8 v, int nv) {       // zero the elements at and past index nv (any nv)
+    #pragma unroll
+    for (int e = 0; e < 4; ++e) { v.lo[e] = e < nv ? v.lo[e] : 0.f; v.hi[e] = 4 + e < nv ? v.hi[e] : 0.f; }
+    return v;
+}
 __device__ __forceinline__ f32x8 keep8(f32x8 v, int nv) {
     if (nv < 8) v.hi = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nv < 4) v.lo = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -434,7 +439,9 @@ __device__ __forceinline__ void hx_epilogue8_stage(const ConvParams& p, const Ep
     }
 }
 
-template <int MW, int NP2, int EPI, bool EST, class KT>
+// TAILK (see conv_hx_kernel): rows may end inside a group of 4 - the straddling group is stored whole (the pitch is
+// a multiple of 4) and only the InstanceNorm sums are masked element by element
+template <int MW, int NP2, int EPI, bool EST, bool TAILK = false, class KT>
 __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[2 * NP2][MW],
                                              float (&s1)[MW], float (&s2)[MW], int sig, int mg, int tcol0,
                                              bool active, int lane, const KT& K, const float* Ew, float* Xw) {
@@ -462,7 +469,7 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
                 const int k = k0 + g;
                 const int t = tcol0 + k * 32 + (lane >> 4) * 8;
                 const bool ok = cok && t < p.T;
-                nv[g] = ok ? min(8, p.T - t) : 0;
+                nv[g] = ok ? min(8, p.T - t) : 0;                  // (TAILK: any count; the stores round it up to 4)
                 boff[g] = ok ? (rowoff + t) * 2 : OOB_OFF;
                 l0[g] = zero8; l1[g] = zero8; l2[g] = zero8;
                 if constexpr (EST) {
@@ -477,7 +484,7 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
                     if (EPI == EPI_RES) l0[g] = act_load8(R.res, boff[g], 0);
                     if (EPI == EPI_RANK1) {                        // the raw float32 signal
                         l0[g].lo = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
-                        l0[g].hi = buf_load4(R.r1x, (ok && nv[g] == 8) ? t * 4 + 16 : OOB_OFF, 0);
+                        l0[g].hi = buf_load4(R.r1x, (ok && nv[g] > 4) ? t * 4 + 16 : OOB_OFF, 0);
                     }
                     if (EPI == EPI_AFF) {
                         l0[g] = act_load8(R.res, boff[g], 0);      // zero-length descriptor when absent
@@ -495,12 +502,13 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
                 if (EPI == EPI_RES || EPI == EPI_AFF) { v.lo += l0[g].lo; v.hi += l0[g].hi; }
                 if (EPI == EPI_RANK1) { v.lo += l0[g].lo * r1w + r1b; v.hi += l0[g].hi * r1w + r1b; }
                 acc[2 * (k0 + g)][m] = v.lo; acc[2 * (k0 + g) + 1][m] = v.hi;     // (finished values, in the pair layout)
-                act_store8(R.y, boff[g], v, nv[g]);                // dropped when y is absent
+                const int nvs = TAILK ? ((nv[g] + 3) & ~3) : nv[g];
+                act_store8(R.y, boff[g], v, nvs);                  // dropped when y is absent
                 if (EPI == EPI_AFF) {
                     f32x8 u;
                     u.lo = l1[g].lo * v.lo + l2[g].lo; u.hi = l1[g].hi * v.hi + l2[g].hi;
-                    u = keep8(u, nv[g]);
-                    act_store8(R.y2, boff[g], u, nv[g]);
+                    u = TAILK ? keep8_exact(u, nv[g]) : keep8(u, nv[g]);
+                    act_store8(R.y2, boff[g], u, nvs);
                     s1[m] += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
                     s2[m] += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
                              ((u.hi.x * u.hi.x + u.hi.y * u.hi.y) + (u.hi.z * u.hi.z + u.hi.w * u.hi.w));
@@ -511,7 +519,7 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
 }
 // Polyphase epilogue in bfloat16 storage: a lane's 4 S consecutive output samples go out as 16-byte pieces
 // (8 samples; one 8-byte piece left over for odd S) instead of S 8-byte ones (see ws_epilogue_poly).
-template <int MW, int NW, int EPI, int S, class KT>
+template <int MW, int NW, int EPI, int S, bool TAILK = false, class KT>
 __device__ __forceinline__ void hx_epilogue_poly8(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[3][NW][MW],
                                                   float (&s1)[MW], float (&s2)[MW],
                                                   int mg, int tcol0, bool active, int lane, const KT& K) {
@@ -531,6 +539,7 @@ __device__ __forceinline__ void hx_epilogue_poly8(const ConvParams& p, const Epi
         for (int n = 0; n < NW; ++n) {
             const int t = tcol0 + n * 16 + (lane >> 4) * 4;            // input-rate column (rows are a multiple of 4 long)
             const bool ok = cok && t < p.T;
+            const int nvo = TAILK ? (ok ? min(4, p.T - t) * S : 0) : 4 * S;   // output samples of this lane inside the row
             const int boff0 = ok ? (rowoff + t * S) * 2 : OOB_OFF;     // bytes
             const int foff0 = ok ? (rowoff + t * S) * 4 : OOB_OFF;     // the 4-wide helpers take float bytes
             const f32x4 zz = acc[1][n][m] + bias;
@@ -565,7 +574,7 @@ __device__ __forceinline__ void hx_epilogue_poly8(const ConvParams& p, const Epi
                 if (EPI == EPI_AFF) {
                     f32x8 u;
                     u.lo = l1[q].lo * v.lo + l2[q].lo; u.hi = l1[q].hi * v.hi + l2[q].hi;
-                    u = keep8(u, ok ? 8 : 0);
+                    u = TAILK ? keep8_exact(u, nvo - 8 * q) : keep8(u, ok ? 8 : 0);
                     act_store8(R.y2, ok ? boff0 + q * 16 : OOB_OFF, u, ok ? 8 : 0);
                     s1[m] += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
                     s2[m] += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
@@ -580,6 +589,7 @@ __device__ __forceinline__ void hx_epilogue_poly8(const ConvParams& p, const Epi
                 if (EPI == EPI_AFF) {
                     f32x4 u = t1 * v + t2;
                     if (!ok) u = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (TAILK) u = keep_first(u, nvo - 4 * (S - 1));
                     act_store4(R.y2, ok ? foff0 + (S - 1) * 16 : OOB_OFF, u);
                     s1[m] += (u.x + u.y) + (u.z + u.w);
                     s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
@@ -1291,7 +1301,7 @@ void conv_hx_kernel(const ConvParams p0) {
                     if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))); }
                     if constexpr (POLY) {
 #ifdef FASTSVC_ACT_BF16
-                        hx_epilogue_poly8<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
+                        hx_epilogue_poly8<MW, NW, EPI, S, TAILK>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
 #else
                         ws_epilogue_poly<MW, NW, EPI, S, TAILK ? 2 : 0>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
 #endif
@@ -1302,7 +1312,7 @@ void conv_hx_kernel(const ConvParams p0) {
 #ifdef FASTSVC_ACT_BF16
                         if constexpr (PAIRS) {
                             if (!(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
-                                hx_epilogue8<MW, NW / 2, EPI, EST>(p, R, acc, s1, s2, sig, mg,
+                                hx_epilogue8<MW, NW / 2, EPI, EST, TAILK>(p, R, acc, s1, s2, sig, mg,
                                                                    (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew, Xw);
                         } else
 #endif
@@ -1358,13 +1368,9 @@ static hipError_t hx_launch_instance(dim3 grid, size_t smem, hipStream_t stream,
 }
 
 // instances compiled with the row-end handling (TAILK): the layers that run at the frame rate or twice it - C >= 96
-// in the recipe's configuration, i.e. MW = 3 - in float32 storage
+// in the recipe's configuration, i.e. MW = 3 - in both storages
 constexpr bool hx_tail_instance(int MW, int MODE, int EPI, int S) {
-#ifdef FASTSVC_ACT_BF16
-    return false;
-#else
     return MW == 3 && ((MODE == MODE_DIRECT && EPI != EPI_RANK1) || (MODE == MODE_POLY && S != 5) || MODE == MODE_DEC2);
-#endif
 }
 
 template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S>

@@ -215,7 +215,7 @@ hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t s
 hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 // whether launch_conv_hx is compiled for this mode / shape
 bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN);
-// whether the float32-storage instances of this mode / epilogue kind handle rows whose own length (ragged batch at
+// whether the half-precision-MFMA instances of this mode / epilogue kind handle rows whose own length (ragged batch at
 // the frame rate or twice it) is not a multiple of 4 - the pitches must be
 bool conv_hx_tail_ok(int mode, int MW, int epi_kind, int S);
 

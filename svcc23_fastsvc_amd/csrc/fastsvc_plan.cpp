@@ -1492,11 +1492,10 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         const bool hx_mode = (p.mode == MODE_DIRECT && p.x_T == p.T) || (p.mode == MODE_POLY && c.hxp_off[0]) ||
                              (p.mode == MODE_DEC2 && (p.x_T & 3) == 0);
         // ragged batch whose rows run at the frame rate or twice it (len_mul 1 or 2): an utterance's own row length
-        // need not be a multiple of 4.  The float32-storage instances handle that (producers zero what lies past the
-        // row end after the prologue, epilogues keep it out of the sums) as long as the row PITCHES are a multiple
-        // of 4; the bfloat16 ones do not
+        // need not be a multiple of 4.  The TAILK instances handle that (producers zero what lies past the row end
+        // after the prologue, epilogues keep it out of the sums) as long as the row PITCHES are a multiple of 4
         const bool ragged_tail = p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0);
-        const bool hx_tail_ok = !ragged_tail || (!act_bf16 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 &&
+        const bool hx_tail_ok = !ragged_tail || ((p.ldx & 3) == 0 && (p.ldy & 3) == 0 &&
                                                  conv_hx_tail_ok(p.mode, c.MW, epi_kind, poly ? p.s : 1));
         const bool hx_ok = hx_env != 0 && !p.no_hx && c.hx && hx_mode && c.ntaps == 3 && (p.T & 3) == 0 &&
                            c.dil <= 28 && !(p.flags & F_PRE_AFFINE) && hx_tail_ok;
