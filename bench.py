@@ -466,9 +466,11 @@ def main():
                 f = n_frames[i]
                 utts[i] = dict(ppg=ppg[j, :, :f], sine=sine[j, :, : f * cfg.hop], lft=lft[j, :, : f * cfg.hop], spk_emb=emb[j])
         ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
-        first = sorted(mine, key=lambda i: -n_frames[i])[:B]
-        args_dev = [torch.stack([torch.nn.functional.pad(utts[i][k], (0, (F - n_frames[i]) * (1 if k == "ppg" else cfg.hop)))
+        def roofline_batch():                           # the longest B utterances as one full batch (profiled after the timing)
+            first = sorted(mine, key=lambda i: -n_frames[i])[:B]
+            return [torch.stack([torch.nn.functional.pad(utts[i][k], (0, (F - n_frames[i]) * (1 if k == "ppg" else cfg.hop)))
                                  if k != "spk_emb" else utts[i][k] for i in first]) for k in ("ppg", "sine", "lft", "spk_emb")]
+        args_dev = None
 
         if ragged:
             def fwd(ppg, sine, lft, emb, lens, out=None):
@@ -513,6 +515,8 @@ def main():
     # one-off, untimed: pick the launch shape of every layer for this (B, F) on this device
     # (the reference's recipes run with torch.backends.cudnn.benchmark = True, train_fastsvc.py:617)
     if args.autotune:
+        if args_dev is None:
+            args_dev = roofline_batch()
         plan.forward(blob, *args_dev, workspace=ws, autotune=True)
     elapsed = time_steps(step, drain, args.steps, args.warmup, dist if world > 1 else None, dev)
     ms_per_step = elapsed / args.steps * 1e3
@@ -520,6 +524,8 @@ def main():
     if rank == 0:
         # per-batch time for the end-to-end fraction: the step's time scaled to one full B x F batch of samples
         # (cfg4: 1 / batches per step; cfg4var: by the samples of this rank's shard - its batches differ in size)
+        if args_dev is None:
+            args_dev = roofline_batch()
         batch_share = B * T / (float(sum(n_frames[i] for i in mine)) * cfg.hop) if strong else 1.0
         roof = roofline(plan, blob, args_dev, ms_per_step * batch_share)
         secondary = None

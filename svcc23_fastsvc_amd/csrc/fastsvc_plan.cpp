@@ -1859,20 +1859,22 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     const Workspace ws = layout_workspace(P, B, F);
     if (workspace_bytes < ws.bytes) return fail(FASTSVC_E_WORKSPACE, "workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const bool serial = std::getenv("FASTSVC_SERIAL") != nullptr;   // debugging: one stream
     g_tune.plan = plan;
+    // ONE stream by default.  The forward can fork side work onto two helper streams (FASTSVC_STREAMS: bit 0 = the
+    // 1x1 / stretch residual convs, bit 1 = the FiLM nets of stages 0..n-2 + speaker projections), and rounds 1-2
+    // ran the FiLM nets that way from ~10^5 samples per call.  With the fused launches of rounds 2-3 the critical
+    // path has no slack left for them to fill - one stream and two measure the same at every size (cfg1 0.474 / 0.478,
+    // cfg2 1.425 / 1.428, cfg3 22.40 / 22.30 ms) - while helper streams that come to life after another library's
+    // (an RCCL communicator initialised between the first allocation and the first forward) make the two-stream
+    // schedule SLOWER: cfg2 2.54 ms, cfg3 23.5 ms (tools/stream_order_check.py).  Nothing to gain, a cliff to fall
+    // off: the helper streams are opt-in.  (FASTSVC_SERIAL, the older switch, still forces one stream.)
+    static const bool serial = std::getenv("FASTSVC_SERIAL") != nullptr;
+    static const int streams_env = std::getenv("FASTSVC_STREAMS") ? std::atoi(std::getenv("FASTSVC_STREAMS")) : 0;
+    const int streams_mask = serial ? 0 : (streams_env & 3);
     // per-launch profiling and autotuning run on ONE stream so that every kernel is timed alone
-    ExecCtx* ctx = (serial || g_tune.tuning || prof) ? nullptr : exec_ctx_for(stream);
+    ExecCtx* ctx = (streams_mask == 0 || g_tune.tuning || prof) ? nullptr : exec_ctx_for(stream);
     std::unique_lock<std::mutex> ctx_lock;
     if (ctx) ctx_lock = std::unique_lock<std::mutex>(ctx->busy);
-    // FASTSVC_STREAMS: bit 0 = residual-conv helper stream, bit 1 = FiLM helper stream (experiments)
-    // Measured with tuned launch shapes: the FiLM stream pays from ~10^5 samples per call (cfg2 -2 %),
-    // below that the fork/join events cost more than the overlap (cfg1 +4 %); the residual-conv
-    // stream costs 2-15 % everywhere (two extra fork/joins per stage) and is off by default.
-    static const int streams_env = std::getenv("FASTSVC_STREAMS") ? std::atoi(std::getenv("FASTSVC_STREAMS")) : -1;
-    int64_t hop_all = 1;
-    for (int i = 0; i < plan->n; ++i) hop_all *= plan->cfg.upsampling_scales[i];
-    const int streams_mask = streams_env >= 0 ? streams_env : ((int64_t)B * F * hop_all >= 150000 ? 2 : 0);
     hipStream_t s_film = (ctx && (streams_mask & 2)) ? ctx->aux[0] : stream;      // FiLM nets of stages 0..n-2
     hipStream_t s_side = (ctx && (streams_mask & 1)) ? ctx->aux[1] : stream;      // 1x1 / stretch residual convs
     int evi = 0;

@@ -231,9 +231,10 @@ def test_compact_workspace_same_waveform_less_memory(dev):
 
 
 def test_short_lived_streams_release_their_helper_streams(dev):
-    """A caller that makes a stream per request: forward on it, release the library's context for it before the
-    stream goes away (include/fastsvc_hip.h, fastsvc_stream_release); same waveform every time, the context is
-    there exactly once per stream, and the default stream's context is untouched."""
+    """A caller that makes a stream per request.  The forward runs on that one stream (helper streams are opt-in,
+    FASTSVC_STREAMS); where a context of helper streams / events was created for it (fastsvc_stream_prepare, or a
+    forward under FASTSVC_STREAMS), fastsvc_stream_release frees it before the stream goes away - the context is there
+    exactly once per stream, and the waveform is the same every time."""
     cfg = S.FULL_CONFIG
     sd = S.synth_state_dict(cfg, 35)
     plan = A.Plan(cfg)
@@ -245,6 +246,7 @@ def test_short_lived_streams_release_their_helper_streams(dev):
         st = torch.cuda.Stream(device=dev)
         st.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(st):
+            plan.prepare_stream(dev)                       # helper streams / events of (device, st)
             y = plan.forward(blob, *ins)
         assert plan.release_stream(st) is True            # waits for the helper streams, frees them
         assert plan.release_stream(st) is False
@@ -316,3 +318,44 @@ def test_gather_padded_assembles_ragged_batches(dev):
         A.gather_padded([torch.zeros((2, 9), device=dev)], 8)          # longer than the batch is wide
     with pytest.raises(A.FastSVCError):
         A.gather_padded([torch.zeros((2, 4))], 8)                      # CPU tensors: no fallback
+
+
+def test_opt_in_helper_stream_schedule_gives_the_same_waveforms(dev):
+    """FASTSVC_STREAMS (read once per process) forks the FiLM nets / residual convs onto helper streams: same
+    waveform as the default one-stream schedule, ragged batch and poisoned workspace included - run in a child
+    process per mask, checked against this process's one-stream result."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 71)
+    plan = A.Plan(cfg)
+    blob = plan.pack(sd).to(dev)
+    ins = list(S.device_batch(cfg, 3, 52, 72, dev))          # (device_batch is deterministic for a seed)
+    lens = [52, 33, 7]
+    want = plan.forward(blob, *ins).cpu().numpy()
+    want_ragged = plan.forward(blob, *ins, lengths=lens).cpu().numpy()
+    child = (
+        "import sys, numpy as np, torch\n"
+        "import svcc23_fastsvc_amd as A\n"
+        "from svcc23_fastsvc_amd import synth as S\n"
+        "dev = torch.device('cuda:0'); cfg = S.FULL_CONFIG\n"
+        "plan = A.Plan(cfg); blob = plan.pack(S.synth_state_dict(cfg, 71)).to(dev)\n"
+        "ins = list(S.device_batch(cfg, 3, 52, 72, dev))\n"
+        "ws = torch.full((plan.workspace_bytes(3, 52),), 0xFF, dtype=torch.uint8, device=dev)\n"
+        "ys = [plan.forward(blob, *ins, workspace=ws).cpu().numpy() for _ in range(3)]\n"
+        "yr = plan.forward(blob, *ins, lengths=[52, 33, 7], workspace=ws).cpu().numpy()\n"
+        "np.savez(sys.argv[1], y0=ys[0], y2=ys[2], yr=yr)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mask in ("2", "3"):
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "y.npz")
+            env = dict(os.environ, FASTSVC_STREAMS=mask, PYTHONPATH=root)
+            env.pop("FASTSVC_SERIAL", None)
+            r = subprocess.run([sys.executable, "-c", child, out], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            got = np.load(out)
+            for k in ("y0", "y2"):
+                assert float(np.abs(got[k] - want).max()) <= 2e-5, (mask, k)
+            assert float(np.abs(got["yr"] - want_ragged).max()) <= 2e-5, mask
