@@ -17,13 +17,15 @@
  *   - device memory is owned by the caller (PyTorch's caching allocator in the shipped host
  *     code): the packed weight blob, the workspace, the inputs and the output.  The plan object
  *     is host-only and immutable after creation, so one plan may serve several devices/streams.
- *   - every launch is enqueued on the hipStream_t passed in; no hidden synchronisation, and a forward allocates
- *     nothing (it can be captured in a hipGraph).  With FASTSVC_STREAMS=<mask> in the environment (an experiment
- *     switch: it stopped paying once the launches were fused) kernels off the critical path run on
- *     helper streams forked from and joined back into that stream with events; the helper streams / events of a
- *     (device, stream) pair are then created by the FIRST forward on that pair, or ahead of time by
- *     fastsvc_stream_prepare(), and freed by fastsvc_stream_release() (streams handed to forward must outlive their
- *     context).  Concurrent forwards on DIFFERENT streams are independent.
+ *   - every launch is ordered with respect to the hipStream_t passed in; no hidden synchronisation - with ONE
+ *     exception: large calls (from ~1.5e5 output samples) may fork kernels off the critical path onto a helper
+ *     stream, forked from and joined back into that stream with events, and the helper streams / events of a
+ *     (device, stream) pair are created, and the cost of a fork + join through them MEASURED (which synchronises
+ *     the stream once), by the first such forward on that pair - or ahead of time by fastsvc_stream_prepare(),
+ *     e.g. before graph capture (during capture nothing is created or measured: one stream).  Where the fork +
+ *     join is slow the forward stays on the one stream.  fastsvc_stream_release() frees the pair's
+ *     context (streams handed to forward must outlive it).  Concurrent forwards on DIFFERENT streams are
+ *     independent; forwards issued from several host threads on the SAME stream are serialised while they enqueue.
  *   - return value 0 = success; negative = FASTSVC_E_*; fastsvc_last_error() gives the text.
  */
 #ifndef FASTSVC_HIP_H
@@ -127,9 +129,10 @@ int fastsvc_forward(const fastsvc_plan* plan, const void* dev_blob,
                     float* out, int32_t B, int32_t F, const int32_t* lengths,
                     void* workspace, size_t workspace_bytes, void* stream);
 
-/* Creates the helper streams / events fastsvc_forward uses for `stream` on the current device under
- * FASTSVC_STREAMS (see the conventions above; the default one-stream schedule needs none), so that the forward
- * itself allocates nothing (call once per stream, e.g. before graph capture).  Idempotent. */
+/* Creates (and calibrates, see the conventions above: synchronises `stream`) the helper streams / events
+ * fastsvc_forward may use for `stream` on the current device, so that the forward itself allocates nothing and
+ * never synchronises (call once per stream, e.g. before graph capture or a latency-critical first call).
+ * Idempotent. */
 int fastsvc_stream_prepare(void* stream);
 
 /* Frees the helper streams / events held for `stream` on the current device (after waiting for whatever

@@ -232,6 +232,7 @@ hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const flo
 // Every (tensor, utterance) entry is AMAX_W = 8 floats wide (writers spread over the slots, readers take their max):
 // the scan stores 8 partial maxima per input row (no atomics, nothing to zero first) and zeroes the `nzero` floats
 // at `zero` - the intermediate tensors' entries, which later kernels of the forward accumulate into by atomic max.
+hipError_t launch_noop(hipStream_t stream);          // empty kernel (stream calibration)
 hipError_t launch_amax_inputs(const float* sig, long sig_stride, const float* ppg, int B, int C, int F, int hop,
                               const int* lens, float* amax_in, float* zero, int nzero, hipStream_t stream);
 

@@ -1095,7 +1095,57 @@ struct ExecCtx {
     hipStream_t aux[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev;
     std::mutex busy;                   // one forward at a time enqueues through a context
+    bool pays = false;                 // a fork + join through these streams is cheap enough to use them (measured once)
+    float fork_join_us = 0.f;
 };
+
+// What a fork + join between the caller's stream and a helper stream costs HERE, measured once per context with
+// empty kernels: R rounds of [record, wait, launch on the helper, record, wait, launch] against 2R launches on the
+// caller's stream alone.  Normally a few microseconds.  Helper streams that come to life after another library's
+// streams (an RCCL communicator initialised between the process's first allocation and its first forward) take far
+// longer per dependency - the two-stream schedule of cfg2 then ran 2.54 ms instead of 1.43 (tools/stream_order_check.py)
+// - and the forward then stays on one stream.  Synchronises `stream` (first forward on a stream, or
+// fastsvc_stream_prepare); skipped, and the helper streams left unused, while the stream is being captured.
+bool measure_fork_join(hipStream_t stream, ExecCtx* c) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    hipEvent_t t[3] = {nullptr, nullptr, nullptr};
+    for (hipEvent_t& e : t)
+        if (hipEventCreate(&e) != hipSuccess) return false;
+    const int R = 12;
+    bool ok = true;
+    auto alone = [&]() { for (int r = 0; r < 2 * R && ok; ++r) ok = launch_noop(stream) == hipSuccess; };
+    auto forked = [&]() {
+        for (int r = 0; r < R && ok; ++r) {
+            hipEvent_t a = c->ev[(2 * r) % c->ev.size()], b = c->ev[(2 * r + 1) % c->ev.size()];
+            ok = hipEventRecord(a, stream) == hipSuccess && hipStreamWaitEvent(c->aux[0], a, 0) == hipSuccess &&
+                 launch_noop(c->aux[0]) == hipSuccess && hipEventRecord(b, c->aux[0]) == hipSuccess &&
+                 hipStreamWaitEvent(stream, b, 0) == hipSuccess && launch_noop(stream) == hipSuccess;
+        }
+    };
+    alone(); forked();                                    // (code objects loaded, queues awake)
+    float best_alone = 1e30f, best_forked = 1e30f;
+    for (int rep = 0; rep < 3 && ok; ++rep) {
+        ok = ok && hipEventRecord(t[0], stream) == hipSuccess;
+        alone();
+        ok = ok && hipEventRecord(t[1], stream) == hipSuccess;
+        forked();
+        ok = ok && hipEventRecord(t[2], stream) == hipSuccess && hipEventSynchronize(t[2]) == hipSuccess;
+        float ms_a = 0.f, ms_f = 0.f;
+        ok = ok && hipEventElapsedTime(&ms_a, t[0], t[1]) == hipSuccess && hipEventElapsedTime(&ms_f, t[1], t[2]) == hipSuccess;
+        if (ms_a < best_alone) best_alone = ms_a;
+        if (ms_f < best_forked) best_forked = ms_f;
+    }
+    for (hipEvent_t e : t) (void)hipEventDestroy(e);
+    if (!ok) return false;
+    c->fork_join_us = (best_forked - best_alone) * 1e3f / R;
+    static const double limit_us = std::getenv("FASTSVC_FORK_JOIN_LIMIT_US") ? std::atof(std::getenv("FASTSVC_FORK_JOIN_LIMIT_US")) : 40.0;   // measured: 24-27 us where the streams are independent, 52 us where they are not
+    c->pays = c->fork_join_us < limit_us;
+    if (std::getenv("FASTSVC_STREAM_DEBUG"))
+        std::fprintf(stderr, "[fastsvc] fork + join through a helper stream: %.1f us (limit %.0f): helper streams %s\n",
+                     c->fork_join_us, limit_us, c->pays ? "on" : "off");
+    return true;
+}
 
 // One context per (device, caller stream): two host threads driving different streams of one device
 // get their own helper streams and event rings, so a wait can never bind to the other thread's
@@ -1125,6 +1175,7 @@ ExecCtx* exec_ctx_for(hipStream_t stream) {
     c->ev.resize(nev);
     for (int i = 0; i < nev; ++i)
         if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+    (void)measure_fork_join(stream, c);
     g_ctxs[key] = c;
     return c;
 }
@@ -1860,19 +1911,21 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     if (workspace_bytes < ws.bytes) return fail(FASTSVC_E_WORKSPACE, "workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     g_tune.plan = plan;
-    // ONE stream by default.  The forward can fork side work onto two helper streams (FASTSVC_STREAMS: bit 0 = the
-    // 1x1 / stretch residual convs, bit 1 = the FiLM nets of stages 0..n-2 + speaker projections), and rounds 1-2
-    // ran the FiLM nets that way from ~10^5 samples per call.  With the fused launches of rounds 2-3 the critical
-    // path has no slack left for them to fill - one stream and two measure the same at every size (cfg1 0.474 / 0.478,
-    // cfg2 1.425 / 1.428, cfg3 22.40 / 22.30 ms) - while helper streams that come to life after another library's
-    // (an RCCL communicator initialised between the first allocation and the first forward) make the two-stream
-    // schedule SLOWER: cfg2 2.54 ms, cfg3 23.5 ms (tools/stream_order_check.py).  Nothing to gain, a cliff to fall
-    // off: the helper streams are opt-in.  (FASTSVC_SERIAL, the older switch, still forces one stream.)
+    // Scheduling: the FiLM nets of stages 0..n-2 + the speaker projections can run on a lowest-priority
+    // helper stream (mask bit 1; bit 0: the 1x1 / stretch residual convs, an experiment that never paid).  With the
+    // fused launches that is worth ~2 % at cfg2 and nothing at cfg3 / cfg1 - and only where a fork + join through the
+    // helper stream is as cheap as it should be, which ExecCtx measures once (measure_fork_join): with helper streams
+    // created after an RCCL communicator the same schedule ran cfg2 in 2.54 ms instead of 1.43.  Default: bit 1 from
+    // ~1.5e5 samples per call where the context says it pays, one stream otherwise; FASTSVC_STREAMS=<mask> forces a
+    // mask (0: one stream), FASTSVC_SERIAL one stream.
     static const bool serial = std::getenv("FASTSVC_SERIAL") != nullptr;
-    static const int streams_env = std::getenv("FASTSVC_STREAMS") ? std::atoi(std::getenv("FASTSVC_STREAMS")) : 0;
-    const int streams_mask = serial ? 0 : (streams_env & 3);
+    static const int streams_env = std::getenv("FASTSVC_STREAMS") ? std::atoi(std::getenv("FASTSVC_STREAMS")) : -1;
+    int64_t hop_all = 1;
+    for (int i = 0; i < plan->n; ++i) hop_all *= plan->cfg.upsampling_scales[i];
+    int streams_mask = serial ? 0 : streams_env >= 0 ? (streams_env & 3) : ((int64_t)B * F * hop_all >= 150000 ? 2 : 0);
     // per-launch profiling and autotuning run on ONE stream so that every kernel is timed alone
     ExecCtx* ctx = (streams_mask == 0 || g_tune.tuning || prof) ? nullptr : exec_ctx_for(stream);
+    if (ctx && streams_env < 0 && !ctx->pays) { ctx = nullptr; streams_mask = 0; }
     std::unique_lock<std::mutex> ctx_lock;
     if (ctx) ctx_lock = std::unique_lock<std::mutex>(ctx->busy);
     hipStream_t s_film = (ctx && (streams_mask & 2)) ? ctx->aux[0] : stream;      // FiLM nets of stages 0..n-2
