@@ -1797,8 +1797,10 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (L.pipe == 2) {
             const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
             const int kind = aff ? 4 : p.r1x ? 3 : p.res ? 2 : 1;
-            std::snprintf(kname, sizeof(kname), "conv_hx<%d,%d,%d,%d,%d,%d,%d,%s>", L.MW, L.NW, L.WM, L.WN, p.mode,
-                          p.mode == MODE_DEC2 ? 1 : poly ? (aff ? 4 : 1) : kind, poly ? p.s : 1, act_bf16 ? "x1" : "x3");
+            const bool tail_inst = p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0);      // the row-end (TAILK) instance
+            std::snprintf(kname, sizeof(kname), "conv_hx<%d,%d,%d,%d,%d,%d,%d,%s%s>", L.MW, L.NW, L.WM, L.WN, p.mode,
+                          p.mode == MODE_DEC2 ? 1 : poly ? (aff ? 4 : 1) : kind, poly ? p.s : 1, act_bf16 ? "x1" : "x3",
+                          tail_inst ? ",tail" : "");
         } else if (L.pipe)
         {
             // same rule as launch_conv_pipe: compile-time epilogue kind of the 3-tap DIRECT / STRETCH launches
