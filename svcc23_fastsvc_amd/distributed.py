@@ -30,6 +30,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 
@@ -204,6 +205,20 @@ class _Stager:
         self.pin_free: List[Optional[torch.cuda.Event]] = [None, None]
         self.turn = 0
 
+    @staticmethod
+    def _fill(jobs) -> None:
+        """Rows into the page-locked batch, zero padded.  Through numpy views: one host thread moves 12-14 GB/s that way
+        (plain row memcpys), where `Tensor.copy_` into the strided destination managed 2 GB/s (its 128-thread iterator
+        costs more than it brings at 1 MB per row) and a thread pool on top of either was erratic - a pass over the
+        512 utterances of 2 - 10 s stages 874 MB: 615 ms then, against 125 ms of GPU work (tools/ragged_check.py)."""
+        for dst, src in jobs:
+            d = dst.numpy()
+            a = src.numpy() if isinstance(src, torch.Tensor) else np.asarray(src)
+            n = a.shape[-1]
+            d[..., :n] = a
+            if n < d.shape[-1]:
+                d[..., n:] = 0
+
     def _host_buffer(self, slot: int, key: str, shape, dtype) -> torch.Tensor:
         need = 1
         for s in shape:
@@ -246,15 +261,14 @@ class _Stager:
         if self.pin_free[slot] is not None:
             self.pin_free[slot].synchronize()                      # the copy that last read this set is done
         host = {}
+        jobs = []
         for key, width in keys:
             t0 = torch.as_tensor(first[key])
             hb = self._host_buffer(slot, key, (len(chunk), t0.shape[0], width), t0.dtype)
             for j, i in enumerate(chunk):
-                t = torch.as_tensor(self.utts[i][key])
-                hb[j, :, : t.shape[-1]] = t
-                if t.shape[-1] < width:
-                    hb[j, :, t.shape[-1]:] = 0
+                jobs.append((hb[j], torch.as_tensor(self.utts[i][key])))
             host[key] = hb
+        self._fill(jobs)
         if has_emb:
             e0 = torch.as_tensor(first["spk_emb"])
             hb = self._host_buffer(slot, "spk_emb", (len(chunk), e0.shape[0]), e0.dtype)

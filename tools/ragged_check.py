@@ -127,4 +127,17 @@ print("phases, device-synchronised between them (ms):", one_pass(True))
 t0 = time.perf_counter()
 h = one_pass(False)
 print("asynchronous pass: host time per phase (ms)", h, "total %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+# ---- the same pass with HOST-resident utterances (what a decode harness reading h5 features has): the stager fills
+# page-locked buffers and uploads one batch ahead of the compute stream ----
+if os.environ.get("RAGGED_HOST", "1") != "0":
+    host_utts = [{k: v.cpu() for k, v in u.items()} for u in utts]
+    torch.cuda.synchronize()
+    t_host = timed(lambda: D.run_utterance_parallel(fwd, host_utts, dev, max_batch=64, n_frames=frames, hop=cfg.hop, forward_into=True, ragged=True))
+    print(f"whole pass, utterances in HOST memory (pinned staging + upload overlapped with compute): {t_host:.1f} ms")
+    st2 = D._Stager(host_utts, dev, cfg.hop)
+    t0 = time.perf_counter()
+    for chunk in mine:
+        st2.stage(chunk, max(frames[i] for i in chunk))
+    torch.cuda.synchronize()
+    print(f"   staging alone (host copies into pinned buffers + H2D): {(time.perf_counter() - t0) * 1e3:.1f} ms for {sum(frames) * (cfg.in_channels + 2 * cfg.hop) * 4 / 1e6:.0f} MB")
 dist.destroy_process_group()
