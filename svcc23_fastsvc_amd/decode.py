@@ -90,6 +90,21 @@ def load_features(path: str) -> Dict[str, np.ndarray]:
     raise ValueError(f"unsupported feature container: {path}")
 
 
+class _PinnedSet:
+    """One batch worth of page-locked staging (inputs up, waveforms down), grown on demand and reused."""
+
+    def __init__(self):
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, key: str, shape) -> torch.Tensor:
+        need = int(np.prod(shape))
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(max(need, 1), dtype=torch.float32, pin_memory=True)
+            self.bufs[key] = buf
+        return buf[:need].view(*shape)
+
+
 @torch.no_grad()
 def decode_utterances(model, feats: Sequence[Dict[str, np.ndarray]], signal_generator, device,
                       trg_emb=None, src_f0_stats: Optional[Sequence[Sequence[float]]] = None,
@@ -103,35 +118,99 @@ def decode_utterances(model, feats: Sequence[Dict[str, np.ndarray]], signal_gene
     trg_emb           target-speaker embedding (E,) / (1,E), or None
     src_f0_stats      per utterance [mean, std] of its SOURCE speaker's log F0, or None for no shift
     trg_f0_stats      [mean, std] of the target speaker (the reference forces both stds to 1)
-    """
+
+    A three-stage pipeline over the length-bucketed batches, so that the GPU is the only thing the pass waits for:
+    while batch k computes, the host assembles batch k+1 in page-locked memory (numpy row copies, F0 shift) and
+    uploads it on a copy stream, and takes batch k-1's waveforms out of the page-locked buffer they were downloaded
+    to.  Two staging sets each way; one at a time it was host-bound 5:1 (tools/decode_throughput.py)."""
     hop = signal_generator.hop_size
     frames = [int(np.asarray(u["ppg"]).shape[0]) for u in feats]
     out: List[Optional[np.ndarray]] = [None] * len(feats)
+    if not feats:
+        return []
+    device = torch.device(device)
     emb_row = None
     if trg_emb is not None:
         emb_row = torch.as_tensor(np.asarray(trg_emb), dtype=torch.float32).reshape(1, -1).to(device)
-    for chunk in bucket_ragged(range(len(feats)), frames, max_batch, pad_tolerance):
-        fmax = frames[chunk[0]]
-        B = len(chunk)
+    batches = list(bucket_ragged(range(len(feats)), frames, max_batch, pad_tolerance))
+    cuda = device.type == "cuda"
+    up_sets, down_sets = [_PinnedSet(), _PinnedSet()], [_PinnedSet(), _PinnedSet()]
+    copy_stream = torch.cuda.Stream(device) if cuda else None
+    up_free = [None, None]                    # event: the upload that last read this input set is done
+    staged = {}
+
+    def stage(k: int) -> None:
+        chunk = batches[k]
+        fmax, B = frames[chunk[0]], len(chunk)
         C = int(np.asarray(feats[chunk[0]]["ppg"]).shape[1])
-        ppg = torch.zeros((B, C, fmax), dtype=torch.float32)
-        f0 = torch.zeros((B, 1, fmax), dtype=torch.float32)
-        lft = torch.zeros((B, 1, fmax * hop), dtype=torch.float32)
+        slot = k & 1
+        if cuda and up_free[slot] is not None:
+            up_free[slot].synchronize()
+        shapes = {"ppg": (B, C, fmax), "f0": (B, 1, fmax), "lft": (B, 1, fmax * hop)}
+        if cuda:
+            host = {key: up_sets[slot].get(key, shp) for key, shp in shapes.items()}
+        else:
+            host = {key: torch.empty(shp, dtype=torch.float32) for key, shp in shapes.items()}
+        hp, hf, hl = (host[key].numpy() for key in ("ppg", "f0", "lft"))
         for j, i in enumerate(chunk):
             u, n = feats[i], frames[i]
-            ppg[j, :, :n] = torch.as_tensor(np.asarray(u["ppg"], dtype=np.float32)).T
+            hp[j, :, :n] = np.asarray(u["ppg"], dtype=np.float32).T
+            hp[j, :, n:] = 0
             f = np.asarray(u["f0"], dtype=np.float64).reshape(-1)
             if src_f0_stats is not None and trg_f0_stats is not None:
                 f = F0Statistics().convert(f, src_f0_stats[i], trg_f0_stats)
-            f0[j, 0, :n] = torch.as_tensor(f.astype(np.float32))
-            lft[j, 0, : n * hop] = torch.as_tensor(np.asarray(u["lft"], dtype=np.float32)).reshape(-1)[: n * hop]
-        ppg, f0, lft = ppg.to(device), f0.to(device), lft.to(device)
+            hf[j, 0, :n] = f
+            hf[j, 0, n:] = 0
+            hl[j, 0, : n * hop] = np.asarray(u["lft"], dtype=np.float32).reshape(-1)[: n * hop]
+            hl[j, 0, n * hop:] = 0
+        if not cuda:
+            staged[k] = (host["ppg"], host["f0"], host["lft"], None)
+            return
+        compute = torch.cuda.current_stream(device)
+        with torch.cuda.stream(copy_stream):
+            dev = {key: host[key].to(device, non_blocking=True) for key in shapes}
+            ready = torch.cuda.Event()
+            ready.record(copy_stream)
+        for t in dev.values():
+            t.record_stream(compute)            # allocated on the copy stream's pool, consumed on the compute stream
+        up_free[slot] = ready
+        staged[k] = (dev["ppg"], dev["f0"], dev["lft"], ready)
+
+    pending = {}
+
+    def compute(k: int) -> None:
+        chunk = batches[k]
+        ppg, f0, lft, ready = staged.pop(k)
+        if ready is not None:
+            torch.cuda.current_stream(device).wait_event(ready)
         sine = signal_generator(f0)
-        emb = None if emb_row is None else emb_row.expand(B, -1).contiguous()
-        y = model(ppg, sine, lft, emb, lengths=[frames[i] for i in chunk])
-        y = y.to("cpu", torch.float32).numpy()
-        for j, i in enumerate(chunk):
+        emb = None if emb_row is None else emb_row.expand(len(chunk), -1).contiguous()
+        y = model(ppg, sine, lft, emb, lengths=[frames[i] for i in chunk]).to(torch.float32)
+        if cuda:
+            host_y = down_sets[k & 1].get("y", tuple(y.shape))
+            host_y.copy_(y, non_blocking=True)          # download queued behind the forward on the compute stream
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(device))
+            pending[k] = (host_y, done)
+        else:
+            pending[k] = (y, None)
+
+    def finish(k: int) -> None:
+        host_y, done = pending.pop(k)
+        if done is not None:
+            done.synchronize()
+        y = host_y.numpy()
+        for j, i in enumerate(batches[k]):
             out[i] = y[j].reshape(-1)[: frames[i] * hop].copy()
+
+    stage(0)
+    for k in range(len(batches)):
+        compute(k)                               # asynchronous: the host goes on while the GPU runs batch k
+        if k + 1 < len(batches):
+            stage(k + 1)
+        if k >= 1:
+            finish(k - 1)                        # (before compute(k + 1) reuses that download set)
+    finish(len(batches) - 1)
     return out  # type: ignore[return-value]
 
 

@@ -617,6 +617,33 @@ def test_batched_decode_equals_the_reference_decode_loop(dev):
     assert all(p.dtype == np.int16 and len(p) == f * cfg.hop for p, f in zip(pcm, frames))
 
 
+def test_pipelined_decode_is_batching_invariant(dev):
+    """The harness overlaps staging, upload, compute and download across batches with two page-locked sets each
+    way: many small batches (every set reused several times), a few large ones and one utterance at a time must give
+    the same waveforms - slot reuse before a copy has finished would show up here."""
+    from svcc23_fastsvc_amd import decode as Dc
+    cfg = S.FULL_CONFIG
+    frames = [31, 7, 25, 26, 18, 40, 12, 33, 9, 21, 38]
+    rng = np.random.default_rng(11)
+    feats = []
+    for f in frames:
+        f0 = np.where(rng.random((f, 1)) < 0.3, 0.0, rng.uniform(80, 400, (f, 1)))
+        feats.append(dict(f0=f0, ppg=rng.standard_normal((f, cfg.in_channels)).astype(np.float32),
+                          lft=rng.uniform(-9, 1, (f * cfg.hop, 1)).astype(np.float32)))
+    m = _module(cfg, S.synth_state_dict(cfg, 12), dev, fold=True)
+    sg = A.SignalGenerator(sample_rate=24000, hop_size=cfg.hop, sine_amp=0.1, noise_amp=0.0, signal_types=["sine"])
+    emb = rng.standard_normal(cfg.spk_emb_size).astype(np.float32)
+    kw = dict(trg_emb=emb, src_f0_stats=[[5.0, 1.0]] * len(feats), trg_f0_stats=[5.2, 1.0])
+    alone = [Dc.decode_utterances(m, [u], sg, dev, trg_emb=emb, src_f0_stats=[[5.0, 1.0]], trg_f0_stats=[5.2, 1.0])[0] for u in feats]
+    for max_batch, tol in ((2, 0.125), (3, 0.9), (16, 0.9)):
+        for _ in range(2):                                   # (a second pass reuses warm buffers)
+            ys = Dc.decode_utterances(m, feats, sg, dev, max_batch=max_batch, pad_tolerance=tol, **kw)
+            for i, (y, a) in enumerate(zip(ys, alone)):
+                assert y.shape == a.shape == (frames[i] * cfg.hop,)
+                assert float(np.abs(y - a).max()) <= 2e-5, (max_batch, i)
+    assert Dc.decode_utterances(m, [], sg, dev) == []
+
+
 def test_bfloat16_activation_storage_mode(dev):
     """BASELINE config 3's dtype: workspace tensors stored as bfloat16 and the convolutions multiplied on
     the bf16 MFMA (bf16-rounded activations AND weights, f32 accumulation; InstanceNorm statistics in
