@@ -102,14 +102,14 @@ def test_utterance_parallel_path_on_the_nccl_backend(dev):
         blob = D.broadcast_packed_weights(g, dev, src=0)
         assert blob.is_cuda and blob.numel() * 4 == g.plan.blob_bytes
         utts = []
-        for i, F in enumerate([40, 48, 44, 40, 48, 44, 40, 36, 48, 40, 44]):
+        for i, F in enumerate([40, 48, 45, 40, 47, 44, 41, 36, 48, 37, 44]):        # (odd lengths too: padded to 4 frames, run ragged)
             b = S.synth_batch(cfg, 1, F, 300 + i)
             utts.append(dict(ppg=torch.from_numpy(b.ppg[0]), sine=torch.from_numpy(b.sine[0]),
                              lft=torch.from_numpy(b.lft[0]), spk_emb=torch.from_numpy(b.spk_emb[0])))
         plan = g.plan
 
-        def fwd(ppg, sine, lft, emb, lengths=None):
-            return plan.forward(blob, ppg, sine, lft, emb, lengths=lengths)
+        def fwd(ppg, sine, lft, emb, lengths=None, out=None):
+            return plan.forward(blob, ppg, sine, lft, emb, lengths=lengths, out=out)
 
         with torch.no_grad():
             ys = D.run_utterance_parallel(fwd, utts, dev, max_batch=3)
@@ -117,10 +117,14 @@ def test_utterance_parallel_path_on_the_nccl_backend(dev):
             # device-resident utterances take the in-place stacking route
             utts_dev = [{k: v.to(dev) for k, v in u.items()} for u in utts]
             yd = D.run_utterance_parallel(fwd, utts_dev, dev, max_batch=64)
+            # ... and, ragged, the batch-assembly kernel (fastsvc_gather_padded), the forward writing straight into
+            # the gather's send buffer
+            ydr = D.run_utterance_parallel(fwd, utts_dev, dev, max_batch=4, ragged=True, pad_tolerance=0.3, forward_into=True)
+            yhr = D.run_utterance_parallel(fwd, utts, dev, max_batch=5, ragged=True, pad_tolerance=0.3, forward_into=True)
             for i, u in enumerate(utts):
                 alone = plan.forward(blob, u["ppg"][None].to(dev), u["sine"][None].to(dev), u["lft"][None].to(dev),
                                      u["spk_emb"][None].to(dev))[0]
-                for got in (ys[i], yr[i], yd[i]):
+                for got in (ys[i], yr[i], yd[i], ydr[i], yhr[i]):
                     assert got.is_cuda and tuple(got.shape) == tuple(alone.shape)
                     assert float((got - alone).abs().max()) <= 2e-5
         # ad-hoc gather on the GPU backend with an EMPTY local list (used to pick a CPU tensor)
