@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -19,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <atomic>
 #include <string>
 #include <unordered_map>
@@ -210,6 +212,7 @@ struct fastsvc_plan {
     // Off-table shapes: the (NW, WM, WN, algorithm) of the table entry of the SAME layer whose problem size is
     // nearest (cached per key; algo < 0 = the table has nothing for the layer); cleared whenever `tuned` changes.
     mutable std::map<std::string, Choice> priors;
+    mutable std::vector<double> pack_cost;      // per pack job: what the last fastsvc_pack_weights measured (longest first next time)
 
     // |ln work ratio| + a quarter of |ln row-length ratio|: what a launch shape trades off (workgroups against tiles
     // per workgroup against columns per tile) depends on B * T first and on the row length second
@@ -562,7 +565,21 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         sd[tensors[i].name] = &tensors[i];
     }
     float* blob = static_cast<float*>(host_blob);
-    std::memset(blob, 0, plan->blob_floats * sizeof(float));
+    {
+        // zero the blob (padding granules, absent formats) - in parallel: one thread takes 3-4 ms for the 54 MB, a
+        // third of what the whole pack takes on 16 threads
+        const size_t bytes = plan->blob_floats * sizeof(float);
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nz = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, bytes >> 22));
+        std::vector<std::thread> zs;
+        auto zero = [&](unsigned k) {
+            const size_t a = (bytes / nz * k) & ~(size_t)63, b = k + 1 == nz ? bytes : (bytes / nz * (k + 1)) & ~(size_t)63;
+            std::memset(reinterpret_cast<char*>(blob) + a, 0, b - a);
+        };
+        for (unsigned k = 1; k < nz; ++k) zs.emplace_back(zero, k);
+        zero(0);
+        for (auto& th : zs) th.join();
+    }
 
     // split-half / bf16 fragments (fastsvc_hx.hip): lane l of fragment (group, chunk, slot, tile m) holds
     // Wt[co = (group*MW + m)*16 + (l & 15)][ci = chunk*32 + 8*(l >> 4) + e][slot], e = 0..7
@@ -571,20 +588,25 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
     // weight within 2^-17 of that maximum whatever the channel's absolute scale (weight_g) is; the inverse factors go
     // to inv[table * n16 + co] (ConvParams::whx_inv; the epilogue's bias FMA applies them).  `table_of(ci, slot)`
     // says which output a fragment feeds (MODE_DEC2: slot 3 = the 1x1 conv; fused pair: the second conv's units).
-    auto pack_hx = [&](const PackedConv& c, const size_t (&off)[2], int nslots,
-                       const std::function<float(int, int, int)>& wt, size_t inv_off = 0, int ntables = 1,
-                       const std::function<int(int, int)>& table_of = nullptr) {
+    // (generic over the accessors: through std::function the per-element calls made this the longest part of a pack)
+    struct OneTable { int operator()(int, int) const { return 0; } };
+    auto pack_hx = [&](const PackedConv& c, const size_t (&off)[2], int nslots, auto&& wt, size_t inv_off, int ntables,
+                       auto&& table_of_, int precs = 3 /* bit 0: binary16 pieces (+ the scale tables), bit 1: bfloat16 */,
+                       int gpart = 0, int gparts = 1 /* this call's share of the channel groups */) {
+        const int g0 = c.ngroups * gpart / gparts, g1 = c.ngroups * (gpart + 1) / gparts;
+        constexpr bool has_tables = !std::is_same<std::decay_t<decltype(table_of_)>, OneTable>::value;
+        auto table_of = [&](int ci, int slot) -> int { return table_of_(ci, slot); };
         const int n16 = c.ngroups * 16 * c.MW;
         std::vector<int> ex((size_t)ntables * n16, 0);
-        if (inv_off) {
+        if (inv_off && (precs & 1)) {
             float* inv = blob + inv_off;
             for (int t = 0; t < ntables; ++t)
-                for (int co = 0; co < n16; ++co) {
+                for (int co = g0 * 16 * c.MW; co < g1 * 16 * c.MW; ++co) {
                     float m = 0.f;
                     if (co < c.cout)
                         for (int ci = 0; ci < c.cin; ++ci)
                             for (int slot = 0; slot < nslots; ++slot)
-                                if (!table_of || table_of(ci, slot) == t) m = std::max(m, std::fabs(wt(co, ci, slot)));
+                                if (!has_tables || table_of(ci, slot) == t) m = std::max(m, std::fabs((float)wt(co, ci, slot)));
                     int e = 0;
                     if (m > 0.f && std::isfinite(m)) e = std::min(60, std::max(-60, 14 - std::ilogb(m)));
                     ex[(size_t)t * n16 + co] = e;
@@ -592,10 +614,10 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                 }
         }
         for (int prec = 0; prec < 2; ++prec) {
-            if (!off[prec]) continue;                        // (a fragment set that exists for one storage type only)
+            if (!off[prec] || !(precs & (1 << prec))) continue;   // (a fragment set that exists for one storage type only)
             const int np = prec == 0 ? 2 : 1;
             uint16_t* hp = reinterpret_cast<uint16_t*>(blob + off[prec]);
-            for (int grp = 0; grp < c.ngroups; ++grp)
+            for (int grp = g0; grp < g1; ++grp)
                 for (int ch = 0; ch < c.nch32; ++ch)
                     for (int slot = 0; slot < nslots; ++slot)
                         for (int m = 0; m < c.MW; ++m) {
@@ -604,9 +626,9 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                                 for (int e = 0; e < 8; ++e) {
                                     const int co = (grp * c.MW + m) * 16 + (lane & 15);
                                     const int ci = ch * 32 + 8 * (lane >> 4) + e;
-                                    float v = (co < c.cout && ci < c.cin) ? wt(co, ci, slot) : 0.f;
+                                    float v = (co < c.cout && ci < c.cin) ? (float)wt(co, ci, slot) : 0.f;
                                     if (prec == 0) {
-                                        if (inv_off) v = std::ldexp(v, ex[(size_t)(table_of ? table_of(ci, slot) : 0) * n16 + co]);
+                                        if (inv_off) v = std::ldexp(v, ex[(size_t)(has_tables ? table_of(ci, slot) : 0) * n16 + co]);
                                         const uint16_t hi = f32_to_f16(v);
                                         frag[lane * 8 + e] = hi;
                                         frag[512 + lane * 8 + e] = f32_to_f16(v - f16_to_f32(hi));
@@ -618,13 +640,27 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         }
     };
     // Every job writes its own region of the blob: they run on a small thread pool (the fold + pack of the whole
-    // generator is ~120 ms single-threaded - paid by every training step, whose optimizer update invalidates the
-    // packed copy - and ~15 ms on 16 cores).  The first failing job's code and message are reported.
+    // generator is ~55 ms of single-thread work - paid by every training step, whose optimizer update invalidates the
+    // packed copy - and ~7 ms on the pool: 11-13 ms before the big layers' jobs were cut up, ordered longest first
+    // and given inlined accessors).  The first failing job's code and message are reported.
     std::vector<std::function<int()>> tasks;
-    for (const auto& job_ : plan->pack_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
+    std::vector<std::string> task_names;                 // (FASTSVC_PACK_DEBUG)
+    // A conv's formats (f32 fragments, split-binary16 / bf16 fragments, Winograd, polyphase) are independent regions
+    // of the blob: the big layers' jobs are cut into parts that each build the dense matrix and write a subset of the
+    // formats - the 2C -> 2C FiLM heads of the C = 192 stage alone took 7.9 ms of a 11 ms pack as one job
+    for (const auto& job_ : plan->pack_jobs) {
+      const size_t wcount = (size_t)job_.first->cout * job_.first->cin * job_.first->ntaps;
+      const int nparts = job_.second.dec2 ? 1 : wcount > 300000 ? 6 : wcount > 60000 ? 2 : 1;
+      for (int part = 0; part < nparts; ++part) {
+      task_names.push_back(job_.second.pieces.empty() ? std::string("conv") : job_.second.pieces[0].layer + (nparts > 1 ? "#" + std::to_string(part) : ""));
+      tasks.emplace_back([&, pj = &job_, part, nparts]() -> int {
         const auto& job = *pj;
         const PackedConv& c = *job.first;
         const PackSource& src = job.second;
+        // sections: 0 / 1 binary16 pieces of the first / second half of the channel groups, 2 bfloat16 pieces,
+        // 3 f32 fragments + bias + bounds, 4 Winograd, 5 Winograd (32-channel grouping), 6 / 7 polyphase pieces / fragments
+        static const int to2[8] = {0, 0, 1, 1, 0, 1, 0, 1}, to6[8] = {0, 1, 2, 3, 4, 5, 4, 5};
+        auto mine = [&](int section) { return (nparts == 1 ? 0 : nparts == 2 ? to2[section] : to6[section]) == part; };
         if (src.dec2) {
             // MODE_DEC2: components w0 w1 w2 (k=3 conv) | w1x1, step order inside a chunk
             // (half * 4 + component) * 3 + k-group-in-half (mfma_unit_dec2)
@@ -698,9 +734,13 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                             }
                         }
         };
-        pack_fragments(W, blob + c.w_off, c.ntaps);
-        if (c.hx) pack_hx(c, c.hx_off, 3, [&](int co, int ci, int tap) { return W[((size_t)co * c.cin + ci) * 3 + tap]; }, c.hx_inv_off);
-        if (c.wino) {
+        if (mine(3)) pack_fragments(W, blob + c.w_off, c.ntaps);
+        auto wt3 = [&](int co, int ci, int tap) { return W[((size_t)co * c.cin + ci) * 3 + tap]; };
+        if (c.hx && mine(0) && mine(1)) pack_hx(c, c.hx_off, 3, wt3, c.hx_inv_off, 1, OneTable{}, 1);
+        else if (c.hx && mine(0)) pack_hx(c, c.hx_off, 3, wt3, c.hx_inv_off, 1, OneTable{}, 1, 0, 2);
+        else if (c.hx && mine(1)) pack_hx(c, c.hx_off, 3, wt3, c.hx_inv_off, 1, OneTable{}, 1, 1, 2);
+        if (c.hx && mine(2)) pack_hx(c, c.hx_off, 3, wt3, c.hx_inv_off, 1, OneTable{}, 2);
+        if (c.wino && (mine(4) || mine(5))) {
             // Winograd F(2,3) weight transform G w (fastsvc_kernels.h, MODE_WINO), in f64
             std::vector<float> Ww((size_t)c.cout * c.cin * 4);
             for (size_t i = 0; i < (size_t)c.cout * c.cin; ++i) {
@@ -730,10 +770,10 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                                     }
                                 }
             };
-            pack_wino(blob + c.ww_off, c.MW);
-            if (c.wino2) pack_wino(blob + c.ww2_off, 2);
+            if (mine(4)) pack_wino(blob + c.ww_off, c.MW);
+            if (c.wino2 && mine(5)) pack_wino(blob + c.ww2_off, 2);
         }
-        if (c.poly) {
+        if (c.poly && (mine(6) || mine(7))) {
             // polyphase taps (fastsvc_kernels.h, MODE_POLY): slot 0 = W0, slot 1 = W0+W1+W2, slot 2 = W2
             std::vector<float> Wp(W.size());
             for (size_t i = 0; i + 2 < W.size(); i += 3) {
@@ -741,12 +781,12 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
                 Wp[i + 1] = (float)((double)W[i] + (double)W[i + 1] + (double)W[i + 2]);
                 Wp[i + 2] = W[i + 2];
             }
-            pack_fragments(Wp, blob + c.wp_off, c.ntaps);
-            if (c.hx) pack_hx(c, c.hxp_off, 3, [&](int co, int ci, int tap) { return Wp[((size_t)co * c.cin + ci) * 3 + tap]; }, c.hxp_inv_off);
+            if (mine(7)) pack_fragments(Wp, blob + c.wp_off, c.ntaps);
+            if (c.hx && mine(6)) pack_hx(c, c.hxp_off, 3, [&](int co, int ci, int tap) { return Wp[((size_t)co * c.cin + ci) * 3 + tap]; }, c.hxp_inv_off, 1, OneTable{});
         }
         float* bp = blob + c.b_off;
-        for (int co = 0; co < c.cout; ++co) bp[co] = bias[co];
-        {
+        if (mine(3)) for (int co = 0; co < c.cout; ++co) bp[co] = bias[co];
+        if (mine(3)) {
             float l1 = 0.f, bmax = 0.f;
             const size_t per = (size_t)c.cin * c.ntaps;
             for (int co = 0; co < c.cout; ++co) {
@@ -758,7 +798,10 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             blob[c.bnd_off] = l1; blob[c.bnd_off + 1] = bmax;
         }
         return FASTSVC_OK;
-    });
+      });
+      }
+    }
+    task_names.insert(task_names.end(), plan->chain_jobs.size(), "chain");
     for (const auto& job_ : plan->chain_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
         const auto& job = *pj;
         const PackedConv& c = *job.c;                       // second conv; the first maps cout -> cin of it (square)
@@ -799,6 +842,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         }
         return FASTSVC_OK;
     });
+    task_names.insert(task_names.end(), plan->film_chain_jobs.size(), "film_chain");
     for (const auto& job_ : plan->film_chain_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
         const auto& job = *pj;
         const PackedConv& c = *job.c;
@@ -845,6 +889,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         cst[0] = l1; cst[1] = bmax; cst[2] = 0.f; cst[3] = 0.f;
         return FASTSVC_OK;
     });
+    task_names.insert(task_names.end(), plan->up_head_jobs.size(), "up_head");
     for (const auto& job_ : plan->up_head_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
         const auto& job = *pj;
         const PackedConv& c = *job.c;
@@ -883,6 +928,7 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         cst[0] = l1; cst[1] = bmax; cst[2] = 0.f; cst[3] = 0.f;
         return FASTSVC_OK;
     });
+    task_names.insert(task_names.end(), plan->raw_jobs.size(), "raw");
     for (const RawParam* r_ : plan->raw_jobs) tasks.emplace_back([&, r = r_]() -> int {
         HostLayer L;
         const int cout = (int)r->b_floats;
@@ -904,15 +950,31 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
         return FASTSVC_OK;
     });
     static const int env_threads = std::getenv("FASTSVC_PACK_THREADS") ? std::atoi(std::getenv("FASTSVC_PACK_THREADS")) : 0;
-    unsigned nthreads = env_threads > 0 ? (unsigned)env_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned nthreads = env_threads > 0 ? (unsigned)env_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     nthreads = (unsigned)std::min<size_t>(nthreads, tasks.size());
     std::atomic<size_t> next{0};
     std::atomic<int> first_rc{FASTSVC_OK};
     std::mutex err_mu;
     std::string err_msg;
+    static const bool pack_debug = std::getenv("FASTSVC_PACK_DEBUG") != nullptr;
+    // Longest job first: the jobs differ 20:1 (the 2C -> 2C FiLM heads and block-diagonal chains of the C = 192 stage
+    // against a 1 x 1 conv), the queue is dynamic, and a long job that starts last IS the makespan.  The order comes
+    // from the durations the previous pack of this plan measured (a training step packs after every optimizer
+    // update); the first pack runs in declaration order.
+    std::vector<double> task_ms(tasks.size(), 0.0);
+    std::vector<size_t> order(tasks.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    {
+        std::lock_guard<std::mutex> lock(plan->tune_mu);
+        if (plan->pack_cost.size() == tasks.size())
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return plan->pack_cost[a] > plan->pack_cost[b]; });
+    }
     auto worker = [&]() {
-        for (size_t i = next.fetch_add(1); i < tasks.size(); i = next.fetch_add(1)) {
+        for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
+            const size_t i = order[k];
+            const auto t0 = std::chrono::steady_clock::now();
             const int rc = tasks[i]();
+            task_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (rc != FASTSVC_OK) {
                 std::lock_guard<std::mutex> lock(err_mu);
                 if (first_rc.load() == FASTSVC_OK) { first_rc = rc; err_msg = g_err; }     // g_err: this thread's message
@@ -923,6 +985,21 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
     for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
     worker();
     for (auto& th : pool) th.join();
+    {
+        std::lock_guard<std::mutex> lock(plan->tune_mu);
+        plan->pack_cost = task_ms;
+    }
+    if (pack_debug) {
+        double sum = 0.0, mx = 0.0;
+        for (double v : task_ms) { sum += v; mx = std::max(mx, v); }
+        std::vector<size_t> top(task_ms.size());
+        for (size_t i = 0; i < top.size(); ++i) top[i] = i;
+        std::sort(top.begin(), top.end(), [&](size_t a, size_t b) { return task_ms[a] > task_ms[b]; });
+        std::fprintf(stderr, "[fastsvc] pack: %zu tasks on %u threads, sum %.1f ms, longest %.1f ms, top:", tasks.size(), nthreads, sum, mx);
+        for (size_t i = 0; i < std::min<size_t>(8, top.size()); ++i)
+            std::fprintf(stderr, " %s %.1f", top[i] < task_names.size() ? task_names[top[i]].c_str() : "?", task_ms[top[i]]);
+        std::fprintf(stderr, "\n");
+    }
     if (first_rc.load() != FASTSVC_OK) return fail(first_rc.load(), err_msg);
     return FASTSVC_OK;
 }
