@@ -278,13 +278,17 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
     return res
 
 
-def run_cfg4_single_gpu(cfg, dev, steps=3, warmup=1):
+def run_cfg4_single_gpu(cfg, dev, steps=3, warmup=1, name="cfg4"):
     """BASELINE config 4's single-GPU leg: the 512 x 10 s set through `run_utterance_parallel` (the multi-GPU code
-    path) on a 1-rank RCCL group, inputs resident in HBM, waveforms gathered into the result list."""
+    path) on a 1-rank RCCL group, inputs resident in HBM, waveforms gathered into the result list.
+    name="cfg4var": SURVEY 8(d)'s variable-length variant (2 - 10 s, ragged length-bucketed batches; `value` counts
+    real samples only)."""
     import torch.distributed as dist1
     from svcc23_fastsvc_amd import distributed as D
-    wl = S.WORKLOADS["cfg4"]
+    wl = S.WORKLOADS[name]
     n_utts, F = wl["B"], wl["F"]
+    frames = S.workload_frames(name)
+    ragged = name == "cfg4var"
     T = F * cfg.hop
     own_group = not dist1.is_initialized()
     if own_group:
@@ -297,19 +301,24 @@ def run_cfg4_single_gpu(cfg, dev, steps=3, warmup=1):
         utts = []
         for c0 in range(0, n_utts, 64):
             ppg, sine, lft, emb = S.device_batch(cfg, 64, F, wl["seed"] + c0, dev)
-            utts += [dict(ppg=ppg[j], sine=sine[j], lft=lft[j], spk_emb=emb[j]) for j in range(64)]
+            utts += [dict(ppg=ppg[j, :, : frames[c0 + j]], sine=sine[j, :, : frames[c0 + j] * cfg.hop],
+                          lft=lft[j, :, : frames[c0 + j] * cfg.hop], spk_emb=emb[j]) for j in range(64)]
         ws = torch.empty(plan.workspace_bytes(64, F), dtype=torch.uint8, device=dev)
 
-        def fwd(ppg, sine, lft, emb, out=None):
-            return plan.forward(blob, ppg, sine, lft, emb, workspace=ws, out=out)
+        if ragged:
+            def fwd(ppg, sine, lft, emb, lens, out=None):
+                return plan.forward(blob, ppg, sine, lft, emb, lengths=lens, workspace=ws, out=out)
+        else:
+            def fwd(ppg, sine, lft, emb, out=None):
+                return plan.forward(blob, ppg, sine, lft, emb, workspace=ws, out=out)
 
         def step(i):
-            D.run_utterance_parallel(fwd, utts, dev, max_batch=64, n_frames=[F] * n_utts, hop=cfg.hop, forward_into=True)
+            D.run_utterance_parallel(fwd, utts, dev, max_batch=64, n_frames=frames, hop=cfg.hop, forward_into=True, ragged=ragged)
 
         elapsed = time_steps(step, torch.cuda.synchronize, steps, warmup, None, dev)
         ms = elapsed / steps * 1e3
-        res = {"workload": f"cfg4: {wl['desc']} on ONE GPU (8 batches of 64 through run_utterance_parallel, 1-rank RCCL group)",
-               "ms_per_step": ms, "value": n_utts * T * steps / elapsed, "unit": "samples/s", "steps": steps, "warmup": warmup,
+        res = {"workload": f"{name}: {wl['desc']} on ONE GPU (batches of <= 64 through run_utterance_parallel, 1-rank RCCL group)",
+               "ms_per_step": ms, "value": float(sum(frames)) * cfg.hop * steps / elapsed, "unit": "samples/s", "steps": steps, "warmup": warmup,
                "dtype": plan.arithmetic, "data": "synthetic (generated on the device)"}
         del ws, utts, blob
         torch.cuda.empty_cache()
@@ -542,6 +551,7 @@ def main():
             for key, fn in (("cfg1_float32", lambda: run_single_gpu_workload(cfg, "cfg1", "float32", dev, steps=200, warmup=50,
                                                                                use_table=not args.no_table)),
                             ("cfg4_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev)),
+                            ("cfg4var_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev, name="cfg4var")),
                             ("off_table_shape", lambda: run_off_table_shape(cfg, dev))):
                 try:
                     secondary[key] = fn()
