@@ -49,7 +49,8 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
         merged[key] = n0 + fetch[k][1]
     # half-precision MFMA kernels: MW, NW, WM, WN, mode, epilogue kind, S (+ resident weights: merged); x3 = split
     # binary16 products (float32 storage), x1 = bf16 products (namespace fastsvc::bf16)
-    m = re.search(r"conv_hx_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", k)
+    # (round 3: a tenth argument marks the row-end instances of ragged batches - same traffic model, merged too)
+    m = re.search(r"conv_hx_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false)){0,2}>", k)
     if m:
         key = "conv_hx<%s,%s,%s,%s,%s,%s,%s," % m.groups() + ("x1>" if "bf16::" in k else "x3>")
         n0 = merged.get(key, 0)
