@@ -270,6 +270,20 @@ __device__ __forceinline__ void hx_unit_dec2(f32x4 (&acc)[2][NW][MW], const unsi
 }
 
 // convert / split 8 channel values of one time step into the tile's 16-byte slot(s)
+// Low pieces of a pair of staged values: lo = f16(e - (float)hi), ONE mixed-precision FMA each (binary16 source from
+// either half of the packed hi register, f32 addend, binary16 result into the low / high half of the destination).
+// e - hi is exact in float32, so the single rounding is the one the convert-back / subtract / convert sequence made:
+// bit-identical.  hipcc forms this instruction from the plain expression in a few instances only; in the hot ones it
+// emitted v_cvt_f32_f16 + v_sub / v_fma + v_cvt_pk_f16_f32 - 2.5 instructions per value where this is 1 - and the
+// staging waves are the critical path of every narrow layer.
+__device__ __forceinline__ unsigned hx_lo_pair(unsigned hi_pair, float e0, float e1) {
+    unsigned d;
+    const float minus1 = -1.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi_pair), "s"(minus1), "v"(e0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi_pair), "s"(minus1), "v"(e1));
+    return d;
+}
+
 __device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int lo_off, const float (&e)[8]) {
     // float32 storage: the staged values are pre-scaled so that |e| < 2^15 by construction (hx_scale_for of a
     // measured maximum, of a bound derived from one through the layers' l1 / bmax, or of the bound of a normalised
@@ -282,10 +296,12 @@ __device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int
     if constexpr (HX_NP == 2) {
         // low piece = f16(e - hi): written as an FMA on the binary16 value so that it maps onto the mixed-precision
         // FMA (f16 source, f32 source, f16 result) instead of convert-back, subtract, convert
-        hx8 l;
+        typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+        const u32x4w hp = __builtin_bit_cast(u32x4w, h);
+        u32x4w lp;
         #pragma unroll
-        for (int c = 0; c < 8; ++c) l[c] = (hx_t)__builtin_fmaf((float)h[c], -1.0f, e[c]);
-        *reinterpret_cast<hx8*>(tile + lo_off + off) = l;
+        for (int k = 0; k < 4; ++k) lp[k] = hx_lo_pair(hp[k], e[2 * k], e[2 * k + 1]);
+        *reinterpret_cast<u32x4w*>(tile + lo_off + off) = lp;
     }
 }
 
@@ -300,6 +316,7 @@ typedef hx_t hx4 __attribute__((ext_vector_type(4)));
 // intermediate tile's own scale (LeakyReLU commutes with a positive factor): v = acc * kinv + kb.  Read here, once
 // per tile, instead of living in 8 MW registers across the tile loop.
 // RAW_TOO (MODE_UPHEAD): the tile is also stored WITHOUT the LeakyReLU, `raw_bytes` further.
+typedef unsigned u32x2p __attribute__((ext_vector_type(2)));
 template <int MW, int NA, bool RAW_TOO = false>
 __device__ __forceinline__ void hx_chain_store(const f32x4 (&acc)[NA][MW], int ntl, unsigned char* T2, int chunk_bytes,
                                                int lo_off, int mg, int row0, int col0, int T, const float* smid,
@@ -323,16 +340,20 @@ __device__ __forceinline__ void hx_chain_store(const f32x4 (&acc)[NA][MW], int n
             if constexpr (RAW_TOO) {
                 const hx4 hr = __builtin_convertvector(v, hx4);
                 *reinterpret_cast<hx4*>(base + raw_bytes + n * 16 * HX_ROW) = hr;
-                if constexpr (HX_NP == 2)
-                    *reinterpret_cast<hx4*>(base + raw_bytes + lo_off + n * 16 * HX_ROW) = __builtin_convertvector(v - __builtin_convertvector(hr, f32x4), hx4);
+                if constexpr (HX_NP == 2) {
+                    const u32x2p hp = __builtin_bit_cast(u32x2p, hr);
+                    *reinterpret_cast<u32x2p*>(base + raw_bytes + lo_off + n * 16 * HX_ROW) =
+                        u32x2p{hx_lo_pair(hp.x, v.x, v.y), hx_lo_pair(hp.y, v.z, v.w)};
+                }
             }
             #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * LRELU_SLOPE);
             const hx4 h = __builtin_convertvector(v, hx4);
             *reinterpret_cast<hx4*>(base + n * 16 * HX_ROW) = h;
             if constexpr (HX_NP == 2) {
-                const f32x4 back = __builtin_convertvector(h, f32x4);
-                *reinterpret_cast<hx4*>(base + lo_off + n * 16 * HX_ROW) = __builtin_convertvector(v - back, hx4);
+                const u32x2p hp = __builtin_bit_cast(u32x2p, h);
+                *reinterpret_cast<u32x2p*>(base + lo_off + n * 16 * HX_ROW) =
+                    u32x2p{hx_lo_pair(hp.x, v.x, v.y), hx_lo_pair(hp.y, v.z, v.w)};
             }
         }
     }
@@ -970,7 +991,9 @@ void conv_hx_kernel(const ConvParams p0) {
                 #pragma unroll
                 for (int c = 0; c < 8; ++c) Bc[c] = tok ? Bc[c] : 0.f;
                 // one time step (= one 16-byte slot of 8 channels per piece) at a time: the transformed values
-                // never exist as a second copy of the register set
+                // never exist as a second copy of the register set (two steps at a time - the prologue FMA and the
+                // LeakyReLU multiply as packed float32 operations on (t, t+1) - saves 0.75 instructions per value and was
+                // measured SLOWER: cfg2 1.412 vs 1.388 ms)
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float e[8];
