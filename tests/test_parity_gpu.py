@@ -793,8 +793,9 @@ def test_ragged_batch_on_a_non_default_configuration(dev):
         assert float(y[j, :, n * hop:].abs().max() if n < F else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("width,storage", [("tiny", "float32"), ("full", "float32"), ("full", "bfloat16")])
-def test_ragged_batch_with_odd_lengths_equals_every_utterance_alone(dev, width, storage):
+@pytest.mark.parametrize("width,storage,spk", [("tiny", "float32", True), ("full", "float32", True), ("full", "bfloat16", True),
+                                               ("full", "float32", False), ("tiny", "float32", False)])
+def test_ragged_batch_with_odd_lengths_equals_every_utterance_alone(dev, width, storage, spk):
     """A padded batch with per-utterance lengths: utterance b is what it would be alone at lengths[b] frames, for
     lengths that are odd, = 2 mod 4 and multiples of 4 (rows at the frame rate and twice it then end inside a
     float4 - float32 storage runs them on the row-end instances of the split-binary16 kernels, narrow
@@ -811,12 +812,17 @@ def test_ragged_batch_with_odd_lengths_equals_every_utterance_alone(dev, width, 
         ppg[i, :, n:] = 1e3; sine[i, :, n * cfg.hop:] = -1e3; lft[i, :, n * cfg.hop:] = 1e3
     plan = A.Plan(cfg, storage=storage)
     blob = plan.pack(sd).to(dev)
+    emb = t(b.spk_emb) if spk else None
     ws = torch.empty(plan.workspace_bytes(B, Fp) // 4 * 4 + 4, dtype=torch.uint8, device=dev)
     ws[: ws.numel() // 4 * 4].view(torch.float32).fill_(1000.0)
-    y = plan.forward(blob, t(ppg), t(sine), t(lft), t(b.spk_emb), lengths=lens, workspace=ws).cpu().numpy()
+    y = plan.forward(blob, t(ppg), t(sine), t(lft), emb, lengths=lens, workspace=ws).cpu().numpy()
     ws.fill_(0xFF)                                      # and once more over NaN patterns
-    y2 = plan.forward(blob, t(ppg), t(sine), t(lft), t(b.spk_emb), lengths=lens, workspace=ws).cpu().numpy()
+    y2 = plan.forward(blob, t(ppg), t(sine), t(lft), emb, lengths=lens, workspace=ws).cpu().numpy()
     assert np.isfinite(y2).all()
+    # ... and over huge finite values: a stale 1e30 past a row's end once counted into the running maximum that scales
+    # the next layer's split-binary16 staging (no-speaker path, f32-family epilogue) - found by tools/stress_parity.py
+    ws[: ws.numel() // 4 * 4].view(torch.float32).fill_(1e30)
+    y3 = plan.forward(blob, t(ppg), t(sine), t(lft), emb, lengths=lens, workspace=ws).cpu().numpy()
     alone = A.Plan(cfg, storage=storage)
     alone.pad_odd_lengths = False
     for i, n in enumerate(lens):
@@ -824,8 +830,8 @@ def test_ragged_batch_with_odd_lengths_equals_every_utterance_alone(dev, width, 
         if storage == "bfloat16" and n % 4:
             alone.pad_odd_lengths = True                # (bfloat16 storage has no unpadded route for such lengths)
         yi = alone.forward(blob, t(b.ppg[i:i + 1, :, :n]), t(b.sine[i:i + 1, :, :T]), t(b.lft[i:i + 1, :, :T]),
-                           t(b.spk_emb[i:i + 1])).cpu().numpy()[0]
-        tol = 2e-5 if storage == "float32" else 0.15
-        for got in (y, y2):
+                           t(b.spk_emb[i:i + 1]) if spk else None).cpu().numpy()[0]
+        tol = (2e-5 if spk else 2e-4) if storage == "float32" else 0.15      # (no norm: the unnormalised activations run larger)
+        for got in (y, y2, y3):
             assert float(np.abs(got[i, :, :T] - yi).max()) <= tol, (i, n, float(np.abs(got[i, :, :T] - yi).max()))
             assert not got[i, :, T:].any()
