@@ -33,6 +33,10 @@ for it in range(n):
     b = S.synth_batch(cfg, B, F, 5000 + it + 100 * seed)
     ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft)]
     emb = torch.from_numpy(b.spk_emb).to(dev) if spk else None
+    # a DIRTY workspace: the forward allocates its workspace from the caching allocator, which hands back this block
+    need = plan.workspace_bytes(B, plan.padded_frames(F))
+    junk = torch.full((need // 4 + 16,), rng.choice([1e30, float("nan"), -3e38, 1000.0, float("inf")]), dtype=torch.float32, device=dev)
+    del junk
     y = plan.forward(blob, *ins, emb, lengths=lens).cpu()
     err = 0.0
     if lens is None:
@@ -60,6 +64,9 @@ for it in range(n):
         print("   fresh plan, no padding:", [round(one(p3), 6) for _ in range(2)])
         wsz = torch.zeros(plan.workspace_bytes(B, plan.padded_frames(F)), dtype=torch.uint8, device=dev)
         print("   zeroed workspace:", [round(one(p2, workspace=wsz), 6) for _ in range(2)])
+        for v in (1e30, float("nan"), -3e38, 1000.0, float("inf")):
+            junk = torch.full((need // 4 + 16,), v, dtype=torch.float32, device=dev); del junk
+            print(f"   allocator block poisoned with {v}:", round(one(p2), 6))
         torch.cuda.synchronize()
     worst = max(worst, err)
     flag = "" if err <= (3e-2 if BF16 else 1e-4) else "   <-- ABOVE TOLERANCE"
