@@ -233,6 +233,8 @@ hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const flo
 // the scan stores 8 partial maxima per input row (no atomics, nothing to zero first) and zeroes the `nzero` floats
 // at `zero` - the intermediate tensors' entries, which later kernels of the forward accumulate into by atomic max.
 hipError_t launch_noop(hipStream_t stream);          // empty kernel (stream calibration)
+// exact (float64) InstanceNorm sums of a float32 (B, C, ld) tensor over each row's own length -> st (B, C, 2), overwriting
+hipError_t launch_stats_exact(const float* u, double* st, int B, int C, int ld, const int* lens, int len_mul, hipStream_t stream);
 hipError_t launch_amax_inputs(const float* sig, long sig_stride, const float* ppg, int B, int C, int F, int hop,
                               const int* lens, float* amax_in, float* zero, int nzero, hipStream_t stream);
 

@@ -1381,6 +1381,28 @@ void amax_inputs_kernel(const float* __restrict__ sig, long sig_stride, const fl
     if (tid == 0) amax_in[row * AMAX_ENTRY + part * AMAX_STRIDE] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// InstanceNorm sums of a FiLM-affined tensor, EXACT: sum u and sum u^2 over each row's own length with every element
+// and every product in float64 (a float32 squared is exact in float64).  The conv epilogues accumulate these sums per
+// lane in float32 - fine for real rows, not for a row that is nearly constant (var << 1e-5 mean^2: the cancellation in
+// E[u^2] - mean^2 eats the partial sums' last bits), which is what a 1-frame utterance's two samples at the first block
+// are.  Launched behind the producing conv for batches of at most 4 frames (fastsvc_plan.cpp, g_exact_f32) and
+// OVERWRITES the (b, c) entries that conv accumulated.  u: (B, C, ld) float32; grid (C, B), one wave per row.
+__global__ __launch_bounds__(64)
+void stats_exact_kernel(const float* __restrict__ u, double* __restrict__ st, int C, int ld, const int* __restrict__ lens, int len_mul) {
+    const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int T = lens ? lens[b] * len_mul : ld;
+    const float* row = u + ((long)b * C + c) * ld;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < T; t += 64) { const double v = (double)row[t]; s1 += v; s2 += v * v; }
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+    if (lane == 0) { st[((long)b * C + c) * 2 + 0] = s1; st[((long)b * C + c) * 2 + 1] = s2; }
+}
+hipError_t launch_stats_exact(const float* u, double* st, int B, int C, int ld, const int* lens, int len_mul, hipStream_t stream) {
+    hipLaunchKernelGGL(stats_exact_kernel, dim3((unsigned)C, (unsigned)B), dim3(64), 0, stream, u, st, C, ld, lens, len_mul);
+    return hipGetLastError();
+}
+
 // an empty launch: what fastsvc_plan.cpp times a fork / join between two streams with (ExecCtx calibration)
 __global__ void noop_kernel() {}
 hipError_t launch_noop(hipStream_t stream) {

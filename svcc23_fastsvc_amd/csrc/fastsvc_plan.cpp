@@ -2385,6 +2385,12 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         HIP_TRY(run_conv(u.up, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".up_stretch").c_str()));
         }
 
+        // tiny batches: the sums the epilogue accumulated are replaced by exact ones (see stats_exact_kernel)
+        auto exact_stats = [&](const float* ut, double* stp) -> hipError_t {
+            if (!g_exact_f32 || !spk) return hipSuccess;
+            return launch_stats_exact(ut, stp, B, u.C, (int)Tout, lengths, (int)(Tout / F), stream);
+        };
+        HIP_TRY(exact_stats(u1, st));
         p = base;                                                  // xmid = conv_d3(lrelu(norm(u1))) + xr
         p.x = u1; p.x_b = cb; p.x_T = (int)Tout; p.T = (int)Tout;
         p.flags = pre | aff_out; p.st_in = st; p.spk = pb;
@@ -2399,12 +2405,14 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.y = xm; p.y_b = cb; p.y2 = u2; p.y2_b = cb;              // and u2 = aff(xmid)
         p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn;
         HIP_TRY(run_conv(u.d3, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d3").c_str()));
+        HIP_TRY(exact_stats(u2, st + stn));
 
         p.x = u2; p.st_in = st + stn; p.res = nullptr;             // u3 = aff(conv_d9(lrelu(norm(u2))))
         p.y = nullptr; p.y2 = u3;
         p.st_out = st + 2 * stn;
         
         HIP_TRY(run_conv(u.d9, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d9").c_str()));
+        HIP_TRY(exact_stats(u3, st + 2 * stn));
 
         p.x = u3; p.st_in = st + 2 * stn;                          // out = conv_d27(lrelu(norm(u3))) + xmid
         p.flags = pre; p.ss_out = nullptr; p.st_out = nullptr; p.y2 = nullptr;

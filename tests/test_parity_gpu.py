@@ -272,20 +272,26 @@ def test_output_is_affine_in_conv_last(dev):
     assert float((y4 - 4.0 * y).abs().max()) <= 4e-5     # exact up to the f64-atomics jitter of the norms upstream
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7524])
 def test_single_frame_utterances_over_several_seeds(dev, seed):
     """F = 1: the first up block normalises over TWO samples per channel, so (x - mean) * rstd amplifies
-    fp32 rounding by up to 1/sqrt(eps) ~ 316 and single inputs reach 1e-4..3e-4 against the oracle
-    (conditioning of the input, the same with every kernel variant): held to the north-star 1e-3."""
+    rounding by up to 1/sqrt(eps) ~ 316.  With the conv epilogues' one-pass float32 partial sums a near-constant
+    pair lost several per cent of its variance (seed 7524 = the randomised sweep's seed 75, case 24: 2.5e-3 of the
+    output's range, with every kernel variant); batches of at most 4 frames now recompute the sums exactly in float64
+    (stats_exact_kernel) and run on the f32-input kernels: 7e-5 there, held to 3e-4 here (north-star bar: 1e-3)."""
     O = _oracle()
     cfg = S.FULL_CONFIG
-    sd = S.synth_state_dict(cfg, 400 + seed)
-    b = S.synth_batch(cfg, 2, 1, 500 + seed)
+    if seed == 7524:
+        sd = S.synth_state_dict(cfg, 975)
+        b = S.synth_batch(cfg, 1, 1, 5000 + 24 + 7500)
+    else:
+        sd = S.synth_state_dict(cfg, 400 + seed)
+        b = S.synth_batch(cfg, 2, 1, 500 + seed)
     m = _module(cfg, sd, dev)
     with torch.no_grad():
         y = m(*_to(dev, b.ppg, b.sine, b.lft, b.spk_emb)).cpu()
     ref = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb)
-    assert float((y - ref).abs().max()) <= TOL * max(1.0, float(ref.abs().max()))
+    assert float((y - ref).abs().max()) <= 3e-4 * max(1.0, float(ref.abs().max()))
 
 
 def test_errors_mirror_reference(dev):
