@@ -295,7 +295,7 @@ class FastSVCGenerator(nn.Module):
         plan = self.plan
         B, _, F = x.shape
         step = B
-        Fw = plan.padded_frames(F)                 # (bfloat16 storage runs frame counts padded to a multiple of 4)
+        Fw = plan.padded_frames(F)                 # (frame counts are run padded to a multiple of 4, as a ragged batch)
         while step > 1 and plan.workspace_bytes(step, Fw) > self.max_workspace_bytes:
             step = (step + 1) // 2
         if step == B:
