@@ -234,7 +234,9 @@ hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const flo
 // at `zero` - the intermediate tensors' entries, which later kernels of the forward accumulate into by atomic max.
 hipError_t launch_noop(hipStream_t stream);          // empty kernel (stream calibration)
 // exact (float64) InstanceNorm sums of a float32 (B, C, ld) tensor over each row's own length -> st (B, C, 2), overwriting
-hipError_t launch_stats_exact(const float* u, double* st, int B, int C, int ld, const int* lens, int len_mul, hipStream_t stream);
+// (ragged batch: rows of utterances longer than max_frames are left as the conv accumulated them)
+hipError_t launch_stats_exact(const float* u, double* st, int B, int C, int ld, const int* lens, int len_mul, int max_frames,
+                              hipStream_t stream);
 hipError_t launch_amax_inputs(const float* sig, long sig_stride, const float* ppg, int B, int C, int F, int hop,
                               const int* lens, float* amax_in, float* zero, int nzero, hipStream_t stream);
 

@@ -1388,8 +1388,10 @@ void amax_inputs_kernel(const float* __restrict__ sig, long sig_stride, const fl
 // are.  Launched behind the producing conv for batches of at most 4 frames (fastsvc_plan.cpp, g_exact_f32) and
 // OVERWRITES the (b, c) entries that conv accumulated.  u: (B, C, ld) float32; grid (C, B), one wave per row.
 __global__ __launch_bounds__(64)
-void stats_exact_kernel(const float* __restrict__ u, double* __restrict__ st, int C, int ld, const int* __restrict__ lens, int len_mul) {
+void stats_exact_kernel(const float* __restrict__ u, double* __restrict__ st, int C, int ld, const int* __restrict__ lens, int len_mul,
+                        int max_frames) {
     const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (lens && lens[b] > max_frames) return;            // (a ragged batch: only its SHORT utterances need this)
     const int T = lens ? lens[b] * len_mul : ld;
     const float* row = u + ((long)b * C + c) * ld;
     double s1 = 0.0, s2 = 0.0;
@@ -1398,8 +1400,9 @@ void stats_exact_kernel(const float* __restrict__ u, double* __restrict__ st, in
     for (int d = 32; d >= 1; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
     if (lane == 0) { st[((long)b * C + c) * 2 + 0] = s1; st[((long)b * C + c) * 2 + 1] = s2; }
 }
-hipError_t launch_stats_exact(const float* u, double* st, int B, int C, int ld, const int* lens, int len_mul, hipStream_t stream) {
-    hipLaunchKernelGGL(stats_exact_kernel, dim3((unsigned)C, (unsigned)B), dim3(64), 0, stream, u, st, C, ld, lens, len_mul);
+hipError_t launch_stats_exact(const float* u, double* st, int B, int C, int ld, const int* lens, int len_mul, int max_frames,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(stats_exact_kernel, dim3((unsigned)C, (unsigned)B), dim3(64), 0, stream, u, st, C, ld, lens, len_mul, max_frames);
     return hipGetLastError();
 }
 

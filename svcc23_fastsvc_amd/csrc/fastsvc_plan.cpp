@@ -2387,8 +2387,12 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
 
         // tiny batches: the sums the epilogue accumulated are replaced by exact ones (see stats_exact_kernel)
         auto exact_stats = [&](const float* ut, double* stp) -> hipError_t {
-            if (!g_exact_f32 || !spk) return hipSuccess;
-            return launch_stats_exact(ut, stp, B, u.C, (int)Tout, lengths, (int)(Tout / F), stream);
+            // ... and, in a small ragged batch of float32 storage, for its utterances of at most 4 frames (the launch is
+            // B x C one-wave workgroups that leave at once for the longer ones: not worth it on big batches, where a
+            // decode harness's length buckets never put a 1-frame utterance anyway)
+            const bool small_ragged = lengths && P.storage == 0 && F <= 64;
+            if (!spk || !(g_exact_f32 || small_ragged)) return hipSuccess;
+            return launch_stats_exact(ut, stp, B, u.C, (int)Tout, lengths, (int)(Tout / F), 4, stream);
         };
         HIP_TRY(exact_stats(u1, st));
         p = base;                                                  // xmid = conv_d3(lrelu(norm(u1))) + xr
