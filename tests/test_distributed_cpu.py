@@ -172,3 +172,26 @@ def test_ragged_buckets_bound_the_padding():
     for b in batches:
         assert len(b) <= 3
         assert min(frames[i] for i in b) >= 0.875 * max(frames[i] for i in b)
+
+
+def test_variable_length_workload_is_deterministic_and_buckets_tightly():
+    """bench.py --workload cfg4var (SURVEY 8d's variant of cfg4): 512 lengths uniform in 2 - 10 s, the same on every
+    rank and run; length-bucketed into padded batches whose padding stays within the tolerance."""
+    from svcc23_fastsvc_amd import synth as S
+    from svcc23_fastsvc_amd import distributed as D
+    f1, f2 = S.workload_frames("cfg4var"), S.workload_frames("cfg4var")
+    assert f1 == f2 and len(f1) == 512 and min(f1) >= 300 and max(f1) <= 1500
+    assert S.workload_frames("cfg4") == [1500] * 512
+    for world in (1, 8):
+        sched = D.GatherSchedule(f1, 160, world, 64, True, 0.125)
+        seen = []
+        for rank in range(world):
+            for chunk in sched.batches[rank]:
+                assert 1 <= len(chunk) <= 64
+                longest, shortest = max(f1[i] for i in chunk), min(f1[i] for i in chunk)
+                assert shortest >= (1.0 - 0.125) * longest - 1          # padding within the tolerance
+                seen += list(chunk)
+        assert sorted(seen) == list(range(512))                          # every utterance exactly once
+    # LPT sharding: the ranks' total frames differ by little
+    totals = [sum(f1[i] for i in D.shard_utterances(f1, 8)[r]) for r in range(8)]
+    assert max(totals) - min(totals) <= 0.02 * max(totals)
