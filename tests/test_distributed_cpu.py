@@ -85,9 +85,23 @@ def _worker(rank, world, port, q):
             return out
 
         yq = D.run_utterance_parallel(fwd_into, eq, torch.device("cpu"), max_batch=64, forward_into=True)
+        # ragged AND `out=`: a rank whose batch is as wide as the round's widest writes into the send buffer, a rank
+        # with a narrower batch is called without `out` and copied (bench.py --workload cfg4var on several GPUs)
+        direct = []
+
+        def fwd_ragged_into(ppg, sine, lft, emb, lengths, out=None):
+            direct.append(out is not None)
+            y = _fake_forward_ragged(ppg, sine, lft, emb, lengths)
+            if out is None:
+                return y
+            out.copy_(y)
+            return out
+
+        yrf = D.run_utterance_parallel(fwd_ragged_into, utts, torch.device("cpu"), max_batch=3, ragged=True,
+                                       pad_tolerance=0.5, forward_into=True)
         q.put((rank, blob.numpy().copy(), [y.numpy().copy() for y in ys], [y.numpy().copy() for y in yr],
                [y.numpy().copy() for y in y1], [None if y is None else y.numpy().copy() for y in adhoc],
-               [y.numpy().copy() for y in yq], calls))
+               [y.numpy().copy() for y in yq], calls, [y.numpy().copy() for y in yrf], direct))
     finally:
         dist.destroy_process_group()
 
@@ -112,8 +126,8 @@ def test_two_ranks_broadcast_shard_gather():
         p.start()
     res = {}
     for _ in range(world):
-        rank, blob, ys, yr, y1, adhoc, yq, calls = q.get(timeout=120)
-        res[rank] = (blob, ys, yr, y1, adhoc, yq, calls)
+        rank, blob, ys, yr, y1, adhoc, yq, calls, yrf, direct = q.get(timeout=120)
+        res[rank] = (blob, ys, yr, y1, adhoc, yq, calls, yrf, direct)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -127,9 +141,10 @@ def test_two_ranks_broadcast_shard_gather():
         want = _fake_forward(torch.from_numpy(u["ppg"])[None], torch.from_numpy(u["sine"])[None],
                              torch.from_numpy(u["lft"])[None], torch.from_numpy(u["spk_emb"])[None])[0].numpy()
         for r in range(world):
-            for got in (res[r][1][i], res[r][2][i]):      # same-length buckets, and padded ragged batches
+            for got in (res[r][1][i], res[r][2][i], res[r][7][i]):      # same-length buckets, padded ragged batches (+ `out=`)
                 assert got.shape == want.shape
                 assert np.allclose(got, want, atol=1e-6)
+    assert any(any(res[r][8]) for r in range(world))             # somebody wrote straight into a send buffer
     # the one-batch-per-rank set: two rounds of 8 utterances per rank, every forward wrote into the send buffer
     cfg = S.TINY_CONFIG
     for r in range(world):
