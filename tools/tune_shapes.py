@@ -74,8 +74,15 @@ if os.path.exists(TUNED_TABLE_PATH):
 doc["device"] = torch.cuda.get_device_name(0)
 doc["format"] = "tables[config signature][layer|B|T] = [NW, WM, WN, tiles_per_workgroup]"
 doc["tables"].setdefault(sig, {}).update(table)
-with open(TUNED_TABLE_PATH, "w") as f:
-    json.dump(doc, f, indent=1, sort_keys=True)
+with open(TUNED_TABLE_PATH, "w") as f:                  # one table entry per line
+    lines = ["{"] + [" %s: %s," % (json.dumps(k), json.dumps(doc[k])) for k in sorted(doc) if k != "tables"] + [' "tables": {']
+    tabs = sorted(doc["tables"].items())
+    for ti, (tsig, t) in enumerate(tabs):
+        items = sorted(t.items())
+        lines.append("  %s: {" % json.dumps(tsig))
+        lines += ["   %s: %s%s" % (json.dumps(k), json.dumps(v), "," if i + 1 < len(items) else "") for i, (k, v) in enumerate(items)]
+        lines.append("  }%s" % ("," if ti + 1 < len(tabs) else ""))
+    f.write("\n".join(lines + [" }", "}"]) + "\n")
 os.makedirs("gpurun_out", exist_ok=True)
 shutil.copy(TUNED_TABLE_PATH, "gpurun_out/tuned_mi355x.json")
 print(f"{len(table)} entries -> {TUNED_TABLE_PATH}")
