@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip.so")
 # the stamped diagnostic build (--timeline) is a separate file: loaded only when FASTSVC_HIP_LIB names it
 TIMELINE_LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip_timeline.so")
-SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip", "fastsvc_loudness.hip"]
+SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_cond.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip", "fastsvc_loudness.hip"]
 HEADERS = [os.path.join(CSRC, "fastsvc_kernels.h"), os.path.join(ROOT, "include", "fastsvc_hip.h")]
 ARCH = "gfx950"
 
@@ -44,6 +44,9 @@ UNITS = [
     ("fastsvc_kernels.hip", ["-DFASTSVC_ACT_BF16=1"], "kernels_bf16.o"),
     ("fastsvc_hx.hip", [], "hx_f32.o"),
     ("fastsvc_hx.hip", ["-DFASTSVC_ACT_BF16=1"], "hx_bf16.o"),
+    # (-fno-honor-nans: LeakyReLU as max(v, 0.2 v) without the canonicalising v_max v, v, v in front of it)
+    ("fastsvc_cond.hip", ["-fno-honor-nans"], "cond_f32.o"),
+    ("fastsvc_cond.hip", ["-fno-honor-nans", "-DFASTSVC_ACT_BF16=1"], "cond_bf16.o"),
     ("fastsvc_plan.cpp", [], "plan.o"),
     ("fastsvc_signal.hip", [], "signal.o"),
     ("fastsvc_loudness.hip", [], "loudness.o"),

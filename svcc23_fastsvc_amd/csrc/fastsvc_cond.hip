@@ -1,0 +1,543 @@
+// fastsvc_cond.hip - gfx950 (CDNA4 / MI355X): a WHOLE conditioning stage of the FastSVC generator as one launch.
+//
+// Reference dataflow (harana/models/fastsvc.py): FastSVCDownsampleNet.forward (:164-193) for both conditioning
+// signals (loudness, sine excitation), then FastSVCFiLMNet.forward (:220-232) of the same stage for both signals,
+// summed as FastSVCUpsampleNet._feature_affine sums them (:129-130):
+//
+//     per signal:  c1 = conv3_d1(lrelu(x)) + b1            x: the stage's input (stage 0: the raw 1-channel signal)
+//                  c2 = conv3_d2(lrelu(c1)) + b2
+//                  h  = conv3_d4(lrelu(c2)) + b3 + conv1x1(x)
+//                  u  = lrelu(conv3_d1(h) + b4)            film.conv
+//     both:        [scale ; shift] = conv3_d1([u_lft ; u_sine]) + b5     film.conv_scale / conv_shift, K-concatenated
+//
+// None of these layers has a reduction over time (the InstanceNorms live in the up blocks), so a time tile of the
+// stage's OUTPUT depends on a +-9 column window of its input only: one workgroup walks time tiles of one utterance,
+// keeps every intermediate tile (both signals) in LDS in the MFMA operand format and writes only
+//     ss   (B, 2C, T)       scale / shift of the stage - what the up block reads, and
+//     hd   (2B, C, T / s')  h[..., ::s'] COMPACT - the only part of h the next stage reads (Squeeze2d, upsample.py:53-74)
+// i.e. per output column 2C + 2C/s' elements are written and 2 read, where the separate launches move ~6C (c123 writes
+// h, the FiLM chain reads it and writes ss, the next stage's decimating pair gathers every line of h again).
+//
+// Work layout (stage 0, C = 24): 4 waves, two workgroups per CU.  Layers c2 / c3 / film.conv: wave = (signal, every
+// second 16-column tile), SWAPPED MFMA operands (A = weights, B = activations), so a lane ends with 4 consecutive
+// CHANNELS of one time step = one 8-byte store into the next layer's time-major LDS tile.  Heads: wave = every fourth
+// time tile, all three 16-channel output tiles, plain operand order, result staged channel-major in LDS and copied
+// out in whole rows (16 B per lane).  The first conv (C_in = 1) runs on the VALU.  All weight fragments of a wave -
+// its signal's three layers and the heads: 36 KB-sized fragments = 144 registers - stay resident for the whole
+// launch (re-fetched per tile they would be 144 KB of L2 traffic per 23 KB of output).
+#include "fastsvc_kernels.h"
+
+namespace fastsvc {
+#ifdef FASTSVC_ACT_BF16
+namespace bf16 {
+#endif
+
+#include "fastsvc_device.inc"
+
+#ifdef FASTSVC_ACT_BF16
+typedef __bf16 cs_t;
+constexpr int CS_NP = 1;
+#else
+typedef _Float16 cs_t;
+constexpr int CS_NP = 2;
+#endif
+typedef cs_t cs8 __attribute__((ext_vector_type(8)));
+typedef cs_t cs4 __attribute__((ext_vector_type(4)));
+typedef unsigned cs_u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 cs_mfma(cs8 a, cs8 b, f32x4 c) {
+#ifdef FASTSVC_ACT_BF16
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+constexpr int CS_ROW = 64;               // bytes of one LDS tile row: 32 channels
+constexpr int CS_FRAG = 1024;            // bytes of one packed weight fragment (64 lanes x 8 halves)
+constexpr int CS_C = 24;                 // channels of the stage this file is compiled for (fastsvc.yaml mid_channels[-1])
+constexpr int CS_NQ = 2;                 // waves per signal
+constexpr int CS_NTHREADS = 2 * CS_NQ * 64;
+
+// same row / slot swizzle as fastsvc_hx.hip (conflict-free ds_read_b128 at any row offset)
+__device__ __forceinline__ int cs_off(int row, int oct) {
+    return ((row ^ ((row >> 2) & 1)) * CS_ROW) + ((oct ^ ((row >> 1) & 2)) << 4);
+}
+
+struct CsFrag { cs8 p[CS_NP]; };
+__device__ __forceinline__ CsFrag cs_read(const unsigned char* plane, int off, int lo_off) {
+    CsFrag f;
+    f.p[0] = *reinterpret_cast<const cs8*>(plane + off);
+    if constexpr (CS_NP == 2) f.p[1] = *reinterpret_cast<const cs8*>(plane + lo_off + off);
+    return f;
+}
+struct CsW { u32x4 p[CS_NP]; };
+__device__ __forceinline__ CsW cs_wload(const unsigned char* frag, int lane) {
+    CsW w;
+    #pragma unroll
+    for (int q = 0; q < CS_NP; ++q) w.p[q] = *reinterpret_cast<const u32x4*>(frag + q * CS_FRAG + lane * 16);
+    return w;
+}
+// acc += w (.) a: bf16 one product; split binary16: hi*hi + hi*lo + lo*hi.  SWAP: weights are the A operand.
+template <bool SWAP>
+__device__ __forceinline__ f32x4 cs_prod(const CsW& w, const CsFrag& a, f32x4 acc) {
+    #pragma unroll
+    for (int pr = 0; pr < (CS_NP == 2 ? 3 : 1); ++pr) {
+        const int ia = (CS_NP == 2 && pr == 2) ? 1 : 0, iw = (CS_NP == 2 && pr == 1) ? 1 : 0;
+        if constexpr (SWAP) acc = cs_mfma(__builtin_bit_cast(cs8, w.p[iw]), a.p[ia], acc);
+        else acc = cs_mfma(a.p[ia], __builtin_bit_cast(cs8, w.p[iw]), acc);
+    }
+    return acc;
+}
+
+// 4 consecutive channels of one time step -> the 8-byte slot of a time-major tile row
+__device__ __forceinline__ void cs_store4(unsigned char* dst, int lo_off, f32x4 v) {
+    const cs4 h = __builtin_convertvector(v, cs4);
+    *reinterpret_cast<cs4*>(dst) = h;
+    if constexpr (CS_NP == 2) {
+        cs4 l;
+        #pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = (cs_t)(v[e] - (float)h[e]);
+        *reinterpret_cast<cs4*>(dst + lo_off) = l;
+    }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// LeakyReLU(0.2) = max(v, 0.2 v), the multiply as packed float32 (two values per instruction)
+__device__ __forceinline__ f32x4 cs_lrelu4(f32x4 v) {
+    const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    const f32x2 ta = a * LRELU_SLOPE, tb = b * LRELU_SLOPE;
+    return f32x4{fmaxf(a.x, ta.x), fmaxf(a.y, ta.y), fmaxf(b.x, tb.x), fmaxf(b.y, tb.y)};
+}
+
+__device__ __forceinline__ void cs_store4_masked(unsigned char* dst, int lo_off, f32x4 v, unsigned keep) {
+    const cs4 h = __builtin_convertvector(v, cs4);
+    cs_u2 hp = __builtin_bit_cast(cs_u2, h);
+    hp.x &= keep; hp.y &= keep;
+    *reinterpret_cast<cs_u2*>(dst) = hp;
+    if constexpr (CS_NP == 2) {
+        cs4 l;
+        #pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = (cs_t)(v[e] - (float)h[e]);
+        cs_u2 lp = __builtin_bit_cast(cs_u2, l);
+        lp.x &= keep; lp.y &= keep;
+        *reinterpret_cast<cs_u2*>(dst + lo_off) = lp;
+    }
+}
+
+// One k=3 layer of one signal on this wave's tiles (j = q, q + NQ, ...), swapped operands.
+//   in:  plane of the layer's input (time-major rows), rows = t - t0 + 16
+//   out: tile rows out_row0 + 16 j + (lane & 15), channels 4 g .. 4 g + 3 of channel tile m
+// KIND 0: lrelu(acc + b) -> own signal's plane;  1: acc + b + rank-1 residual, raw;
+//      2: lrelu(acc + b) -> the 2C-channel plane pair [lft ; sine] the heads read
+// The bias rides in the accumulator's initial value; tiles are walked in groups of G with the NEXT group's products
+// issued ahead of a group's epilogue (two accumulator sets), so that the matrix pipe runs under the VALU work.
+template <int NTL, int KIND>
+__device__ __forceinline__ void cs_layer(const unsigned char* in_plane, unsigned char* out_planes, int lo_off, int plane_bytes,
+                                         const CsW (&W)[3][2], int dil, int out_row0, const float* kb /* LDS [32] */,
+                                         const float* xs_sig /* LDS, KIND 1 */, const float* r1w_lds /* LDS [32], KIND 1 */,
+                                         int sig, int q, int t0, int Tv, int lane) {
+    constexpr int NI = NTL / CS_NQ;                    // tiles per wave
+    constexpr int G = 2;                               // tiles per group
+    constexpr int NG = NI / G;
+    static_assert(NTL % (CS_NQ * G) == 0, "tiles per wave must be a whole number of groups");
+    const int l15 = lane & 15, g = lane >> 4;
+    int aoff[3];
+    #pragma unroll
+    for (int tap = 0; tap < 3; ++tap) aoff[tap] = cs_off(out_row0 + (tap - 1) * dil + l15, g) + q * 16 * CS_ROW;
+    f32x4 kbv[2], r1w[2];
+    int wbase[2];
+    #pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int co0 = m * 16 + 4 * g;
+        kbv[m] = *reinterpret_cast<const f32x4*>(kb + co0);
+        if constexpr (KIND == 1) r1w[m] = *reinterpret_cast<const f32x4*>(r1w_lds + co0);
+        if constexpr (KIND == 2) {
+            // (this signal's channel padding co >= C would land on the other signal's channels: its zeros go to the
+            // pair's own padding 2C + 8 .. instead - no divergent store)
+            const int cc0 = co0 < CS_C ? sig * CS_C + co0 : 2 * CS_C + 8 + (co0 - CS_C);
+            wbase[m] = (cc0 >> 5) * plane_bytes + cs_off(out_row0 + l15, (cc0 & 31) >> 3) + (cc0 & 7) * 2 + q * 16 * CS_ROW;
+        } else {
+            wbase[m] = sig * plane_bytes + cs_off(out_row0 + l15, co0 >> 3) + (co0 & 7) * 2 + q * 16 * CS_ROW;
+        }
+    }
+    const int tbase = t0 - 16 + out_row0;              // time of row out_row0
+    // Software pipeline over the groups, written out: the LDS reads of group n + 1, the matrix products of group n and
+    // the VALU epilogue of group n - 1 are independent and sit in one scheduling region per step; the group barriers
+    // below ask for them interleaved (one fragment read and ~4 VALU instructions per product) instead of the
+    // read -> wait -> product chains the default schedule made of it (118 cycles per product, measured).
+    f32x4 acc[2][G][2];
+    CsFrag fr[2][G][3];
+    auto fetch = [&](int grp, CsFrag (&f)[G][3]) {
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            #pragma unroll
+            for (int ii = 0; ii < G; ++ii) f[ii][tap] = cs_read(in_plane, aoff[tap] + (CS_NQ * (grp * G + ii)) * 16 * CS_ROW, lo_off);
+    };
+    auto products = [&](int grp, const CsFrag (&f)[G][3], f32x4 (&ac)[G][2]) {
+        #pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const int j = q + CS_NQ * (grp * G + ii);
+            #pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if constexpr (KIND == 1) ac[ii][m] = r1w[m] * xs_sig[out_row0 + 16 * j + l15] + kbv[m];
+                else ac[ii][m] = kbv[m];
+            }
+        }
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            #pragma unroll
+            for (int ii = 0; ii < G; ++ii)
+                #pragma unroll
+                for (int m = 0; m < 2; ++m) ac[ii][m] = cs_prod<true>(W[tap][m], f[ii][tap], ac[ii][m]);
+    };
+    auto finish = [&](int grp, const f32x4 (&ac)[G][2]) {
+        #pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const int j = q + CS_NQ * (grp * G + ii);
+            // outside the utterance: the next conv's zero padding - applied to the PACKED values (one AND per register)
+            const unsigned keep = (unsigned)(tbase + 16 * j + l15) < (unsigned)Tv ? 0xffffffffu : 0u;
+            #pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x4 v = ac[ii][m];
+                if constexpr (KIND != 1) v = cs_lrelu4(v);
+                cs_store4_masked(out_planes + wbase[m] + (CS_NQ * (grp * G + ii)) * 16 * CS_ROW, lo_off, v, keep);
+            }
+        }
+    };
+    fetch(0, fr[0]);
+    #pragma unroll
+    for (int grp = 0; grp <= NG; ++grp) {
+        if (grp + 1 < NG) fetch(grp + 1, fr[(grp + 1) & 1]);
+        if (grp < NG) products(grp, fr[grp & 1], acc[grp & 1]);
+        if (grp > 0) finish(grp - 1, acc[(grp - 1) & 1]);
+        if (grp > 0 && grp < NG) {
+            // region = G*3 fragment reads, G*6 (x3 split) products, ~G*2*12 VALU, G*2 LDS stores
+            #pragma unroll
+            for (int k = 0; k < G * 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, CS_NP == 2 ? 3 : 1, 0);    // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                      // VALU
+                if (k < G * 3) __builtin_amdgcn_sched_group_barrier(0x100, CS_NP, 0);   // DS read
+                if (k % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, CS_NP, 0);  // DS write
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NTL>
+struct CsGeom {
+    static constexpr int NTO = NTL - 1;                // output tiles per workgroup tile
+    static constexpr int NT = 16 * NTO;                // output columns per workgroup tile
+    static constexpr int ROWS = NT + 40;               // LDS rows: row r <-> t = t0 - 16 + r (the deepest read ends at NT + 34)
+    static constexpr int PLANE = CS_NP * ROWS * CS_ROW;
+    static constexpr int XS_BYTES = 2 * ROWS * 4;
+    static constexpr int CONST_FLOATS = 2 * 32 * 4 /* in1 w0 w1 w2 b */ + 2 * 32 /* r1 w */ + 3 * 2 * 32 /* biases */ + 64 /* heads */;
+    static constexpr int SP = NT * (int)sizeof(act_t) + 16;  // staging pitch of a scale / shift row (bytes; 16-byte aligned rows)
+    static constexpr size_t LDS = XS_BYTES + CONST_FLOATS * 4 + 4 * (size_t)PLANE;
+    static_assert(2 * CS_C * SP <= 2 * PLANE, "staging rows must fit the planes they alias");
+};
+
+template <int NTL>
+__global__ __launch_bounds__(CS_NTHREADS, 2)
+void cond_stage0_kernel(const CondStage0Params p) {
+    using GEO = CsGeom<NTL>;
+    constexpr int NT = GEO::NT, ROWS = GEO::ROWS, PLANE = GEO::PLANE, NTO = GEO::NTO;
+    constexpr int lo_off = ROWS * CS_ROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                                  // [2][ROWS] raw signal tiles (float32)
+    float* kin1 = xs + 2 * ROWS;                                                  // [2][w0 w1 w2 b][32] of the 1 -> C conv
+    float* kr1 = kin1 + 2 * 32 * 4;                                               // [2][32]  rank-1 residual weights (1x1 conv, C_in = 1; its bias joins c3's)
+    float* kbias = kr1 + 2 * 32;                                                  // [3][2][32]  c2 / c3 / film.conv
+    float* kb5 = kbias + 3 * 2 * 32;                                              // [64] heads
+    unsigned char* bufA = reinterpret_cast<unsigned char*>(kb5 + 64);             // 2 planes: c1 -> h -> output staging
+    unsigned char* bufB = bufA + 2 * PLANE;                                       // 2 planes: c2 -> u
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z;
+    const int Tv = p.lens ? p.lens[b] * p.len_mul : p.T;
+    const int ntx = (Tv + NT - 1) / NT;
+    const int tpw = p.tpw & 0xffff, dbg = p.tpw >> 16;      // (dbg: developer ablation switches, tools/cond_check.py)
+    const int tile_begin = blockIdx.x * tpw;
+    const int tile_end = min(tile_begin + tpw, ntx);
+    if (tile_begin >= tile_end) return;
+
+    // ---- per-wave weight fragments, resident for the whole launch ----
+    const int sig = wave & 1, q = wave >> 1;
+    CsW W2[3][2], W3[3][2], W4[3][2];
+    #pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+        #pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const long fo = (long)(tap * 2 + m) * CS_NP * CS_FRAG;
+            W2[tap][m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[0][sig]) + fo, lane);
+            W3[tap][m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[1][sig]) + fo, lane);
+            W4[tap][m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[2][sig]) + fo, lane);
+        }
+    CsW W5[2][3][3];                                                              // heads: [K chunk][tap][output channel tile]
+    #pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            #pragma unroll
+            for (int m = 0; m < 3; ++m)
+                W5[ch][tap][m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w5) + (long)((ch * 3 + tap) * 3 + m) * CS_NP * CS_FRAG, lane);
+
+    // ---- constants (no tile is zeroed: every row / channel a needed output depends on is written before it is read -
+    // c1 incl. its channel padding by P1, c2 / h with padding by their layers - and what feeds only the unneeded halo
+    // columns of a layer never reaches a stored value: columns are independent in a convolution) ----
+    for (int i = tid; i < 2 * 32; i += CS_NTHREADS) {
+        const int s = i >> 5, c = i & 31;
+        const bool ok = c < CS_C;
+        const float* wp = p.in1_w[s] + (ok ? c : 0) * 3;
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap) kin1[(s * 4 + tap) * 32 + c] = ok ? wp[tap] : 0.f;
+        kin1[(s * 4 + 3) * 32 + c] = ok ? p.in1_b[s][c] : 0.f;
+        kr1[s * 32 + c] = ok ? p.r1w[s][c] : 0.f;
+        #pragma unroll
+        for (int l = 0; l < 3; ++l)                     // (c3's bias carries the 1x1 residual conv's: both join h)
+            kbias[(l * 2 + s) * 32 + c] = ok ? p.bias[l][s][c] + (l == 1 ? p.r1b[s][c] : 0.f) : 0.f;
+        kb5[i] = i < 2 * CS_C ? p.b5[i] : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(p.x + (long)b * p.x_b, Tv);
+    const __amdgpu_buffer_rsrc_t xr1 = make_rsrc(p.x + p.x_sig + (long)b * p.x_b, Tv);
+    const __amdgpu_buffer_rsrc_t ssr = act_rsrc(reinterpret_cast<const float*>(p.ss), (long)b * p.ss_b, (long)2 * CS_C * p.ld);
+    const int hdTv = Tv / p.hd_s;
+    const __amdgpu_buffer_rsrc_t hdr0 = act_rsrc(reinterpret_cast<const float*>(p.hd), (long)b * p.hd_b, (long)CS_C * p.hd_ld);
+    const __amdgpu_buffer_rsrc_t hdr1 = act_rsrc(reinterpret_cast<const float*>(p.hd), p.hd_sig + (long)b * p.hd_b, (long)CS_C * p.hd_ld);
+
+    // raw signal rows t0 - 16 .. of both signals for one tile, 0 outside the utterance: fetched one tile ahead
+    constexpr int XN = (ROWS + CS_NTHREADS - 1) / CS_NTHREADS;
+    float xpre[2][XN];
+    auto xfetch = [&](int t0n) {
+        #pragma unroll
+        for (int k = 0; k < XN; ++k) {
+            const int r = tid + k * CS_NTHREADS;
+            const int t = t0n - 16 + r;
+            const int o = (r < ROWS && (unsigned)t < (unsigned)Tv) ? t * 4 : OOB_OFF;
+            xpre[0][k] = buf_load1(xr0, o, 0);
+            xpre[1][k] = buf_load1(xr1, o, 0);
+        }
+    };
+    xfetch(tile_begin * NT);
+#ifdef FASTSVC_COND_TRACE
+    unsigned long long* trace = (p.amax_hd && blockIdx.x == 1 && blockIdx.z == 0 && lane == 0)
+        ? reinterpret_cast<unsigned long long*>(p.amax_hd) + wave * 64 : nullptr;
+    int tri = 0;
+#define CS_STAMP() do { if (trace && tri < 64) trace[tri++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CS_STAMP() do {} while (0)
+#endif
+    // the signal rows of a tile reach LDS one tile ahead, from registers requested two tiles ahead (xs_commit sits in
+    // front of the output stores of the tile before: vmcnt counts loads and stores in one in-order queue, and behind
+    // those stores the wait for the rows also waited for the stores' acknowledgements - 12 % of the launch, measured)
+    auto xs_commit = [&]() {
+        #pragma unroll
+        for (int k = 0; k < XN; ++k) {
+            const int r = tid + k * CS_NTHREADS;
+            if (r < ROWS) { xs[r] = xpre[0][k]; xs[ROWS + r] = xpre[1][k]; }
+        }
+    };
+    xs_commit();
+    xfetch((tile_begin + 1) * NT);
+    __syncthreads();
+    CS_STAMP();
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int t0 = tile * NT;
+        CS_STAMP();
+        // ---- P1: c1 = lrelu(conv3(lrelu(x)) + b1) on the VALU, rows 8 .. NT + 24: thread = row, one (signal, octet of 8
+        // channels) per step, whose taps are wave-uniform LDS reads ----
+        if (!(dbg & 2)) {
+            static_assert(16 * NTL == CS_NTHREADS, "one c1 row per thread");
+            const int r = 8 + tid;
+            const int t = t0 - 16 + r;
+            const unsigned keep = (unsigned)t < (unsigned)Tv ? 0xffffffffu : 0u;    // outside the utterance: c2's zero padding
+            #pragma unroll
+            for (int s1 = 0; s1 < 2; ++s1) {
+                const float* xrow = xs + s1 * ROWS;
+                float xa = xrow[r - 1], xb = xrow[r], xc = xrow[r + 1];
+                xa = fmaxf(xa, xa * LRELU_SLOPE); xb = fmaxf(xb, xb * LRELU_SLOPE); xc = fmaxf(xc, xc * LRELU_SLOPE);
+                const f32x2 xa2 = {xa, xa}, xb2 = {xb, xb}, xc2 = {xc, xc};
+                #pragma unroll
+                for (int oct = 0; oct < 3; ++oct) {
+                    f32x4 o4[2];
+                    #pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const float* kw = kin1 + s1 * 4 * 32 + oct * 8 + hh * 4;
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(kw), w1 = *reinterpret_cast<const f32x4*>(kw + 32),
+                                    w2 = *reinterpret_cast<const f32x4*>(kw + 64), wb = *reinterpret_cast<const f32x4*>(kw + 96);
+                        #pragma unroll
+                        for (int pq = 0; pq < 2; ++pq) {          // packed float32: two channels per instruction
+                            const f32x2 a0 = {w0[2 * pq], w0[2 * pq + 1]}, a1 = {w1[2 * pq], w1[2 * pq + 1]},
+                                        a2 = {w2[2 * pq], w2[2 * pq + 1]}, ab = {wb[2 * pq], wb[2 * pq + 1]};
+                            const f32x2 u = __builtin_elementwise_fma(a2, xc2, __builtin_elementwise_fma(a1, xb2, __builtin_elementwise_fma(a0, xa2, ab)));
+                            o4[hh][2 * pq] = u.x; o4[hh][2 * pq + 1] = u.y;
+                        }
+                        o4[hh] = cs_lrelu4(o4[hh]);
+                    }
+                    unsigned char* dst = bufA + s1 * PLANE + cs_off(r, oct);
+                    cs_store4_masked(dst, lo_off, o4[0], keep);
+                    cs_store4_masked(dst + 8, lo_off, o4[1], keep);
+                }
+                // channel padding 24 .. 31 (the staging rows of the previous tile lay here)
+                unsigned char* pad = bufA + s1 * PLANE + cs_off(r, 3);
+                *reinterpret_cast<u32x4*>(pad) = u32x4{0u, 0u, 0u, 0u};
+                if constexpr (CS_NP == 2) *reinterpret_cast<u32x4*>(pad + lo_off) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        CS_STAMP();
+        __syncthreads();
+        CS_STAMP();
+        // ---- P2: c2 = lrelu(conv3_d2(c1) + b2): output rows 10 .. (t = -6 ..) ----
+        if (!(dbg & 4)) cs_layer<NTL, 0>(bufA + sig * PLANE, bufB, lo_off, PLANE, W2, 2, 10, kbias + (0 * 2 + sig) * 32, nullptr, nullptr, sig, q, t0, Tv, lane);
+        CS_STAMP();
+        __syncthreads();
+        CS_STAMP();
+        // ---- P3: h = conv3_d4(c2) + b3 + (r1w x + r1b): output rows 14 .. (t = -2 ..) ----
+        if (!(dbg & 4)) cs_layer<NTL, 1>(bufB + sig * PLANE, bufA, lo_off, PLANE, W3, 4, 14, kbias + (1 * 2 + sig) * 32, xs + sig * ROWS, kr1 + sig * 32, sig, q, t0, Tv, lane);
+        CS_STAMP();
+        __syncthreads();
+        CS_STAMP();
+        // ---- P4: u = lrelu(conv3_d1(h) + b4) -> [lft ; sine] channel planes; h[::s'] -> hd ----
+        if (!(dbg & 4)) cs_layer<NTL, 2>(bufA + sig * PLANE, bufB, lo_off, PLANE, W4, 1, 15, kbias + (2 * 2 + sig) * 32, nullptr, nullptr, sig, q, t0, Tv, lane);
+        if (p.hd && !(dbg & 8)) {
+            // lane = decimated column, wave = the (signal, channel) rows sc = wave, wave + 4, ...: every LDS read of a
+            // lane issued before the first store; addresses = one per-lane base + immediates (the slot swizzle moves
+            // octets 0 / 1 up and 2 / 3 down by 32 bytes in rows whose bit 2 is set: two bases)
+            const int j_lo = (t0 + p.hd_s - 1) / p.hd_s;
+            const int j_hi = min((min(t0 + NT, Tv) + p.hd_s - 1) / p.hd_s, hdTv);
+            constexpr int NR = 2 * CS_C / (2 * CS_NQ);
+            for (int j = j_lo + lane; j < j_hi; j += 64) {
+                const int row = j * p.hd_s - t0 + 16;
+                const int rowb = (row ^ ((row >> 2) & 1)) * CS_ROW, rx16 = ((row >> 1) & 2) << 4;
+                const unsigned char* b01 = bufA + rowb + rx16;
+                const unsigned char* b23 = bufA + rowb - rx16;
+#ifdef FASTSVC_ACT_BF16
+                unsigned short v[NR];
+#else
+                float v[NR];
+#endif
+                #pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int sc = wave + 2 * CS_NQ * k;               // (wave-uniform; the compiler sees both values of wave & 3 ...)
+                    const int s = sc >= CS_C ? 1 : 0, c = sc - s * CS_C;
+                    const unsigned char* src = ((c >> 3) < 2 ? b01 : b23) + s * PLANE + ((c >> 3) << 4) + (c & 7) * 2;
+#ifdef FASTSVC_ACT_BF16
+                    v[k] = *reinterpret_cast<const unsigned short*>(src);
+#else
+                    v[k] = (float)*reinterpret_cast<const _Float16*>(src) + (float)*reinterpret_cast<const _Float16*>(src + lo_off);
+#endif
+                }
+                #pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int sc = wave + 2 * CS_NQ * k;
+                    const int s = sc >= CS_C ? 1 : 0, c = sc - s * CS_C;
+#ifdef FASTSVC_ACT_BF16
+                    __builtin_amdgcn_raw_buffer_store_b16(v[k], s ? hdr1 : hdr0, j * 2, c * p.hd_ld * 2, 0);
+#else
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), s ? hdr1 : hdr0, j * 4, c * p.hd_ld * 4, 0);
+#endif
+                }
+            }
+        }
+        CS_STAMP();
+        __syncthreads();
+        CS_STAMP();
+        // ---- P5: [scale ; shift] = conv3_d1([u_lft ; u_sine]) + b5: wave = every fourth output tile, all 3 channel tiles ----
+        if (!(dbg & 16)) {
+            constexpr int NI5 = (NTO + 3) / 4;             // tiles per wave: j = wave + 4 i (the last one may lie past the tile: not stored)
+            const int l15 = lane & 15, g = lane >> 4;
+            int aoff[3];
+            #pragma unroll
+            for (int tap = 0; tap < 3; ++tap) aoff[tap] = cs_off(16 + (tap - 1) + l15, g);
+            float bias5[3];
+            #pragma unroll
+            for (int m = 0; m < 3; ++m) bias5[m] = kb5[m * 16 + l15];
+            f32x4 acc[NI5][3];
+            #pragma unroll
+            for (int i = 0; i < NI5; ++i)
+                #pragma unroll
+                for (int m = 0; m < 3; ++m) acc[i][m] = f32x4{bias5[m], bias5[m], bias5[m], bias5[m]};
+            #pragma unroll
+            for (int i = 0; i < NI5; ++i) {
+                #pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    #pragma unroll
+                    for (int tap = 0; tap < 3; ++tap) {
+                        const CsFrag a = cs_read(bufB + ch * PLANE, aoff[tap] + (wave + 4 * i) * 16 * CS_ROW, lo_off);
+                        #pragma unroll
+                        for (int m = 0; m < 3; ++m) acc[i][m] = cs_prod<false>(W5[ch][tap][m], a, acc[i][m]);
+                    }
+            }
+            #pragma unroll
+            for (int i = 0; i < NI5; ++i) {
+                const int j = wave + 4 * i;
+                if (j >= NTO) continue;                    // (wave-uniform)
+                #pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    unsigned char* srow = bufA + (m * 16 + l15) * GEO::SP;
+                    const f32x4 v = acc[i][m];
+                    const int col = j * 16 + 4 * g;
+#ifdef FASTSVC_ACT_BF16
+                    *reinterpret_cast<cs4*>(srow + col * 2) = __builtin_convertvector(v, cs4);
+#else
+                    *reinterpret_cast<cs_u2*>(srow + col * 4) = cs_u2{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)};
+                    *reinterpret_cast<cs_u2*>(srow + col * 4 + 8) = cs_u2{__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+#endif
+                }
+            }
+        }
+        CS_STAMP();
+        __syncthreads();
+        CS_STAMP();
+        // ---- P0 of the next tile: its signal rows -> LDS (every reader of xs is past the third barrier), the rows
+        // after it requested (past the last tile: offsets out of range, nothing is fetched) ----
+        if (!(dbg & 1)) { xs_commit(); xfetch(t0 + 2 * NT); }
+        // ---- P6: staged rows -> ss, 16 bytes per lane, whole rows ----
+        if (!(dbg & 32)) {
+            // thread = (16-byte chunk k of a row, row cc = tid / 32 + 8 i): one LDS read and one store per chunk, the row
+            // stepping in immediates / scalar offsets
+            constexpr int CH = NT * (int)sizeof(act_t) / 16;       // 16-byte chunks per row
+            constexpr int EPC = 16 / (int)sizeof(act_t);           // elements per chunk
+            static_assert(CH <= 32 || (CH <= 64 && sizeof(act_t) == 4), "chunks of a row fit the lanes that copy it");
+            constexpr int LPR = CH <= 32 ? 32 : 64;                // lanes per row
+            constexpr int RPP = CS_NTHREADS / LPR;                 // rows per pass
+            const int k = tid % LPR, r0 = tid / LPR;
+            const int t = t0 + k * EPC;
+            const bool ok = k < CH && t < Tv;
+            const unsigned char* src = bufA + r0 * GEO::SP + k * 16;
+            const int o = ok ? (r0 * p.ld + t) * (int)sizeof(act_t) : OOB_OFF;
+            #pragma unroll
+            for (int i = 0; i < 2 * CS_C / RPP; ++i) {
+                const u32x4 w = *reinterpret_cast<const u32x4*>(src + i * RPP * GEO::SP);
+                __builtin_amdgcn_raw_buffer_store_b128(w, ssr, o, i * RPP * p.ld * (int)sizeof(act_t), 0);
+            }
+        }
+        CS_STAMP();
+        __syncthreads();                                   // staging reads and xs writes before the next tile's P1
+        CS_STAMP();
+    }
+}
+
+hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream) {
+    constexpr int NTL = 16;
+    using GEO = CsGeom<NTL>;
+    if (p.C != CS_C || (p.T % 8) != 0 || (p.ld % 8) != 0 || (p.tpw & 0xffff) < 1) return hipErrorInvalidValue;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_stage0_kernel<NTL>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS);
+    if (attr != hipSuccess) return attr;
+    const int ntx = (p.T + GEO::NT - 1) / GEO::NT;
+    const int tpw = p.tpw & 0xffff;
+    dim3 grid((ntx + tpw - 1) / tpw, 1, p.B);
+    hipLaunchKernelGGL(cond_stage0_kernel<NTL>, grid, dim3(CS_NTHREADS), GEO::LDS, stream, p);
+    return hipGetLastError();
+}
+
+#ifndef FASTSVC_ACT_BF16
+int cond_stage0_tile_columns() { return CsGeom<16>::NT; }
+#endif
+
+#ifdef FASTSVC_ACT_BF16
+}  // namespace bf16
+#endif
+}  // namespace fastsvc

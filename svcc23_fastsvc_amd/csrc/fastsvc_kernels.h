@@ -176,6 +176,37 @@ struct ConvParams {
     int dbg;                     // ablation switches for profiling (FASTSVC_DBG env var); 0 in production
 };
 
+// A whole conditioning stage 0 as ONE launch (fastsvc_cond.hip; fastsvc.py:164-193 + :220-232 for both signals):
+// raw signals -> [scale ; shift] of the stage (ss) and the COMPACT decimated chain output h[..., ::hd_s] (hd) that
+// the next stage reads; no other tensor of the stage reaches memory.  Index s = 0 loudness, 1 sine excitation.
+struct CondStage0Params {
+    const float* x;              // raw signals, float32: signal s row b at x + s * x_sig + b * x_b
+    long x_sig, x_b;
+    int B, C, T, ld;             // T: padded columns of the batch, ld: row pitch of ss (elements)
+    const int* lens;             // ragged batch: valid columns of utterance b = lens[b] * len_mul
+    int len_mul;
+    const float* in1_w[2];       // c1: (C, 1, 3) plain taps, bias (C)
+    const float* in1_b[2];
+    const float* r1w[2];         // 1x1 residual conv (C_in = 1): weight (C), bias (C)
+    const float* r1b[2];
+    const void* w[3][2];         // c2 / c3 / film.conv: half-precision fragments [tap][16-channel tile][piece][lane][8]
+    const float* bias[3][2];
+    const float* winv[3][2];     // float32 storage: inverse per-channel weight scales of those fragments
+    const float* bnd[4][2];      // float32 storage: (l1, bmax) of c1, c2, c3, film.conv (bounds of the LDS-resident tensors)
+    const float* bnd_r[2];       //   ... and of the 1x1 residual conv
+    const void* w5;              // heads: [32-channel chunk][tap][16-channel tile][piece][lane][8]
+    const float* b5;             // (2C): lft + sine biases summed
+    const float* winv5;
+    const float* amax_in;        // float32 storage: amax entries of the raw signals [s * B + b]
+    float* amax_hd;              // float32 storage: amax entries of hd [s * B + b] (largest |value| written)
+    void* ss;                    // (B, 2C, ld) activation storage type
+    long ss_b;
+    void* hd;                    // (2B, C, hd_ld): signal s utterance b at hd + (s * hd_sig + b * hd_b) elements; null: not written
+    long hd_sig, hd_b;
+    int hd_ld, hd_s;
+    int tpw;                     // consecutive time tiles per workgroup
+};
+
 enum : int { DBG_NO_LOAD = 1, DBG_NO_MFMA = 2, DBG_NO_EPILOGUE = 4, DBG_NO_COMMIT = 8, DBG_NO_WEIGHTS = 16 };
 // The switches exist only in the diagnostic build (-DFASTSVC_DEBUG_SWITCHES: `build --timeline`).  A run-time branch
 // around a pipeline stage is not free even when never taken: hipcc's wait-count bookkeeping merges the path that
@@ -244,6 +275,9 @@ hipError_t launch_amax_inputs(const float* sig, long sig_stride, const float* pp
 hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
                                 int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream);
 
+hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream);
+int cond_stage0_tile_columns();
+
 // speaker bias for all up blocks: p[blk][b][c] = bias + W[c] . (e / max(||e||, 1e-12))
 struct SpkBlock {
     const float* w;     // (C, E)
@@ -267,6 +301,7 @@ hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const flo
 hipError_t launch_pointwise_out(const float* x, const float* w, const float* bias, float* y,
                                 int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream);
 hipError_t launch_act_convert(const float* src, float* dst_bf16, long n, hipStream_t stream);
+hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream);
 }  // namespace bf16
 
 }  // namespace fastsvc

@@ -1095,6 +1095,8 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
         add_shared("c1", "down_c1." + s, 2 * B, d.C, Tk, ae);
         add_shared("c2", "down_c2." + s, 2 * B, d.C, Tk, ae);
         ws.add("down_h." + s, 2 * B, d.C, Tk, ae);               // [lft batch ; sine batch]
+        // h_0[..., ::s_1] compact: what the whole-stage launch of stage 0 hands to stage 1 instead of h_0 (run_cond_stage0)
+        if (k == 0 && n > 1) ws.add("down_hd.1", 2 * B, d.C, Tk / P.down[1].scale, ae);
         if (k + 1 < n) add_shared("film_u", "film_u." + s, B, 2 * d.C, Tk, ae);     // channels [lft ; sine]
         else ws.add("film_u." + s, B, 2 * d.C, Tk, ae);          // (last stage: on the caller's stream)
         ws.add("ss." + s, B, 2 * d.C, Tk, ae);                   // channels [scale ; shift]
@@ -1536,6 +1538,92 @@ hipError_t run_uphead(const UpStage& u, const float* blob, ConvParams p, hipStre
         return prof->end();
     }
     return launch_conv_hx(p, L, stream);
+}
+
+// Stage 0 of the conditioning nets as ONE launch (fastsvc_cond.hip): raw signals -> ss.0 and the compact h_0[..., ::s_1].
+// `done` = false when this call has no such variant (the caller runs the separate launches).
+hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float* sig, long sig_stride, int B, long T, int F,
+                           const int* lengths, float* ss, float* hd, hipStream_t stream, Profiler* prof, bool& done) {
+    done = false;
+    static const int cond_env = std::getenv("FASTSVC_COND") ? std::atoi(std::getenv("FASTSVC_COND")) : 1;
+    static const int tpw_env = std::getenv("FASTSVC_COND_TPW") ? std::atoi(std::getenv("FASTSVC_COND_TPW")) : 0;
+    if (!cond_env || P.n < 2 || P.storage != 1 || g_exact_f32) return hipSuccess;
+    const DownStage& d = P.down[0];
+    const DownStage& d1 = P.down[1];
+    if (d.C != 24 || !d.c2[0].hx || !d.c3[0].hx || !d.film[0].hx || !d.heads.hx || d.c2[0].MW != 2 || d.heads.MW != 3 ||
+        d.heads.nch32 != 2 || !d1.rc1[0].dec2 || (T % 8) != 0 || (T / d1.scale) % 4 != 0 || T % d1.scale != 0)
+        return hipSuccess;
+    const int prec = P.storage == 1 ? 1 : 0;
+    CondStage0Params q;
+    std::memset(&q, 0, sizeof(q));
+    q.x = sig; q.x_sig = sig_stride; q.x_b = T;
+    q.B = B; q.C = d.C; q.T = (int)T; q.ld = (int)T;
+    q.lens = lengths; q.len_mul = (int)(T / F);
+    const PackedConv* layers[3] = {d.c2, d.c3, d.film};
+    for (int s = 0; s < 2; ++s) {
+        q.in1_w[s] = blob + d.c1_raw[s].w_off; q.in1_b[s] = blob + d.c1_raw[s].b_off;
+        q.r1w[s] = blob + d.r_raw[s].w_off; q.r1b[s] = blob + d.r_raw[s].b_off;
+        for (int l = 0; l < 3; ++l) {
+            q.w[l][s] = blob + layers[l][s].hx_off[prec];
+            q.bias[l][s] = blob + layers[l][s].b_off;
+            q.winv[l][s] = blob + layers[l][s].hx_inv_off;
+            q.bnd[l + 1][s] = blob + layers[l][s].bnd_off;
+        }
+        q.bnd[0][s] = blob + d.c1_raw[s].bnd_off;
+        q.bnd_r[s] = blob + d.r_raw[s].bnd_off;
+    }
+    q.w5 = blob + d.heads.hx_off[prec]; q.b5 = blob + d.heads.b_off; q.winv5 = blob + d.heads.hx_inv_off;
+    q.ss = ss; q.ss_b = 2L * d.C * T;
+    q.hd = hd; q.hd_ld = (int)(T / d1.scale); q.hd_s = d1.scale;
+    q.hd_b = (long)d.C * q.hd_ld; q.hd_sig = (long)B * q.hd_b;
+    // tiles per workgroup: the grid runs in whole rounds of the 2 x 256 resident workgroups, at most ~32 tiles each
+    // (a workgroup's start - 24 KB of weight fragments per wave, zeroed tiles - costs about two tiles)
+    const int NT = cond_stage0_tile_columns();
+    const long ntx = (T + NT - 1) / NT;
+    if (tpw_env > 0) q.tpw = tpw_env;
+    else {
+        const long slots = 512, total = ntx * B;
+        const long rounds = std::max<long>(1, (total + slots * 32 - 1) / (slots * 32));
+        long tpw = std::max<long>(1, (total + slots * rounds - 1) / (slots * rounds));
+        // (per-utterance rounding: ceil(ntx / tpw) * B workgroups must not spill into one more round)
+        while (tpw < ntx && ((ntx + tpw - 1) / tpw) * B > slots * rounds) ++tpw;
+        q.tpw = (int)std::min<long>(tpw, ntx);
+    }
+    static const int dbg_env = std::getenv("FASTSVC_COND_DBG") ? std::atoi(std::getenv("FASTSVC_COND_DBG")) : 0;
+    q.tpw |= dbg_env << 16;
+    static unsigned long long* trace_buf = nullptr;
+    static const bool trace_env = std::getenv("FASTSVC_COND_TRACE") != nullptr;
+    if (trace_env && prof) {
+        if (!trace_buf) (void)hipMalloc(&trace_buf, 4 * 64 * 8);
+        (void)hipMemsetAsync(trace_buf, 0, 4 * 64 * 8, stream);
+        q.amax_hd = reinterpret_cast<float*>(trace_buf);
+    }
+    done = true;
+    auto launch = [&]() { return P.storage == 1 ? bf16::launch_cond_stage0(q, stream) : launch_cond_stage0(q, stream); };
+    if (prof) {
+        const double C = d.C, cols = (double)T * B;
+        const double flops = (2.0 * (2.0 * (3.0 * C + C) + 2.0 * 3.0 * 3.0 * C * C) + 2.0 * 3.0 * 4.0 * C * C) * cols;
+        const double ae = P.storage == 1 ? 2.0 : 4.0;
+        const double bytes = (2.0 * 4.0 + 2.0 * C * ae + 2.0 * C * ae / d1.scale) * cols +
+                             4.0 * (double)(2 * (d.c2[0].w_floats + d.c3[0].w_floats + d.film[0].w_floats) + d.heads.w_floats);
+        hipError_t e = prof->begin(stream, "cond.0", P.storage == 1 ? "cond_stage0<x1>" : "cond_stage0<x3>", flops, bytes);
+        if (e != hipSuccess) return e;
+        e = launch();
+        if (e != hipSuccess) return e;
+        e = prof->end();
+        if (trace_env && trace_buf) {
+            unsigned long long h[4 * 64];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h, trace_buf, sizeof(h), hipMemcpyDeviceToHost);
+            for (int w = 0; w < 4; ++w) {
+                std::fprintf(stderr, "[cond trace] wave %d:", w);
+                for (int i = 1; i < 64 && h[w * 64 + i]; ++i) std::fprintf(stderr, " %llu", h[w * 64 + i] - h[w * 64 + i - 1]);
+                std::fprintf(stderr, "\n");
+            }
+        }
+        return e;
+    }
+    return launch();
 }
 
 hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int nsig, long pair_w_stride,
@@ -2106,6 +2194,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     const float* hprev = sigbuf;
     int Cprev = 1;
     long Tprev = T;
+    bool hprev_compact = false;          // hprev already holds h_{k-1}[..., ::s_k] (run_cond_stage0)
     for (int k = 0; k < n; ++k) {
         const DownStage& d = P.down[k];
         Tk = Tk / d.scale;
@@ -2140,7 +2229,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                 float* r = buf("down_r." + s);
                 ConvParams p = base;                                   // r = conv1x1(h_{k-1}[::s])
                 p.x = hprev; p.x_sig = (long)B * Cprev * Tprev; p.x_b = (long)Cprev * Tprev; p.x_T = (int)Tprev;
-                p.mode = MODE_DECIMATE; p.s = d.scale;
+                p.mode = MODE_DECIMATE; p.s = hprev_compact ? 1 : d.scale;
                 p.amax_in = am_prev;
                 static const bool no_dec2 = std::getenv("FASTSVC_NO_DEC2") != nullptr;      // A/B switch
                 if (d.rc1[0].dec2 && !no_dec2) {
@@ -2209,6 +2298,16 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             }
             return FASTSVC_OK;
         };
+        // The WHOLE stage - chain and FiLM net of both signals - as one launch where it has the variant (compact
+        // workspace: h_0 itself is then not materialised, stage 1 reads the compact decimated copy)
+        if (k == 0 && P.compact) {
+            bool whole = false;
+            HIP_TRY(run_cond_stage0(P, blob, sigbuf, sig_stride, B, T, F, lengths, buf("ss.0"), buf("down_hd.1"), stream, prof, whole));
+            if (whole) {
+                hprev = buf("down_hd.1"); Cprev = d.C; Tprev = Tk / P.down[1].scale; hprev_compact = true;
+                continue;
+            }
+        }
         // Stage 0 as ONE launch where it has the variant (MODE_CHAIN1): the staging waves compute the 1 -> C conv
         // from the raw signal, so neither c1 nor c2 reaches memory; a tuning pass times it against the other path
         bool stage_fused = false;
@@ -2297,7 +2396,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                 HIP_TRY(hipEventRecord(ss_ready[k], sf));
             }
         }
-        hprev = h; Cprev = d.C; Tprev = Tk;
+        hprev = h; Cprev = d.C; Tprev = Tk; hprev_compact = false;
     }
 
     // ---- up blocks ----
