@@ -56,8 +56,10 @@ __device__ __forceinline__ f32x4 cs_mfma(cs8 a, cs8 b, f32x4 c) {
 constexpr int CS_ROW = 64;               // bytes of one LDS tile row: 32 channels
 constexpr int CS_FRAG = 1024;            // bytes of one packed weight fragment (64 lanes x 8 halves)
 constexpr int CS_C = 24;                 // channels of the stage this file is compiled for (fastsvc.yaml mid_channels[-1])
-constexpr int CS_NQ = 2;                 // waves per signal
-constexpr int CS_NTHREADS = 2 * CS_NQ * 64;
+constexpr int CS_NQ = 2;                 // waves per (signal, 16-channel output tile): every CS_NQ-th time tile each
+constexpr int CS_NM = 2;                 // 16-channel output tiles of a C -> C layer (C = 24 pads to 32)
+constexpr int CS_NWAVES = 2 * CS_NM * CS_NQ;
+constexpr int CS_NTHREADS = CS_NWAVES * 64;
 
 // same row / slot swizzle as fastsvc_hx.hip (conflict-free ds_read_b128 at any row offset)
 __device__ __forceinline__ int cs_off(int row, int oct) {
@@ -125,103 +127,86 @@ __device__ __forceinline__ void cs_store4_masked(unsigned char* dst, int lo_off,
     }
 }
 
-// One k=3 layer of one signal on this wave's tiles (j = q, q + NQ, ...), swapped operands.
+// 8 consecutive channels of one time step -> the 16-byte slot of a time-major tile row (one store per piece)
+__device__ __forceinline__ void cs_store8_masked(unsigned char* dst, int lo_off, f32x4 a, f32x4 b, unsigned keep) {
+    const cs4 ha = __builtin_convertvector(a, cs4), hb = __builtin_convertvector(b, cs4);
+    const cs_u2 pa = __builtin_bit_cast(cs_u2, ha), pb = __builtin_bit_cast(cs_u2, hb);
+    *reinterpret_cast<u32x4*>(dst) = u32x4{pa.x & keep, pa.y & keep, pb.x & keep, pb.y & keep};
+    if constexpr (CS_NP == 2) {
+        cs4 la, lb;
+        #pragma unroll
+        for (int e = 0; e < 4; ++e) { la[e] = (cs_t)(a[e] - (float)ha[e]); lb[e] = (cs_t)(b[e] - (float)hb[e]); }
+        const cs_u2 qa = __builtin_bit_cast(cs_u2, la), qb = __builtin_bit_cast(cs_u2, lb);
+        *reinterpret_cast<u32x4*>(dst + lo_off) = u32x4{qa.x & keep, qa.y & keep, qb.x & keep, qb.y & keep};
+    }
+}
+
+// One k=3 layer on this wave's share: signal `sig`, 16-channel output tile `m`, time tiles j = q, q + NQ, ...;
+// swapped operands.
 //   in:  plane of the layer's input (time-major rows), rows = t - t0 + 16
-//   out: tile rows out_row0 + 16 j + (lane & 15), channels 4 g .. 4 g + 3 of channel tile m
+//   out: tile rows out_row0 + 16 j + (lane & 15), channels 16 m + 4 g .. + 3
 // KIND 0: lrelu(acc + b) -> own signal's plane;  1: acc + b + rank-1 residual, raw;
 //      2: lrelu(acc + b) -> the 2C-channel plane pair [lft ; sine] the heads read
-// The bias rides in the accumulator's initial value; tiles are walked in groups of G with the NEXT group's products
-// issued ahead of a group's epilogue (two accumulator sets), so that the matrix pipe runs under the VALU work.
+// The bias rides in the accumulator's initial value.  A wave holds 3 weight fragments per layer: four waves per SIMD
+// fit the register file, and their interleaving is what hides the LDS and matrix-pipe latencies here (two waves per
+// SIMD with all of a signal's fragments resident ran 51 % of their cycles parked in waits, measured).
 template <int NTL, int KIND>
 __device__ __forceinline__ void cs_layer(const unsigned char* in_plane, unsigned char* out_planes, int lo_off, int plane_bytes,
-                                         const CsW (&W)[3][2], int dil, int out_row0, const float* kb /* LDS [32] */,
+                                         const CsW (&W)[3], int dil, int out_row0, const float* kb /* LDS [32] */,
+                                         const float* kiv /* LDS [32], float32 storage */,
                                          const float* xs_sig /* LDS, KIND 1 */, const float* r1w_lds /* LDS [32], KIND 1 */,
-                                         int sig, int q, int t0, int Tv, int lane) {
+                                         int sig, int m, int q, int t0, int Tv, int lane) {
     constexpr int NI = NTL / CS_NQ;                    // tiles per wave
-    constexpr int G = 2;                               // tiles per group
+    constexpr int G = 4;                               // tiles per group (independent accumulators between dependent products)
     constexpr int NG = NI / G;
     static_assert(NTL % (CS_NQ * G) == 0, "tiles per wave must be a whole number of groups");
     const int l15 = lane & 15, g = lane >> 4;
     int aoff[3];
     #pragma unroll
     for (int tap = 0; tap < 3; ++tap) aoff[tap] = cs_off(out_row0 + (tap - 1) * dil + l15, g) + q * 16 * CS_ROW;
-    f32x4 kbv[2], r1w[2];
-    int wbase[2];
-    #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int co0 = m * 16 + 4 * g;
-        kbv[m] = *reinterpret_cast<const f32x4*>(kb + co0);
-        if constexpr (KIND == 1) r1w[m] = *reinterpret_cast<const f32x4*>(r1w_lds + co0);
-        if constexpr (KIND == 2) {
-            // (this signal's channel padding co >= C would land on the other signal's channels: its zeros go to the
-            // pair's own padding 2C + 8 .. instead - no divergent store)
-            const int cc0 = co0 < CS_C ? sig * CS_C + co0 : 2 * CS_C + 8 + (co0 - CS_C);
-            wbase[m] = (cc0 >> 5) * plane_bytes + cs_off(out_row0 + l15, (cc0 & 31) >> 3) + (cc0 & 7) * 2 + q * 16 * CS_ROW;
-        } else {
-            wbase[m] = sig * plane_bytes + cs_off(out_row0 + l15, co0 >> 3) + (co0 & 7) * 2 + q * 16 * CS_ROW;
-        }
+    const int co0 = m * 16 + 4 * g;
+    const f32x4 kbv = *reinterpret_cast<const f32x4*>(kb + co0);
+    f32x4 r1w = kbv, kivv = kbv;
+    if constexpr (KIND == 1) r1w = *reinterpret_cast<const f32x4*>(r1w_lds + co0);
+    // float32 storage: the accumulator holds conv * (input tile's scale * weight scale of the channel); one multiply
+    // moves it to the output tile's scale (exact: powers of two); bias and residual enter pre-multiplied (kb, r1w)
+    if constexpr (CS_NP == 2) kivv = *reinterpret_cast<const f32x4*>(kiv + co0);
+    int wbase;
+    if constexpr (KIND == 2) {
+        // (this signal's channel padding co >= C would land on the other signal's channels: its zeros go to the
+        // pair's own padding 2C + 8 .. instead - no divergent store)
+        const int cc0 = co0 < CS_C ? sig * CS_C + co0 : 2 * CS_C + 8 + (co0 - CS_C);
+        wbase = (cc0 >> 5) * plane_bytes + cs_off(out_row0 + l15, (cc0 & 31) >> 3) + (cc0 & 7) * 2 + q * 16 * CS_ROW;
+    } else {
+        wbase = sig * plane_bytes + cs_off(out_row0 + l15, co0 >> 3) + (co0 & 7) * 2 + q * 16 * CS_ROW;
     }
-    const int tbase = t0 - 16 + out_row0;              // time of row out_row0
-    // Software pipeline over the groups, written out: the LDS reads of group n + 1, the matrix products of group n and
-    // the VALU epilogue of group n - 1 are independent and sit in one scheduling region per step; the group barriers
-    // below ask for them interleaved (one fragment read and ~4 VALU instructions per product) instead of the
-    // read -> wait -> product chains the default schedule made of it (118 cycles per product, measured).
-    f32x4 acc[2][G][2];
-    CsFrag fr[2][G][3];
-    auto fetch = [&](int grp, CsFrag (&f)[G][3]) {
-        #pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
-            #pragma unroll
-            for (int ii = 0; ii < G; ++ii) f[ii][tap] = cs_read(in_plane, aoff[tap] + (CS_NQ * (grp * G + ii)) * 16 * CS_ROW, lo_off);
-    };
-    auto products = [&](int grp, const CsFrag (&f)[G][3], f32x4 (&ac)[G][2]) {
-        #pragma unroll
-        for (int ii = 0; ii < G; ++ii) {
-            const int j = q + CS_NQ * (grp * G + ii);
-            #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                if constexpr (KIND == 1) ac[ii][m] = r1w[m] * xs_sig[out_row0 + 16 * j + l15] + kbv[m];
-                else ac[ii][m] = kbv[m];
-            }
-        }
-        #pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
-            #pragma unroll
-            for (int ii = 0; ii < G; ++ii)
-                #pragma unroll
-                for (int m = 0; m < 2; ++m) ac[ii][m] = cs_prod<true>(W[tap][m], f[ii][tap], ac[ii][m]);
-    };
-    auto finish = [&](int grp, const f32x4 (&ac)[G][2]) {
-        #pragma unroll
-        for (int ii = 0; ii < G; ++ii) {
-            const int j = q + CS_NQ * (grp * G + ii);
-            // outside the utterance: the next conv's zero padding - applied to the PACKED values (one AND per register)
-            const unsigned keep = (unsigned)(tbase + 16 * j + l15) < (unsigned)Tv ? 0xffffffffu : 0u;
-            #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                f32x4 v = ac[ii][m];
-                if constexpr (KIND != 1) v = cs_lrelu4(v);
-                cs_store4_masked(out_planes + wbase[m] + (CS_NQ * (grp * G + ii)) * 16 * CS_ROW, lo_off, v, keep);
-            }
-        }
-    };
-    fetch(0, fr[0]);
+    const int tbase = t0 - 16 + out_row0 + l15;        // this lane's time in tile 0
     #pragma unroll
-    for (int grp = 0; grp <= NG; ++grp) {
-        if (grp + 1 < NG) fetch(grp + 1, fr[(grp + 1) & 1]);
-        if (grp < NG) products(grp, fr[grp & 1], acc[grp & 1]);
-        if (grp > 0) finish(grp - 1, acc[(grp - 1) & 1]);
-        if (grp > 0 && grp < NG) {
-            // region = G*3 fragment reads, G*6 (x3 split) products, ~G*2*12 VALU, G*2 LDS stores
-            #pragma unroll
-            for (int k = 0; k < G * 6; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, CS_NP == 2 ? 3 : 1, 0);    // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                      // VALU
-                if (k < G * 3) __builtin_amdgcn_sched_group_barrier(0x100, CS_NP, 0);   // DS read
-                if (k % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, CS_NP, 0);  // DS write
-            }
+    for (int grp = 0; grp < NG; ++grp) {
+        f32x4 acc[G];
+        #pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const int jr = CS_NQ * (grp * G + ii);     // tile index minus q
+            if constexpr (KIND == 1) acc[ii] = r1w * xs_sig[out_row0 + 16 * (q + jr) + l15] + kbv;
+            else acc[ii] = kbv;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            #pragma unroll
+            for (int ii = 0; ii < G; ++ii) {
+                const CsFrag a = cs_read(in_plane, aoff[tap] + (CS_NQ * (grp * G + ii)) * 16 * CS_ROW, lo_off);
+                acc[ii] = cs_prod<true>(W[tap], a, acc[ii]);
+            }
+        #pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const int jr = CS_NQ * (grp * G + ii);
+            // outside the utterance: the next conv's zero padding - applied to the PACKED values (one AND per register)
+            const unsigned keep = (unsigned)(tbase + 16 * (q + jr)) < (unsigned)Tv ? 0xffffffffu : 0u;
+            f32x4 v = acc[ii];
+            if constexpr (CS_NP == 2) v = v * kivv;
+            if constexpr (KIND != 1) v = cs_lrelu4(v);
+            cs_store4_masked(out_planes + wbase + jr * 16 * CS_ROW, lo_off, v, keep);
+        }
     }
 }
 
@@ -232,14 +217,14 @@ struct CsGeom {
     static constexpr int ROWS = NT + 40;               // LDS rows: row r <-> t = t0 - 16 + r (the deepest read ends at NT + 34)
     static constexpr int PLANE = CS_NP * ROWS * CS_ROW;
     static constexpr int XS_BYTES = 2 * ROWS * 4;
-    static constexpr int CONST_FLOATS = 2 * 32 * 4 /* in1 w0 w1 w2 b */ + 2 * 32 /* r1 w */ + 3 * 2 * 32 /* biases */ + 64 /* heads */;
+    static constexpr int CONST_FLOATS = 2 * 32 * 4 /* in1 w0 w1 w2 b */ + 2 * 32 /* r1 w */ + 2 * 3 * 2 * 32 /* biases, inverse scales */ + 2 * 64 /* heads */;
     static constexpr int SP = NT * (int)sizeof(act_t) + 16;  // staging pitch of a scale / shift row (bytes; 16-byte aligned rows)
     static constexpr size_t LDS = XS_BYTES + CONST_FLOATS * 4 + 4 * (size_t)PLANE;
     static_assert(2 * CS_C * SP <= 2 * PLANE, "staging rows must fit the planes they alias");
 };
 
 template <int NTL>
-__global__ __launch_bounds__(CS_NTHREADS, 2)
+__global__ __launch_bounds__(CS_NTHREADS, CS_NP == 1 ? 4 : 2)
 void cond_stage0_kernel(const CondStage0Params p) {
     using GEO = CsGeom<NTL>;
     constexpr int NT = GEO::NT, ROWS = GEO::ROWS, PLANE = GEO::PLANE, NTO = GEO::NTO;
@@ -249,8 +234,10 @@ void cond_stage0_kernel(const CondStage0Params p) {
     float* kin1 = xs + 2 * ROWS;                                                  // [2][w0 w1 w2 b][32] of the 1 -> C conv
     float* kr1 = kin1 + 2 * 32 * 4;                                               // [2][32]  rank-1 residual weights (1x1 conv, C_in = 1; its bias joins c3's)
     float* kbias = kr1 + 2 * 32;                                                  // [3][2][32]  c2 / c3 / film.conv
-    float* kb5 = kbias + 3 * 2 * 32;                                              // [64] heads
-    unsigned char* bufA = reinterpret_cast<unsigned char*>(kb5 + 64);             // 2 planes: c1 -> h -> output staging
+    float* kinv = kbias + 3 * 2 * 32;                                             // [3][2][32]  float32 storage: inverse operand scales of those layers
+    float* kb5 = kinv + 3 * 2 * 32;                                               // [64] heads' bias
+    float* k5inv = kb5 + 64;                                                      // [64] heads' inverse operand scales
+    unsigned char* bufA = reinterpret_cast<unsigned char*>(k5inv + 64);           // 2 planes: c1 -> h -> output staging
     unsigned char* bufB = bufA + 2 * PLANE;                                       // 2 planes: c2 -> u
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,41 +250,77 @@ void cond_stage0_kernel(const CondStage0Params p) {
     if (tile_begin >= tile_end) return;
 
     // ---- per-wave weight fragments, resident for the whole launch ----
-    const int sig = wave & 1, q = wave >> 1;
-    CsW W2[3][2], W3[3][2], W4[3][2];
+    // layers: wave = (signal, output channel tile m, time-tile phase q); heads: wave = (output channel tile m5 of 3,
+    // half of the output tiles) for waves 0 .. 5 (waves 6, 7 copy the next tile's signal rows meanwhile)
+    const int sig = wave & 1, mt = (wave >> 1) & 1, q = wave >> 2;
+    CsW W2[3], W3[3], W4[3];
     #pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
-        #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const long fo = (long)(tap * 2 + m) * CS_NP * CS_FRAG;
-            W2[tap][m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[0][sig]) + fo, lane);
-            W3[tap][m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[1][sig]) + fo, lane);
-            W4[tap][m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[2][sig]) + fo, lane);
-        }
-    CsW W5[2][3][3];                                                              // heads: [K chunk][tap][output channel tile]
+    for (int tap = 0; tap < 3; ++tap) {
+        const long fo = (long)(tap * 2 + mt) * CS_NP * CS_FRAG;
+        W2[tap] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[0][sig]) + fo, lane);
+        W3[tap] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[1][sig]) + fo, lane);
+        W4[tap] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[2][sig]) + fo, lane);
+    }
+    const int m5 = wave % 3, half5 = wave / 3;
+    CsW W5[2][3];                                                                 // heads: [K chunk][tap] of channel tile m5
     #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
         #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
-            #pragma unroll
-            for (int m = 0; m < 3; ++m)
-                W5[ch][tap][m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w5) + (long)((ch * 3 + tap) * 3 + m) * CS_NP * CS_FRAG, lane);
+            W5[ch][tap] = cs_wload(reinterpret_cast<const unsigned char*>(p.w5) + (long)((ch * 3 + tap) * 3 + m5) * CS_NP * CS_FRAG, lane);
 
     // ---- constants (no tile is zeroed: every row / channel a needed output depends on is written before it is read -
     // c1 incl. its channel padding by P1, c2 / h with padding by their layers - and what feeds only the unneeded halo
     // columns of a layer never reaches a stored value: columns are independent in a convolution) ----
+    // float32 storage (split-binary16 products): every LDS-resident tensor of utterance b is held times a power of two
+    // that puts its BOUND into [2^14, 2^15) - the bound of the raw signal is its measured maximum (amax_in), the bounds of
+    // c1, c2, h, u follow through the layers' (l1, bmax): |conv(x)| <= l1 max|x| + bmax (ConvParams, "dynamic range").
+    // sc[k][s]: scale of c1, c2, h (per signal) and of u (k = 3: one scale for the channel pair the heads contract over).
+    float sc[4][2] = {{1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}};
+    if constexpr (CS_NP == 2) {
+        float bu = 0.f;
+        #pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float ax = amax_read(p.amax_in, s * p.B + b);
+            const float b1 = ax * p.bnd[0][s][0] + p.bnd[0][s][1];
+            const float b2 = b1 * p.bnd[1][s][0] + p.bnd[1][s][1];
+            const float bh = b2 * p.bnd[2][s][0] + p.bnd[2][s][1] + ax * p.bnd_r[s][0] + p.bnd_r[s][1];
+            bu = fmaxf(bu, bh * p.bnd[3][s][0] + p.bnd[3][s][1]);
+            sc[0][s] = hx_scale_for(b1); sc[1][s] = hx_scale_for(b2); sc[2][s] = hx_scale_for(bh);
+        }
+        sc[3][0] = sc[3][1] = hx_scale_for(bu);
+    }
     for (int i = tid; i < 2 * 32; i += CS_NTHREADS) {
         const int s = i >> 5, c = i & 31;
         const bool ok = c < CS_C;
         const float* wp = p.in1_w[s] + (ok ? c : 0) * 3;
+        // (the 1 -> C conv runs on the VALU in float32: its taps carry c1's scale)
         #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) kin1[(s * 4 + tap) * 32 + c] = ok ? wp[tap] : 0.f;
-        kin1[(s * 4 + 3) * 32 + c] = ok ? p.in1_b[s][c] : 0.f;
-        kr1[s * 32 + c] = ok ? p.r1w[s][c] : 0.f;
+        for (int tap = 0; tap < 3; ++tap) kin1[(s * 4 + tap) * 32 + c] = ok ? wp[tap] * sc[0][s] : 0.f;
+        kin1[(s * 4 + 3) * 32 + c] = ok ? p.in1_b[s][c] * sc[0][s] : 0.f;
         #pragma unroll
-        for (int l = 0; l < 3; ++l)                     // (c3's bias carries the 1x1 residual conv's: both join h)
-            kbias[(l * 2 + s) * 32 + c] = ok ? p.bias[l][s][c] + (l == 1 ? p.r1b[s][c] : 0.f) : 0.f;
-        kb5[i] = i < 2 * CS_C ? p.b5[i] : 0.f;
+        for (int l = 0; l < 3; ++l) {
+            // accumulator scale of layer l: input tile's scale / inverse weight scale of the channel
+            float as = 1.f, os = 1.f;
+            if constexpr (CS_NP == 2) {
+                const float wi = ok ? p.winv[l][s][c] : 1.f;
+                as = sc[l][s] / wi;
+                os = sc[l + 1][s];
+                kinv[(l * 2 + s) * 32 + c] = ok ? os / as : 0.f;
+            }
+            // (c3's bias carries the 1x1 residual conv's: both join h)
+            kbias[(l * 2 + s) * 32 + c] = ok ? (p.bias[l][s][c] + (l == 1 ? p.r1b[s][c] : 0.f)) * as : 0.f;
+            if (l == 1) kr1[s * 32 + c] = ok ? p.r1w[s][c] * as : 0.f;
+        }
+        {
+            const bool ok5 = i < 2 * CS_C;
+            float as = 1.f;
+            if constexpr (CS_NP == 2) {
+                as = sc[3][0] / (ok5 ? p.winv5[i] : 1.f);
+                k5inv[i] = ok5 ? 1.f / as : 0.f;
+            }
+            kb5[i] = ok5 ? p.b5[i] * as : 0.f;
+        }
     }
     const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(p.x + (long)b * p.x_b, Tv);
     const __amdgpu_buffer_rsrc_t xr1 = make_rsrc(p.x + p.x_sig + (long)b * p.x_b, Tv);
@@ -320,7 +343,7 @@ void cond_stage0_kernel(const CondStage0Params p) {
         }
     };
     xfetch(tile_begin * NT);
-#ifdef FASTSVC_COND_TRACE
+#if defined(FASTSVC_COND_TRACE) && defined(FASTSVC_ACT_BF16)
     unsigned long long* trace = (p.amax_hd && blockIdx.x == 1 && blockIdx.z == 0 && lane == 0)
         ? reinterpret_cast<unsigned long long*>(p.amax_hd) + wave * 64 : nullptr;
     int tri = 0;
@@ -340,6 +363,7 @@ void cond_stage0_kernel(const CondStage0Params p) {
     };
     xs_commit();
     xfetch((tile_begin + 1) * NT);
+    float hmax[2] = {0.f, 0.f};                            // float32 storage: largest |value| this lane wrote to hd, per signal
     __syncthreads();
     CS_STAMP();
     for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -348,12 +372,12 @@ void cond_stage0_kernel(const CondStage0Params p) {
         // ---- P1: c1 = lrelu(conv3(lrelu(x)) + b1) on the VALU, rows 8 .. NT + 24: thread = row, one (signal, octet of 8
         // channels) per step, whose taps are wave-uniform LDS reads ----
         if (!(dbg & 2)) {
-            static_assert(16 * NTL == CS_NTHREADS, "one c1 row per thread");
-            const int r = 8 + tid;
+            static_assert(2 * 16 * NTL == CS_NTHREADS, "one (signal, c1 row) per thread");
+            const int r = 8 + (tid & (16 * NTL - 1));
             const int t = t0 - 16 + r;
             const unsigned keep = (unsigned)t < (unsigned)Tv ? 0xffffffffu : 0u;    // outside the utterance: c2's zero padding
-            #pragma unroll
-            for (int s1 = 0; s1 < 2; ++s1) {
+            {
+                const int s1 = wave / (CS_NWAVES / 2);
                 const float* xrow = xs + s1 * ROWS;
                 float xa = xrow[r - 1], xb = xrow[r], xc = xrow[r + 1];
                 xa = fmaxf(xa, xa * LRELU_SLOPE); xb = fmaxf(xb, xb * LRELU_SLOPE); xc = fmaxf(xc, xc * LRELU_SLOPE);
@@ -376,8 +400,7 @@ void cond_stage0_kernel(const CondStage0Params p) {
                         o4[hh] = cs_lrelu4(o4[hh]);
                     }
                     unsigned char* dst = bufA + s1 * PLANE + cs_off(r, oct);
-                    cs_store4_masked(dst, lo_off, o4[0], keep);
-                    cs_store4_masked(dst + 8, lo_off, o4[1], keep);
+                    cs_store8_masked(dst, lo_off, o4[0], o4[1], keep);
                 }
                 // channel padding 24 .. 31 (the staging rows of the previous tile lay here)
                 unsigned char* pad = bufA + s1 * PLANE + cs_off(r, 3);
@@ -389,24 +412,24 @@ void cond_stage0_kernel(const CondStage0Params p) {
         __syncthreads();
         CS_STAMP();
         // ---- P2: c2 = lrelu(conv3_d2(c1) + b2): output rows 10 .. (t = -6 ..) ----
-        if (!(dbg & 4)) cs_layer<NTL, 0>(bufA + sig * PLANE, bufB, lo_off, PLANE, W2, 2, 10, kbias + (0 * 2 + sig) * 32, nullptr, nullptr, sig, q, t0, Tv, lane);
+        if (!(dbg & 4)) cs_layer<NTL, 0>(bufA + sig * PLANE, bufB, lo_off, PLANE, W2, 2, 10, kbias + (0 * 2 + sig) * 32, kinv + (0 * 2 + sig) * 32, nullptr, nullptr, sig, mt, q, t0, Tv, lane);
         CS_STAMP();
         __syncthreads();
         CS_STAMP();
         // ---- P3: h = conv3_d4(c2) + b3 + (r1w x + r1b): output rows 14 .. (t = -2 ..) ----
-        if (!(dbg & 4)) cs_layer<NTL, 1>(bufB + sig * PLANE, bufA, lo_off, PLANE, W3, 4, 14, kbias + (1 * 2 + sig) * 32, xs + sig * ROWS, kr1 + sig * 32, sig, q, t0, Tv, lane);
+        if (!(dbg & 4)) cs_layer<NTL, 1>(bufB + sig * PLANE, bufA, lo_off, PLANE, W3, 4, 14, kbias + (1 * 2 + sig) * 32, kinv + (1 * 2 + sig) * 32, xs + sig * ROWS, kr1 + sig * 32, sig, mt, q, t0, Tv, lane);
         CS_STAMP();
         __syncthreads();
         CS_STAMP();
         // ---- P4: u = lrelu(conv3_d1(h) + b4) -> [lft ; sine] channel planes; h[::s'] -> hd ----
-        if (!(dbg & 4)) cs_layer<NTL, 2>(bufA + sig * PLANE, bufB, lo_off, PLANE, W4, 1, 15, kbias + (2 * 2 + sig) * 32, nullptr, nullptr, sig, q, t0, Tv, lane);
+        if (!(dbg & 4)) cs_layer<NTL, 2>(bufA + sig * PLANE, bufB, lo_off, PLANE, W4, 1, 15, kbias + (2 * 2 + sig) * 32, kinv + (2 * 2 + sig) * 32, nullptr, nullptr, sig, mt, q, t0, Tv, lane);
         if (p.hd && !(dbg & 8)) {
             // lane = decimated column, wave = the (signal, channel) rows sc = wave, wave + 4, ...: every LDS read of a
             // lane issued before the first store; addresses = one per-lane base + immediates (the slot swizzle moves
             // octets 0 / 1 up and 2 / 3 down by 32 bytes in rows whose bit 2 is set: two bases)
             const int j_lo = (t0 + p.hd_s - 1) / p.hd_s;
             const int j_hi = min((min(t0 + NT, Tv) + p.hd_s - 1) / p.hd_s, hdTv);
-            constexpr int NR = 2 * CS_C / (2 * CS_NQ);
+            constexpr int NR = 2 * CS_C / CS_NWAVES;
             for (int j = j_lo + lane; j < j_hi; j += 64) {
                 const int row = j * p.hd_s - t0 + 16;
                 const int rowb = (row ^ ((row >> 2) & 1)) * CS_ROW, rx16 = ((row >> 1) & 2) << 4;
@@ -416,21 +439,23 @@ void cond_stage0_kernel(const CondStage0Params p) {
                 unsigned short v[NR];
 #else
                 float v[NR];
+                const float ih0 = 1.0f / sc[2][0], ih1 = 1.0f / sc[2][1];      // (exact: powers of two)
 #endif
                 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
-                    const int sc = wave + 2 * CS_NQ * k;               // (wave-uniform; the compiler sees both values of wave & 3 ...)
+                    const int sc = wave + CS_NWAVES * k;               // (wave-uniform)
                     const int s = sc >= CS_C ? 1 : 0, c = sc - s * CS_C;
                     const unsigned char* src = ((c >> 3) < 2 ? b01 : b23) + s * PLANE + ((c >> 3) << 4) + (c & 7) * 2;
 #ifdef FASTSVC_ACT_BF16
                     v[k] = *reinterpret_cast<const unsigned short*>(src);
 #else
-                    v[k] = (float)*reinterpret_cast<const _Float16*>(src) + (float)*reinterpret_cast<const _Float16*>(src + lo_off);
+                    v[k] = ((float)*reinterpret_cast<const _Float16*>(src) + (float)*reinterpret_cast<const _Float16*>(src + lo_off)) * (s ? ih1 : ih0);
+                    hmax[s] = fmaxf(hmax[s], fabsf(v[k]));
 #endif
                 }
                 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
-                    const int sc = wave + 2 * CS_NQ * k;
+                    const int sc = wave + CS_NWAVES * k;
                     const int s = sc >= CS_C ? 1 : 0, c = sc - s * CS_C;
 #ifdef FASTSVC_ACT_BF16
                     __builtin_amdgcn_raw_buffer_store_b16(v[k], s ? hdr1 : hdr0, j * 2, c * p.hd_ld * 2, 0);
@@ -443,46 +468,46 @@ void cond_stage0_kernel(const CondStage0Params p) {
         CS_STAMP();
         __syncthreads();
         CS_STAMP();
-        // ---- P5: [scale ; shift] = conv3_d1([u_lft ; u_sine]) + b5: wave = every fourth output tile, all 3 channel tiles ----
-        if (!(dbg & 16)) {
-            constexpr int NI5 = (NTO + 3) / 4;             // tiles per wave: j = wave + 4 i (the last one may lie past the tile: not stored)
+        // ---- P5: [scale ; shift] = conv3_d1([u_lft ; u_sine]) + b5: wave = (channel tile m5, half of the output tiles) ----
+        if (!(dbg & 16) && wave < 6) {
+            constexpr int NH = (NTO + 1) / 2;              // tiles per half (the second half may be one short)
+            const int jb = half5 * NH;
             const int l15 = lane & 15, g = lane >> 4;
             int aoff[3];
             #pragma unroll
-            for (int tap = 0; tap < 3; ++tap) aoff[tap] = cs_off(16 + (tap - 1) + l15, g);
-            float bias5[3];
+            for (int tap = 0; tap < 3; ++tap) aoff[tap] = cs_off(16 + (tap - 1) + l15, g) + jb * 16 * CS_ROW;
+            const float bias = kb5[m5 * 16 + l15];
+            float oinv = 1.f;
+            if constexpr (CS_NP == 2) oinv = k5inv[m5 * 16 + l15];
+            unsigned char* srow = bufA + (m5 * 16 + l15) * GEO::SP + (jb * 16 + 4 * g) * (int)sizeof(act_t);
+            constexpr int G5 = 4;
             #pragma unroll
-            for (int m = 0; m < 3; ++m) bias5[m] = kb5[m * 16 + l15];
-            f32x4 acc[NI5][3];
-            #pragma unroll
-            for (int i = 0; i < NI5; ++i)
+            for (int i0 = 0; i0 < NH; i0 += G5) {
+                f32x4 acc[G5];
                 #pragma unroll
-                for (int m = 0; m < 3; ++m) acc[i][m] = f32x4{bias5[m], bias5[m], bias5[m], bias5[m]};
-            #pragma unroll
-            for (int i = 0; i < NI5; ++i) {
+                for (int ii = 0; ii < G5; ++ii) acc[ii] = f32x4{bias, bias, bias, bias};
                 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch)
                     #pragma unroll
-                    for (int tap = 0; tap < 3; ++tap) {
-                        const CsFrag a = cs_read(bufB + ch * PLANE, aoff[tap] + (wave + 4 * i) * 16 * CS_ROW, lo_off);
+                    for (int tap = 0; tap < 3; ++tap)
                         #pragma unroll
-                        for (int m = 0; m < 3; ++m) acc[i][m] = cs_prod<false>(W5[ch][tap][m], a, acc[i][m]);
-                    }
-            }
-            #pragma unroll
-            for (int i = 0; i < NI5; ++i) {
-                const int j = wave + 4 * i;
-                if (j >= NTO) continue;                    // (wave-uniform)
+                        for (int ii = 0; ii < G5; ++ii) {
+                            if (i0 + ii >= NH) continue;
+                            const CsFrag a = cs_read(bufB + ch * PLANE, aoff[tap] + (i0 + ii) * 16 * CS_ROW, lo_off);
+                            acc[ii] = cs_prod<false>(W5[ch][tap], a, acc[ii]);
+                        }
                 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    unsigned char* srow = bufA + (m * 16 + l15) * GEO::SP;
-                    const f32x4 v = acc[i][m];
-                    const int col = j * 16 + 4 * g;
+                for (int ii = 0; ii < G5; ++ii) {
+                    if (i0 + ii >= NH) continue;
+                    if (jb + i0 + ii >= NTO) continue;     // (wave-uniform: the odd tile of the second half)
+                    f32x4 v = acc[ii];
+                    if constexpr (CS_NP == 2) v = v * oinv;
+                    unsigned char* dst = srow + (i0 + ii) * 16 * (int)sizeof(act_t);
 #ifdef FASTSVC_ACT_BF16
-                    *reinterpret_cast<cs4*>(srow + col * 2) = __builtin_convertvector(v, cs4);
+                    *reinterpret_cast<cs4*>(dst) = __builtin_convertvector(v, cs4);
 #else
-                    *reinterpret_cast<cs_u2*>(srow + col * 4) = cs_u2{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)};
-                    *reinterpret_cast<cs_u2*>(srow + col * 4 + 8) = cs_u2{__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+                    // (not __builtin_bit_cast(unsigned, v.y): on a vector-element lvalue this hipcc reads element 0)
+                    *reinterpret_cast<f32x4*>(dst) = v;
 #endif
                 }
             }
@@ -516,6 +541,18 @@ void cond_stage0_kernel(const CondStage0Params p) {
         CS_STAMP();
         __syncthreads();                                   // staging reads and xs writes before the next tile's P1
         CS_STAMP();
+    }
+    if constexpr (CS_NP == 2) {
+        // the maxima of what went to hd (the scale of stage 1's split-binary16 staging, ConvParams::amax_in): one atomic per
+        // wave and signal, spread over the entry's 8 slots (fastsvc_device.inc)
+        if (p.amax_hd && p.hd) {
+            #pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)wave_max_u32_lane63(__builtin_bit_cast(unsigned, hmax[s])), 63);
+                if (lane == 0 && a != 0u)
+                    atomicMax(reinterpret_cast<unsigned*>(p.amax_hd) + (s * p.B + b) * AMAX_ENTRY + ((blockIdx.x + wave) & (AMAX_W - 1)) * AMAX_STRIDE, a);
+            }
+        }
     }
 }
 

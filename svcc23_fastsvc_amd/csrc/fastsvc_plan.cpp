@@ -1543,11 +1543,13 @@ hipError_t run_uphead(const UpStage& u, const float* blob, ConvParams p, hipStre
 // Stage 0 of the conditioning nets as ONE launch (fastsvc_cond.hip): raw signals -> ss.0 and the compact h_0[..., ::s_1].
 // `done` = false when this call has no such variant (the caller runs the separate launches).
 hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float* sig, long sig_stride, int B, long T, int F,
-                           const int* lengths, float* ss, float* hd, hipStream_t stream, Profiler* prof, bool& done) {
+                           const int* lengths, float* ss, float* hd, const float* amax_in, float* amax_hd, hipStream_t stream,
+                           Profiler* prof, bool& done) {
     done = false;
     static const int cond_env = std::getenv("FASTSVC_COND") ? std::atoi(std::getenv("FASTSVC_COND")) : 1;
     static const int tpw_env = std::getenv("FASTSVC_COND_TPW") ? std::atoi(std::getenv("FASTSVC_COND_TPW")) : 0;
-    if (!cond_env || P.n < 2 || P.storage != 1 || g_exact_f32) return hipSuccess;
+    // (float32 storage needs the measured maxima of the raw signals: not with FASTSVC_NO_AMAX_SCAN)
+    if (!cond_env || P.n < 2 || g_exact_f32 || (P.storage == 0 && (!amax_in || !amax_hd))) return hipSuccess;
     const DownStage& d = P.down[0];
     const DownStage& d1 = P.down[1];
     if (d.C != 24 || !d.c2[0].hx || !d.c3[0].hx || !d.film[0].hx || !d.heads.hx || d.c2[0].MW != 2 || d.heads.MW != 3 ||
@@ -1573,6 +1575,7 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
         q.bnd_r[s] = blob + d.r_raw[s].bnd_off;
     }
     q.w5 = blob + d.heads.hx_off[prec]; q.b5 = blob + d.heads.b_off; q.winv5 = blob + d.heads.hx_inv_off;
+    q.amax_in = P.storage == 0 ? amax_in : nullptr; q.amax_hd = P.storage == 0 ? amax_hd : nullptr;
     q.ss = ss; q.ss_b = 2L * d.C * T;
     q.hd = hd; q.hd_ld = (int)(T / d1.scale); q.hd_s = d1.scale;
     q.hd_b = (long)d.C * q.hd_ld; q.hd_sig = (long)B * q.hd_b;
@@ -1582,7 +1585,7 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
     const long ntx = (T + NT - 1) / NT;
     if (tpw_env > 0) q.tpw = tpw_env;
     else {
-        const long slots = 512, total = ntx * B;
+        const long slots = P.storage == 1 ? 512 : 256, total = ntx * B;     // workgroups resident at a time (LDS: two per CU in bfloat16 storage, one in float32)
         const long rounds = std::max<long>(1, (total + slots * 32 - 1) / (slots * 32));
         long tpw = std::max<long>(1, (total + slots * rounds - 1) / (slots * rounds));
         // (per-utterance rounding: ceil(ntx / tpw) * B workgroups must not spill into one more round)
@@ -1594,8 +1597,8 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
     static unsigned long long* trace_buf = nullptr;
     static const bool trace_env = std::getenv("FASTSVC_COND_TRACE") != nullptr;
     if (trace_env && prof) {
-        if (!trace_buf) (void)hipMalloc(&trace_buf, 4 * 64 * 8);
-        (void)hipMemsetAsync(trace_buf, 0, 4 * 64 * 8, stream);
+        if (!trace_buf) (void)hipMalloc(&trace_buf, 8 * 64 * 8);
+        (void)hipMemsetAsync(trace_buf, 0, 8 * 64 * 8, stream);
         q.amax_hd = reinterpret_cast<float*>(trace_buf);
     }
     done = true;
@@ -2302,7 +2305,8 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         // workspace: h_0 itself is then not materialised, stage 1 reads the compact decimated copy)
         if (k == 0 && P.compact) {
             bool whole = false;
-            HIP_TRY(run_cond_stage0(P, blob, sigbuf, sig_stride, B, T, F, lengths, buf("ss.0"), buf("down_hd.1"), stream, prof, whole));
+            HIP_TRY(run_cond_stage0(P, blob, sigbuf, sig_stride, B, T, F, lengths, buf("ss.0"), buf("down_hd.1"),
+                                    (P.storage == 0 && !no_scan) ? amax_inb : nullptr, am("down_h.0"), stream, prof, whole));
             if (whole) {
                 hprev = buf("down_hd.1"); Cprev = d.C; Tprev = Tk / P.down[1].scale; hprev_compact = true;
                 continue;

@@ -106,6 +106,9 @@ class FastSVCGenerator(nn.Module):
     # "float32" (the parity path) or "bfloat16": workspace tensors stored as bf16 (BASELINE config 3:
     # half the HBM traffic of the narrow layers, bf16-activation accuracy).  Set before the first forward.
     activation_storage = "float32"
+    # True: never build an autograd graph (the plain HIP forward whatever the grad mode says) - for inference code
+    # that does not wrap its calls in torch.no_grad()
+    inference_only = False
 
     def __init__(self, in_channels: int = 144, mid_channels: Sequence[int] = (192, 96, 48, 24),
                  upsampling_scales: Sequence[int] = (2, 4, 4, 5), out_channels: int = 1,
@@ -262,9 +265,10 @@ class FastSVCGenerator(nn.Module):
         the padding of the output is zero.  ``out`` (inference only): a contiguous float32 (B, out_channels, T)
         tensor the waveform is written into (e.g. a collective's send buffer).
 
-        Autograd: the route that saves inputs / parameters for a backward pass is taken in training mode
-        (``model.train()``), or when an INPUT requires grad; ``model.eval()`` always runs the plain HIP forward, with
-        or without ``torch.no_grad()`` - as inference code expects (no graph retained, ``lengths`` allowed)."""
+        Autograd: whenever grad mode is enabled and a parameter or an input requires grad, the output carries a graph
+        (``train()`` and ``eval()`` alike, as for any ``nn.Module``).  The plain HIP forward runs under
+        ``torch.no_grad()`` / ``torch.inference_mode()``, with ``self.inference_only = True``, or - in ``eval()`` - when an
+        inference extension (``lengths``, ``out=``) is used."""
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise FastSVCError("FastSVCGenerator (HIP) needs GPU tensors; there is no CPU fallback "
                                "(the CPU oracle lives in oracle/ and is test infrastructure only)")
@@ -274,9 +278,15 @@ class FastSVCGenerator(nn.Module):
                              f"{s.shape[-1]} / loudness {l.shape[-1]} samples")
         if spk_emb is not None and not self.use_spk_emb:
             raise ValueError("spk_emb given but the generator was built with use_spk_emb=False")
-        needs_grad = torch.is_grad_enabled() and (
-            (self.training and any(p.requires_grad for p in self.parameters())) or
+        # nn.Module semantics (and the reference's): eval() does not detach - with grad enabled and parameters that
+        # require grad the output carries a graph in either mode, so that a loss computed through a discriminator in
+        # eval() still reaches the generator's parameters.  Only the inference extensions (`lengths`, `out=`) and the
+        # explicit `inference_only` switch run the plain HIP forward under an enabled grad mode.
+        needs_grad = torch.is_grad_enabled() and not self.inference_only and (
+            any(p.requires_grad for p in self.parameters()) or
             any(isinstance(t, torch.Tensor) and t.requires_grad for t in (x, s, l, spk_emb)))
+        if needs_grad and not self.training and (lengths is not None or out is not None):
+            needs_grad = False
         if needs_grad:
             # training (train_fastsvc.py:157-240 calls the module under autograd): HIP forward, PyTorch-ROCm
             # autograd backward over a restatement of the same dataflow - see autograd.py (first slice)
