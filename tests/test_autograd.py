@@ -107,3 +107,24 @@ def test_train_step_shape_at_the_recipe_batch():
     y.square().mean().backward()
     for n, p in g.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0.0, n
+
+
+@pytest.mark.gpu
+def test_eval_mode_keeps_the_graph_like_any_module():
+    """nn.Module semantics: with grad enabled and parameters that require grad the output carries a graph in
+    eval() as in train() - a generator loss computed through a discriminator in eval() must reach the generator's
+    parameters; no_grad, `inference_only` and the inference extensions run the plain HIP forward."""
+    dev = torch.device("cuda:0")
+    cfg = S.TINY_CONFIG
+    g = _module(cfg, 3).to(dev).eval()
+    b = S.synth_batch(cfg, 2, 8, 4)
+    ins = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft, b.spk_emb)]
+    y = g(*ins)
+    assert y.requires_grad
+    y.square().mean().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in g.parameters())
+    with torch.no_grad():
+        assert not g(*ins).requires_grad
+    assert not g(*ins, lengths=[8, 5]).requires_grad
+    g.inference_only = True
+    assert not g(*ins).requires_grad

@@ -871,3 +871,50 @@ def test_single_frame_member_of_a_longer_ragged_batch(dev):
     assert float((y[1:2, :, :cfg.hop] - r1).abs().max()) <= 1e-4 * max(1.0, float(r1.abs().max()))
     assert float((y[0:1] - r2).abs().max()) <= 2e-5 * max(1.0, float(r2.abs().max()))
     assert not y[1, :, cfg.hop:].any()
+
+
+@pytest.mark.parametrize("storage", ["float32", "bfloat16"])
+def test_whole_stage_conditioning_launch_taps_vs_oracle(dev, storage):
+    """Conditioning stage 0 as ONE launch (csrc/fastsvc_cond.hip; compact-workspace plans - what the module and
+    bench.py run): its two outputs against the oracle's taps - ss.0 = summed FiLM scale / shift of both signals
+    (fastsvc.py:129-130,220-232) and down_hd.1 = h_0[..., ::5] of both chains (fastsvc.py:164-193; Squeeze2d,
+    upsample.py:53-74) - on a batch whose rows end inside a 240-column tile, then ragged on a poisoned workspace with
+    garbage behind the inputs' row ends; the waveform against the oracle; and that the launch really ran."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 61)
+    wf = S.fold_weight_norm(sd)
+    B, F = 3, 52                                           # T = 8320 = 34 tiles of 240 + 160 columns
+    b = S.synth_batch(cfg, B, F, 62)
+    plan = A.Plan(cfg, storage=storage, compact_workspace=True)
+    blob = plan.pack(sd).to(dev)
+    tol_t, tol_y = (TIGHT, TIGHT) if storage == "float32" else (4e-2, 0.25)
+    ref, taps = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb, return_taps=True)
+    ws = torch.full((plan.workspace_bytes(B, F),), 0xFF, dtype=torch.uint8, device=dev)          # NaN patterns
+    recs = []
+    y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), workspace=ws, profile=recs)
+    layers = [r["layer"] for r in recs]
+    assert "cond.0" in layers and "down.0.c123" not in layers and "film.0.chain" not in layers
+    ss = plan.tap("ss.0", B, F, ws).float().cpu()
+    want = torch.cat([taps["scale.0"], taps["shift.0"]], dim=1)
+    assert float((ss - want).abs().max()) <= tol_t * max(1.0, float(want.abs().max()))
+    hd = plan.tap("down_hd.1", B, F, ws).float().cpu()
+    for sig, sl in (("lft", slice(0, B)), ("sine", slice(B, 2 * B))):
+        wh = taps[f"down_{sig}.0"][..., ::5]
+        assert tuple(hd[sl].shape) == tuple(wh.shape)
+        assert float((hd[sl] - wh).abs().max()) <= tol_t * max(1.0, float(wh.abs().max())), sig
+    e = (y.cpu() - ref).abs()
+    assert float(e.max()) <= tol_y and (storage == "float32" or float(e.mean()) <= 2e-2)
+    # ragged: every utterance as if alone (lengths 52, 31, 4 frames: the last one is a single partial tile), with
+    # NaN behind the row ends of the inputs and in the workspace
+    lens = [52, 31, 4]
+    ppg, sine, lft = b.ppg.copy(), b.sine.copy(), b.lft.copy()
+    for i, n in enumerate(lens):
+        ppg[i, :, n:] = np.nan; sine[i, :, n * 160:] = np.nan; lft[i, :, n * 160:] = np.nan
+    ws.fill_(0xFF)
+    yr = plan.forward(blob, *_to(dev, ppg, sine, lft, b.spk_emb), lengths=lens, workspace=ws).cpu()
+    for i, n in enumerate(lens):
+        r1 = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[i:i + 1, :, :n], b.sine[i:i + 1, :, :n * 160],
+                             b.lft[i:i + 1, :, :n * 160], b.spk_emb[i:i + 1])
+        ei = (yr[i:i + 1, :, :n * 160] - r1).abs()
+        assert float(ei.max()) <= tol_y and (n == F or float(yr[i, :, n * 160:].abs().max()) == 0.0), i
