@@ -8,16 +8,20 @@
 A "step" is one pass of the generator forward over one batch of synthetic utterances already
 resident in HBM.  Workloads (BASELINE.json `configs`):
 
-  cfg2 (default)  8 x 4 s per GPU, fp32 - the configuration the metric is quoted on.  With N > 1
-                  every rank runs the same-sized batch of different utterances (weak scaling), rank 0
-                  packs the weights and broadcasts the blob over RCCL, each step's waveforms are
-                  all-gathered over xGMI asynchronously (overlapping the next step).
-  cfg1 / cfg3     1 x 2 s / 64 x 10 s per GPU, same scheme.
+  cfg3 (default at --gpus 1)   64 x 10 s per GPU in bfloat16 storage - BASELINE's largest single-GPU configuration in
+                  its stated dtype ("bf16 generator forward"): what `value` is quoted on at N = 1.  `secondary` carries
+                  cfg3 in float32, cfg2 (8 x 4 s, float32: the 1e-3 parity configuration), cfg1, cfg4's 1-GPU leg in both
+                  storages, the ragged set and an off-table shape.
+  cfg4 (default at --gpus N > 1)   the 512-utterance set (10 s each), utterance-parallel STRONG scaling in the same
+                  storage: the set is sharded over the ranks (svcc23_fastsvc_amd.distributed.run_utterance_parallel:
+                  LPT shards, batches of 64, round-wise asynchronous all-gather over RCCL); a step is one pass over the
+                  whole set and `value` = 512 * T / step time (at N = 1 this is `secondary.cfg4_bfloat16_n1`, 8 cfg3
+                  batches per pass).  `secondary.weak_cfg2` keeps the weak-scaling figure (every rank a cfg2 batch).
+  cfg1 / cfg2 / cfg3 with --gpus N   every rank runs the same-sized batch of different utterances (weak scaling), rank 0
+                  packs the weights and broadcasts the blob over RCCL, each step's waveforms are all-gathered
+                  asynchronously (overlapping the next step).
   cfg4var         cfg4's variable-length variant (2 - 10 s, ragged length-bucketed batches)
-  cfg4            the 512-utterance set (10 s each), utterance-parallel STRONG scaling: the set is
-                  sharded over the ranks (svcc23_fastsvc_amd.distributed.run_utterance_parallel:
-                  LPT shards, batches of 64, round-wise asynchronous all-gather); a step is one pass
-                  over the whole set and `value` = 512 * T / step time.
+  cfg5            one full training step (see run_cfg5)
 
 Prints ONE JSON line.  `roofline` is measured live with hipEvents on the launch stream
 (fastsvc_forward_profile): `roofline.e2e` prices EVERY launch of the step at
@@ -56,12 +60,13 @@ def parse():
     # slower than 200 after 50); the large workloads scale them down below
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4var", "cfg5"],
-                    help="cfg5: one full training step (generator fwd/bwd, MelGAN MSD, MR-STFT + adversarial losses, RAdam; "
+    ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4var", "cfg5"],
+                    help="default: cfg3 at --gpus 1, cfg4 (the 512-utterance set, strong scaling) at --gpus N > 1.  "
+                         "cfg5: one full training step (generator fwd/bwd, MelGAN MSD, MR-STFT + adversarial losses, RAdam; "
                          "recipe batch 32 x 16000 samples per GPU, data-parallel gradient all-reduce)")
-    ap.add_argument("--storage", default="float32", choices=["float32", "bfloat16"],
-                    help="workspace tensor storage: float32 = the parity path (default, what `value` is quoted "
-                         "on); bfloat16 = BASELINE config 3's dtype (bf16-activation accuracy)")
+    ap.add_argument("--storage", default=None, choices=["float32", "bfloat16"],
+                    help="workspace tensor storage: bfloat16 = BASELINE config 3's dtype (default for the forward "
+                         "workloads: what `value` is quoted on); float32 = the 1e-3 parity path (default for cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 float32 / bfloat16 block")
     ap.add_argument("--autotune", action="store_true",
@@ -71,6 +76,18 @@ def parse():
                     help="ignore the shipped launch-shape table (svcc23_fastsvc_amd/tuned_mi355x.json)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     return ap.parse_args()
+
+
+def resolve_workload(gpus: int, workload, storage):
+    """What a bare `bench.py --gpus N` measures.  N = 1: BASELINE's largest single-GPU configuration (cfg3, 64 x 10 s);
+    N > 1: its multi-GPU configuration (cfg4: the 512-utterance set sharded over the ranks, strong scaling, all-gather of
+    the waveforms included) - both in cfg3's stated dtype (bfloat16 storage) unless --storage says otherwise, so that
+    the N = 1 figure of a scaling run is `secondary.cfg4_bfloat16_n1` of the N = 1 line (8 cfg3 batches per pass)."""
+    if workload is None:
+        workload = "cfg3" if gpus == 1 else "cfg4"
+    if storage is None:
+        storage = "float32" if workload == "cfg5" else "bfloat16"
+    return workload, storage
 
 
 def _usable_cores() -> int:
@@ -150,6 +167,8 @@ def kernel_peak_tflops(kernel: str) -> float:
     if kernel.startswith("conv_hx"):
         nprod = 3 if ",x3" in kernel else 1
         return PEAK_HALF_MFMA_TFLOPS / nprod
+    if kernel.startswith("cond_stage"):                      # whole-stage conditioning launch (csrc/fastsvc_cond.hip)
+        return PEAK_HALF_MFMA_TFLOPS / (3 if "x3" in kernel else 1)
     return PEAK_FP32_MFMA_TFLOPS
 
 
@@ -278,7 +297,7 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
     return res
 
 
-def run_cfg4_single_gpu(cfg, dev, steps=3, warmup=1, name="cfg4"):
+def run_cfg4_single_gpu(cfg, dev, steps=3, warmup=1, name="cfg4", storage="float32"):
     """BASELINE config 4's single-GPU leg: the 512 x 10 s set through `run_utterance_parallel` (the multi-GPU code
     path) on a 1-rank RCCL group, inputs resident in HBM, waveforms gathered into the result list.
     name="cfg4var": SURVEY 8(d)'s variable-length variant (2 - 10 s, ragged length-bucketed batches; `value` counts
@@ -296,7 +315,7 @@ def run_cfg4_single_gpu(cfg, dev, steps=3, warmup=1, name="cfg4"):
         os.environ.setdefault("MASTER_PORT", "29519")
         dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        plan = A.Plan(cfg, compact_workspace=True)
+        plan = A.Plan(cfg, compact_workspace=True, storage=storage)
         blob = plan.pack(S.synth_state_dict(cfg, WEIGHT_SEED)).to(dev)
         utts = []
         for c0 in range(0, n_utts, 64):
@@ -351,6 +370,49 @@ def run_off_table_shape(cfg, dev, B=5, F=731, steps=50, warmup=10):
     return out
 
 
+def cpu_train_step_baseline(budget_s: float):
+    """The recipe's training step on the host cores (reported baseline for cfg5): the same TrainStep harness with the
+    generator as the differentiable PyTorch restatement of the reference dataflow (autograd._forward_torch), yaml-width
+    generator and discriminator, on a BOUNDED batch of 2 crops of 16000 samples (the recipe's is 32)."""
+    import torch.nn as nn
+    from svcc23_fastsvc_amd import autograd as AG
+    from svcc23_fastsvc_amd import training as TRN
+    cfg = S.FULL_CONFIG
+    nt = min(16, _usable_cores())
+    torch.set_num_threads(nt)
+
+    class TorchGen(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = A.FastSVCGenerator(in_channels=cfg.in_channels, mid_channels=list(cfg.mid_channels),
+                                        upsampling_scales=list(cfg.upsampling_scales), out_channels=1,
+                                        spk_emb_size=cfg.spk_emb_size, use_spk_emb=True)
+            self.m.load_state_dict({k: torch.from_numpy(v) for k, v in S.synth_state_dict(cfg, WEIGHT_SEED).items()})
+
+        def forward(self, x, s, l, spk_emb=None):
+            return AG._forward_torch(AG.folded_weights(dict(self.m.named_parameters())), self.m.upsampling_scales, x, s, l, spk_emb)
+
+    B, F = 2, TRN.RECIPE["batch_length"] // cfg.hop
+    T = F * cfg.hop
+    gen = TorchGen().train()
+    disc = TRN.MelGANMultiScaleDiscriminator(**TRN.RECIPE["discriminator_params"]).train()
+    trainer = TRN.TrainStep(gen, disc, dict(discriminator_train_start_steps=0), steps=1)
+    b = S.synth_batch(cfg, B, F, 5000)
+    batch = (tuple(torch.from_numpy(a) for a in (b.ppg, b.sine, b.lft, b.spk_emb)), torch.randn((B, 1, T)) * 0.3)
+    trainer.step(batch, log=False)                           # warm-up
+    times = []
+    t_end = time.time() + budget_s
+    while len(times) < 2 or (time.time() < t_end and len(times) < 10):
+        t = time.time()
+        trainer.step(batch, log=False)
+        times.append(time.time() - t)
+    med = float(np.median(times))
+    return {"value": B * T / med, "unit": "samples/s", "cores": nt, "kind": "port",
+            "sample": f"the same training step (generator fwd + bwd as PyTorch CPU operators over the restated dataflow, MelGAN "
+                      f"discriminator, MR-STFT + adversarial losses, RAdam), batch {B} x {T} samples (recipe: 32), fp32, median of "
+                      f"{len(times)} steps on {nt} threads", "ms_per_step": med * 1e3}
+
+
 def run_cfg5(args, dist, world, rank, dev):
     """BASELINE config 5: the recipe's training step (train_fastsvc.py:157-240) per GPU on a batch of 32 crops of
     16000 samples (fastsvc.yaml:71-72), both sub-networks training, gradients averaged over the ranks (RCCL).
@@ -379,6 +441,23 @@ def run_cfg5(args, dist, world, rank, dev):
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
+    # roofline of the HIP share of the step: the generator forward (run twice per step) profiled launch by launch at
+    # the recipe batch, priced like every forward line; e2e.frac is against the WHOLE step (PyTorch backward,
+    # discriminator and losses included), `hip_share_of_step` says how much of the step the HIP launches are
+    roof = None
+    try:
+        with torch.no_grad():
+            roof = roofline(gen.plan, gen.packed_weights(dev), [ppg, sine, lft, emb], ms, n_prof=2)
+        roof["hip_forwards_per_step"] = 2
+        roof["hip_share_of_step"] = 2.0 * roof["e2e"]["serial_sum_ms"] / ms
+        roof["e2e"]["frac"] = 2.0 * roof["e2e"]["per_kernel_roofline_ms"] / ms
+        roof["e2e"]["note"] += ("  cfg5: frac = 2 x the forward's per-kernel roofline / the measured TRAINING step - the backward, "
+                                "discriminator and losses are PyTorch-ROCm operators and count as time without roofline.")
+    except Exception as e:
+        roof = {"error": repr(e)}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_train_step_baseline(args.cpu_seconds)
     n_g = sum(p.numel() for p in gen.parameters())
     n_d = sum(p.numel() for p in disc.parameters())
     return {
@@ -392,12 +471,14 @@ def run_cfg5(args, dist, world, rank, dev):
                    "global_batch": world * B, "utterance_samples": T, "parallelism": f"data-parallel x{world}",
                    "generator_params": n_g, "discriminator_params": n_d,
                    "hip_path": "generator forward only (two per step); hand-written backward kernels are not built"},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roof, "cpu_baseline": cpu,
     }
 
 
 def main():
     args = parse()
+    default_workload = args.workload is None
+    args.workload, args.storage = resolve_workload(args.gpus, args.workload, args.storage)
     big = args.workload in ("cfg3", "cfg4", "cfg4var")
     if args.workload == "cfg5":
         args.steps = args.steps or 10
@@ -530,6 +611,37 @@ def main():
     elapsed = time_steps(step, drain, args.steps, args.warmup, dist if world > 1 else None, dev)
     ms_per_step = elapsed / args.steps * 1e3
 
+    weak = None
+    if world > 1 and default_workload and not args.no_secondary:
+        # the weak-scaling figure next to the strong-scaling headline: every rank a cfg2 batch (8 x 4 s) of its own
+        # utterances, waveforms all-gathered asynchronously, same storage
+        w2 = S.WORKLOADS["cfg2"]
+        B2, F2 = w2["B"], w2["F"]
+        T2 = F2 * cfg.hop
+        a2 = list(S.device_batch(cfg, B2, F2, w2["seed"] + 1000 * rank, dev))
+        ws2 = torch.empty(plan.workspace_bytes(B2, F2), dtype=torch.uint8, device=dev)
+        outs2 = [torch.empty((B2, 1, T2), dtype=torch.float32, device=dev) for _ in range(2)]
+        gath2 = [torch.empty((world * B2, 1, T2), dtype=torch.float32, device=dev) for _ in range(2)]
+        pend2 = [None, None]
+
+        def step2(i):
+            if pend2[i & 1] is not None:
+                pend2[i & 1].wait()
+            plan.forward(blob, *a2, out=outs2[i & 1], workspace=ws2)
+            pend2[i & 1] = dist.all_gather_into_tensor(gath2[i & 1], outs2[i & 1], async_op=True)
+
+        def drain2():
+            for h in pend2:
+                if h is not None:
+                    h.wait()
+            torch.cuda.synchronize()
+
+        e2 = time_steps(step2, drain2, 100, 20, dist, dev)
+        weak = {"workload": f"cfg2: {w2['desc']} per GPU, weak scaling, all-gather of waveforms", "storage": args.storage,
+                "ms_per_step": e2 / 100 * 1e3, "value": world * B2 * T2 * 100 / e2, "unit": "samples/s", "n_gpus": world,
+                "steps": 100, "warmup": 20, "scaling": "weak"}
+        del ws2, outs2, gath2, a2
+
     if rank == 0:
         # per-batch time for the end-to-end fraction: the step's time scaled to one full B x F batch of samples
         # (cfg4: 1 / batches per step; cfg4var: by the samples of this rank's shard - its batches differ in size)
@@ -538,25 +650,25 @@ def main():
         batch_share = B * T / (float(sum(n_frames[i] for i in mine)) * cfg.hop) if strong else 1.0
         roof = roofline(plan, blob, args_dev, ms_per_step * batch_share)
         secondary = None
-        if world == 1 and not args.no_secondary and args.workload == "cfg2":
+        if world == 1 and not args.no_secondary and default_workload:
             del ws
             torch.cuda.empty_cache()
             secondary = {}
-            for name, storage in (("cfg3", "float32"), ("cfg3", "bfloat16")):
-                try:
-                    secondary[f"{name}_{storage}"] = run_single_gpu_workload(cfg, name, storage, dev, steps=20, warmup=5,
-                                                                             use_table=not args.no_table)
-                except Exception as e:        # an extra block must never take the headline line down
-                    secondary[f"{name}_{storage}"] = {"error": repr(e)}
-            for key, fn in (("cfg1_float32", lambda: run_single_gpu_workload(cfg, "cfg1", "float32", dev, steps=200, warmup=50,
-                                                                               use_table=not args.no_table)),
-                            ("cfg4_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev)),
-                            ("cfg4var_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev, name="cfg4var")),
-                            ("off_table_shape", lambda: run_off_table_shape(cfg, dev))):
+            runs = [("cfg3_float32", lambda: run_single_gpu_workload(cfg, "cfg3", "float32", dev, steps=20, warmup=5, use_table=not args.no_table)),
+                    ("cfg2_float32", lambda: run_single_gpu_workload(cfg, "cfg2", "float32", dev, steps=200, warmup=50, use_table=not args.no_table)),
+                    ("cfg2_bfloat16", lambda: run_single_gpu_workload(cfg, "cfg2", "bfloat16", dev, steps=200, warmup=50, use_table=not args.no_table)),
+                    ("cfg1_float32", lambda: run_single_gpu_workload(cfg, "cfg1", "float32", dev, steps=200, warmup=50, use_table=not args.no_table)),
+                    ("cfg4_bfloat16_n1", lambda: run_cfg4_single_gpu(cfg, dev, storage="bfloat16")),
+                    ("cfg4_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev)),
+                    ("cfg4var_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev, name="cfg4var")),
+                    ("off_table_shape", lambda: run_off_table_shape(cfg, dev))]
+            for key, fn in runs:
                 try:
                     secondary[key] = fn()
-                except Exception as e:
+                except Exception as e:        # an extra block must never take the headline line down
                     secondary[key] = {"error": repr(e)}
+        if weak is not None:
+            secondary = {"weak_cfg2": weak}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_seconds)

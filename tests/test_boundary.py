@@ -409,3 +409,25 @@ def test_split_half_conversions_match_numpy():
     mid = fin & (np.abs(x) < 6e4)
     rec = hi.view(np.float16)[mid].astype(np.float64) + lo.view(np.float16)[mid].astype(np.float64)
     assert np.all(np.abs(rec - x[mid]) <= np.maximum(np.abs(x[mid]) * 2.0 ** -21, 2.0 ** -25))
+
+
+def test_bench_defaults_follow_baseline_configs():
+    """VERDICT r3 task 4: a bare `bench.py --gpus 1` measures BASELINE's largest single-GPU configuration in its stated
+    dtype (cfg3, bfloat16), `--gpus N > 1` measures config 4 (the 512-utterance set, strong scaling) in the same
+    storage; explicit flags win; the training step stays float32."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.resolve_workload(1, None, None) == ("cfg3", "bfloat16")
+    for n in (2, 4, 8):
+        assert bench.resolve_workload(n, None, None) == ("cfg4", "bfloat16")
+    assert bench.resolve_workload(8, "cfg2", None) == ("cfg2", "bfloat16")
+    assert bench.resolve_workload(1, "cfg2", "float32") == ("cfg2", "float32")
+    assert bench.resolve_workload(8, "cfg5", None) == ("cfg5", "float32")
+    # the 512-utterance set shards evenly over 2 / 4 / 8 ranks (64 utterances = one batch per rank at 8)
+    from svcc23_fastsvc_amd import distributed as D
+    frames = S.workload_frames("cfg4")
+    for n in (2, 8):
+        shards = D.shard_utterances(frames, n)
+        assert sorted(i for sh in shards for i in sh) == list(range(512)) and {len(sh) for sh in shards} == {512 // n}
