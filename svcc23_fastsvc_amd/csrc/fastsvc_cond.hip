@@ -74,10 +74,14 @@ __device__ __forceinline__ CsFrag cs_read(const unsigned char* plane, int off, i
     return f;
 }
 struct CsW { u32x4 p[CS_NP]; };
+// (through a buffer descriptor: a wave-uniform base in SGPRs + ONE per-lane offset register for every fragment of the
+// launch - with per-fragment 64-bit addresses hipcc spilled the address pairs and reloaded each in front of its load,
+// `scratch_load; s_waitcnt vmcnt(0); global_load`: the weight stream of a layer ran one memory latency per fragment)
 __device__ __forceinline__ CsW cs_wload(const unsigned char* frag, int lane) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(frag), 0, CS_NP * CS_FRAG, 0x00020000);
     CsW w;
     #pragma unroll
-    for (int q = 0; q < CS_NP; ++q) w.p[q] = *reinterpret_cast<const u32x4*>(frag + q * CS_FRAG + lane * 16);
+    for (int q = 0; q < CS_NP; ++q) w.p[q] = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, q * CS_FRAG, 0);
     return w;
 }
 // acc += w (.) a: bf16 one product; split binary16: hi*hi + hi*lo + lo*hi.  SWAP: weights are the A operand.
@@ -572,6 +576,449 @@ hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream) {
 
 #ifndef FASTSVC_ACT_BF16
 int cond_stage0_tile_columns() { return CsGeom<16>::NT; }
+#endif
+
+
+// =====================================================================================================================
+// Stage k >= 1 with C = 48 (C_in = 24; the yaml's stage 1): the same whole-stage launch.  Differences from stage 0:
+//   * the stage's input is a C_in-channel tensor - the COMPACT decimated output of the stage before - staged time-major in
+//     LDS twice (raw for the 1x1 residual conv, LeakyReLU'd for the first k=3 conv: the MODE_DEC2 pair of fastsvc_hx.hip),
+//     fetched one tile ahead; both convs of the pair run on the matrix pipe, the residual conv's tile stays in registers
+//     until it becomes the initial accumulator of the chain's last conv;
+//   * C = 48 = two 32-channel K chunks per signal (8 LDS planes for the two ping-pong buffers), three 16-channel output
+//     tiles: wave = (signal, output tile), all time tiles of the layer; heads 96 -> 96: wave = one of the six output tiles;
+//   * 31 weight fragments per wave do not stay resident: each layer's are requested one layer ahead (two register sets
+//     that trade places every tile), 186 KB of L2 traffic per 112-column tile against ~11 k cycles of matrix work.
+constexpr int C1_C = 48, C1_CIN = 24, C1_NM = 3, C1_NC = 2;
+constexpr int C1_NWAVES = 2 * C1_NM, C1_NTHREADS = C1_NWAVES * 64;
+
+template <int NTL>
+struct C1Geom {
+    static constexpr int NTO = NTL - 1;
+    static constexpr int NT = 16 * NTO;
+    static constexpr int ROWS = NT + 36;               // rows r <-> t = t0 - 16 + r; the deepest read (c3's taps) ends at NT + 34
+    static constexpr int PLANE = CS_NP * ROWS * CS_ROW;
+    static constexpr int TAB = 2 * 64;                 // one per-(signal, channel) table
+    static constexpr int CONST_FLOATS = (CS_NP == 2 ? 2 : 1) * (TAB /* c1 */ + 3 * TAB /* c2 c3 film */ + 128 /* heads */) + TAB /* r -> c3 */;
+    static constexpr int SP = NT * (int)sizeof(act_t) + 16;
+    static constexpr size_t LDS = CONST_FLOATS * 4 + 8 * (size_t)PLANE;
+    static_assert(2 * C1_C * SP <= 4 * PLANE, "staging rows must fit the buffer they alias");
+};
+
+// one k=3 layer of (signal, output tile m): NC K chunks, all NTL time tiles, swapped operands (see cs_layer)
+//   KIND 0: lrelu -> own signal's planes;  1: raw, accumulator starts from racc * kr;  2: lrelu -> the 2C-channel planes
+template <int NTL, int NC, int KIND>
+__device__ __forceinline__ void c1_layer(const unsigned char* in_planes, unsigned char* out_planes, int lo_off, int plane_bytes,
+                                         const CsW* W /* [NC][3] */, int dil, int out_row0, const float* kb, const float* kiv,
+                                         const f32x4* racc, const float* kr, int sig, int m, int t0, int Tv, int lane) {
+    constexpr int G = 2;
+    const int l15 = lane & 15, g = lane >> 4;
+    int aoff[3];
+    #pragma unroll
+    for (int tap = 0; tap < 3; ++tap) aoff[tap] = cs_off(out_row0 + (tap - 1) * dil + l15, g);
+    const int co0 = m * 16 + 4 * g;
+    const f32x4 kbv = *reinterpret_cast<const f32x4*>(kb + co0);
+    f32x4 kivv = kbv, krv = kbv;
+    if constexpr (CS_NP == 2) kivv = *reinterpret_cast<const f32x4*>(kiv + co0);
+    if constexpr (CS_NP == 2 && KIND == 1) krv = *reinterpret_cast<const f32x4*>(kr + co0);
+    int wbase;
+    if constexpr (KIND == 2) {
+        const int cc0 = sig * C1_C + co0;
+        wbase = (cc0 >> 5) * plane_bytes + cs_off(out_row0 + l15, (cc0 & 31) >> 3) + (cc0 & 7) * 2;
+    } else {
+        wbase = (sig * C1_NC + (co0 >> 5)) * plane_bytes + cs_off(out_row0 + l15, (co0 & 31) >> 3) + (co0 & 7) * 2;
+    }
+    const int tbase = t0 - 16 + out_row0 + l15;
+    #pragma unroll
+    for (int j0 = 0; j0 < NTL; j0 += G) {
+        f32x4 acc[G];
+        #pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            if constexpr (KIND == 1) {
+                if constexpr (CS_NP == 2) acc[ii] = racc[j0 + ii] * krv; else acc[ii] = racc[j0 + ii];
+            } else acc[ii] = kbv;
+        }
+        #pragma unroll
+        for (int ch = 0; ch < NC; ++ch)
+            #pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+                #pragma unroll
+                for (int ii = 0; ii < G; ++ii) {
+                    const CsFrag a = cs_read(in_planes + ch * plane_bytes, aoff[tap] + (j0 + ii) * 16 * CS_ROW, lo_off);
+                    acc[ii] = cs_prod<true>(W[ch * 3 + tap], a, acc[ii]);
+                }
+        #pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const unsigned keep = (unsigned)(tbase + 16 * (j0 + ii)) < (unsigned)Tv ? 0xffffffffu : 0u;
+            f32x4 v = acc[ii];
+            if constexpr (CS_NP == 2) v = v * kivv;
+            if constexpr (KIND != 1) v = cs_lrelu4(v);
+            cs_store4_masked(out_planes + wbase + (j0 + ii) * 16 * CS_ROW, lo_off, v, keep);
+        }
+    }
+}
+
+template <int NTL>
+__global__ __launch_bounds__(C1_NTHREADS, CS_NP == 1 ? 3 : 1)
+void cond_stage1_kernel(const CondStage1Params p) {
+    using GEO = C1Geom<NTL>;
+    constexpr int NT = GEO::NT, ROWS = GEO::ROWS, PLANE = GEO::PLANE, NTO = GEO::NTO, TAB = GEO::TAB;
+    constexpr int lo_off = ROWS * CS_ROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // tables [signal][64 channels] (heads: [128]): accumulator initial values (bias x accumulator scale) and, float32
+    // storage, the factors that move an accumulator to its output tile's scale
+    float* k1b = reinterpret_cast<float*>(smem);                                  // c1
+    float* klb = k1b + TAB;                                                       // [3] c2, c3 (+ residual conv's bias), film.conv
+    float* k5b = klb + 3 * TAB;                                                   // heads [128]
+    float* krr = k5b + 128;                                                       // residual conv's tile -> c3's accumulator scale
+    float* k1i = krr + TAB;                                                       // float32 storage only from here
+    float* kli = k1i + TAB;
+    float* k5i = kli + 3 * TAB;
+    unsigned char* bufA = smem + GEO::CONST_FLOATS * 4;                           // 4 planes: c1 -> h -> output staging
+    unsigned char* bufB = bufA + 4 * PLANE;                                       // 4 planes: x (raw, lrelu) x 2 signals -> c2 -> u (3 planes)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z;
+    const int Tv = p.lens ? p.lens[b] * p.len_mul : p.T;
+    const int ntx = (Tv + NT - 1) / NT;
+    const int tpw = p.tpw & 0xffff;
+    const int tile_begin = blockIdx.x * tpw;
+    const int tile_end = min(tile_begin + tpw, ntx);
+    if (tile_begin >= tile_end) return;
+    const int sig = wave / C1_NM, m = wave - sig * C1_NM;
+
+    // ---- operand scales (float32 storage; see cond_stage0_kernel) and tables ----
+    float sx[2] = {1.f, 1.f}, sc[4][2] = {{1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}};
+    if constexpr (CS_NP == 2) {
+        float bu = 0.f;
+        #pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float ax = amax_read(p.amax_in, s * p.B + b);
+            const float b1 = ax * p.bnd[0][s][0] + p.bnd[0][s][1];
+            const float b2 = b1 * p.bnd[1][s][0] + p.bnd[1][s][1];
+            const float bh = b2 * p.bnd[2][s][0] + p.bnd[2][s][1] + ax * p.bnd_r[s][0] + p.bnd_r[s][1];
+            bu = fmaxf(bu, bh * p.bnd[3][s][0] + p.bnd[3][s][1]);
+            sx[s] = hx_scale_for(ax);
+            sc[0][s] = hx_scale_for(b1); sc[1][s] = hx_scale_for(b2); sc[2][s] = hx_scale_for(bh);
+        }
+        sc[3][0] = sc[3][1] = hx_scale_for(bu);
+    }
+    for (int i = tid; i < TAB; i += C1_NTHREADS) {
+        const int s = i >> 6, c = i & 63;
+        const bool ok = c < C1_C;
+        float a1 = 1.f, ar = 1.f;                          // accumulator scales of the pair: input scale / inverse weight scale
+        if constexpr (CS_NP == 2) {
+            a1 = sx[s] / (ok ? p.winv1[s][c] : 1.f);
+            ar = sx[s] / (ok ? p.winv1[s][C1_C + c] : 1.f);
+            k1i[i] = ok ? sc[0][s] / a1 : 0.f;
+        }
+        k1b[i] = ok ? p.b1[s][c] * a1 : 0.f;
+        float a3 = 1.f;
+        #pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            float as = 1.f;
+            if constexpr (CS_NP == 2) {
+                as = sc[l][s] / (ok ? p.winv[l][s][c] : 1.f);
+                kli[l * TAB + i] = ok ? sc[l + 1][s] / as : 0.f;
+            }
+            if (l == 1) a3 = as;
+            // (c3's own bias joins the residual conv's tile, which starts from both: see krr)
+            klb[l * TAB + i] = ok && l != 1 ? p.bias[l][s][c] * as : 0.f;
+        }
+        // the residual conv's accumulator starts from (its bias + c3's bias) at ITS scale; krr moves the finished tile to
+        // c3's accumulator scale (1 in bfloat16 storage)
+        klb[1 * TAB + i] = ok ? (p.br[s][c] + p.bias[1][s][c]) * ar : 0.f;
+        krr[i] = ok ? a3 / ar : 0.f;
+    }
+    for (int i = tid; i < 128; i += C1_NTHREADS) {
+        const bool ok5 = i < 2 * C1_C;
+        float as = 1.f;
+        if constexpr (CS_NP == 2) {
+            as = sc[3][0] / (ok5 ? p.winv5[i] : 1.f);
+            k5i[i] = ok5 ? 1.f / as : 0.f;
+        }
+        k5b[i] = ok5 ? p.b5[i] * as : 0.f;
+    }
+
+    const __amdgpu_buffer_rsrc_t xr0 = act_rsrc(reinterpret_cast<const float*>(p.x), (long)b * p.x_b, (long)C1_CIN * p.ldx);
+    const __amdgpu_buffer_rsrc_t xr1 = act_rsrc(reinterpret_cast<const float*>(p.x), p.x_sig + (long)b * p.x_b, (long)C1_CIN * p.ldx);
+    const __amdgpu_buffer_rsrc_t ssr = act_rsrc(reinterpret_cast<const float*>(p.ss), (long)b * p.ss_b, (long)2 * C1_C * p.ld);
+    const int hdTv = p.hd ? Tv / p.hd_s : 0;
+    const __amdgpu_buffer_rsrc_t hdr0 = act_rsrc(reinterpret_cast<const float*>(p.hd ? p.hd : p.ss), p.hd ? (long)b * p.hd_b : 0, p.hd ? (long)C1_C * p.hd_ld : 0);
+    const __amdgpu_buffer_rsrc_t hdr1 = act_rsrc(reinterpret_cast<const float*>(p.hd ? p.hd : p.ss), p.hd ? p.hd_sig + (long)b * p.hd_b : 0, p.hd ? (long)C1_C * p.hd_ld : 0);
+
+    // ---- the stage's input tile: item = (signal, octet of 8 channels, quad of 4 rows), rows 4 .. ROWS ----
+    constexpr int NQD = (ROWS - 4) / 4;
+    const bool has_item = tid < 2 * 3 * NQD;
+    const int it_s = tid / (3 * NQD), it_r = tid - it_s * 3 * NQD;
+    const int it_q = it_r / 3, it_o = it_r - it_q * 3;
+    f32x4 px[8];
+    auto xfetch = [&](int t0n) {
+        const int t = t0n - 16 + 4 + 4 * it_q;
+        const bool tok = has_item && (unsigned)t < (unsigned)Tv;
+        #pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int o = tok ? ((it_o * 8 + c) * p.ldx + t) * 4 : OOB_OFF;
+            px[c] = it_s ? act_load4(xr1, o, 0) : act_load4(xr0, o, 0);
+        }
+    };
+    auto xcommit = [&]() {
+        if (has_item) {
+            const float s_in = sx[it_s];
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 lo4 = {px[0][j], px[1][j], px[2][j], px[3][j]}, hi4 = {px[4][j], px[5][j], px[6][j], px[7][j]};
+                if constexpr (CS_NP == 2) { lo4 = lo4 * s_in; hi4 = hi4 * s_in; }
+                unsigned char* dst = bufB + (it_s * 2) * PLANE + cs_off(4 + 4 * it_q + j, it_o);
+                cs_store8_masked(dst, lo_off, lo4, hi4, 0xffffffffu);                             // raw
+                cs_store8_masked(dst + PLANE, lo_off, cs_lrelu4(lo4), cs_lrelu4(hi4), 0xffffffffu);  // LeakyReLU'd
+            }
+        }
+        // channel padding 24 .. 31 of the four input planes (c2 / u lay there), and - float32 storage - the padding
+        // 48 .. 63 of c1's second planes (the staging rows lay there: float32 bits are not finite binary16 values)
+        for (int i = tid; i < 4 * (ROWS - 4); i += C1_NTHREADS) {
+            const int pl = i / (ROWS - 4), r = 4 + i - pl * (ROWS - 4);
+            unsigned char* pad = bufB + pl * PLANE + cs_off(r, 3);
+            *reinterpret_cast<u32x4*>(pad) = u32x4{0u, 0u, 0u, 0u};
+            if constexpr (CS_NP == 2) *reinterpret_cast<u32x4*>(pad + lo_off) = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    // channel padding 48 .. 63 of c1's second planes: the staged output rows of the tile before lay there (float32 bits
+    // are not finite binary16 values; on the first tile the planes are whatever LDS held) - zeroed in P1, i.e. behind the
+    // barrier that ends the copy-out and in front of the one c2 waits for
+    auto zero_c1_padding = [&]() {
+        for (int i = tid; i < 2 * 2 * ROWS; i += C1_NTHREADS) {
+            const int s = i / (2 * ROWS), rr = i - s * 2 * ROWS, r = rr >> 1, o = 2 + (rr & 1);
+            unsigned char* pad = bufA + (s * 2 + 1) * PLANE + cs_off(r, o);
+            *reinterpret_cast<u32x4*>(pad) = u32x4{0u, 0u, 0u, 0u};
+            if constexpr (CS_NP == 2) *reinterpret_cast<u32x4*>(pad + lo_off) = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+
+    // ---- weight fragments: two register sets that trade places every tile ----
+    const unsigned char* wl1 = reinterpret_cast<const unsigned char*>(p.w1[sig]);
+    const unsigned char* wl[3] = {reinterpret_cast<const unsigned char*>(p.w[0][sig]), reinterpret_cast<const unsigned char*>(p.w[1][sig]),
+                                  reinterpret_cast<const unsigned char*>(p.w[2][sig])};
+    const unsigned char* wl5 = reinterpret_cast<const unsigned char*>(p.w5) + (long)(wave / 3) * 27 * CS_NP * CS_FRAG;
+    const int m5t = wave % 3;
+    auto load_pair = [&](CsW (&W)[9]) {                    // slots w0 w1 w2 | w1x1
+        #pragma unroll
+        for (int sl = 0; sl < 4; ++sl) W[sl] = cs_wload(wl1 + (long)(sl * 3 + m) * CS_NP * CS_FRAG, lane);
+    };
+    auto load_layer = [&](CsW (&W)[9], int l) {
+        #pragma unroll
+        for (int q = 0; q < 6; ++q) W[q] = cs_wload(wl[l] + (long)(q * 3 + m) * CS_NP * CS_FRAG, lane);
+    };
+    auto load_heads = [&](CsW (&W)[9]) {
+        #pragma unroll
+        for (int q = 0; q < 9; ++q) W[q] = cs_wload(wl5 + (long)(q * 3 + m5t) * CS_NP * CS_FRAG, lane);
+    };
+    float hmax[2] = {0.f, 0.f};
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    auto do_tile = [&](CsW (&WA)[9], CsW (&WB)[9], int tile) {
+        const int t0 = tile * NT;
+        // ---- P1: the pair on the stage's input: c1 = lrelu(conv3(lrelu(x)) + b1) -> A; r = conv1x1(x) (+ biases) -> registers ----
+        load_layer(WB, 0);
+        zero_c1_padding();
+        f32x4 racc[NTL];
+        {
+            const unsigned char* xraw = bufB + (sig * 2) * PLANE;
+            const unsigned char* xact = xraw + PLANE;
+            const int co0 = m * 16 + 4 * g4;
+            const f32x4 kbv = *reinterpret_cast<const f32x4*>(k1b + sig * 64 + co0);
+            const f32x4 rbv = *reinterpret_cast<const f32x4*>(klb + 1 * TAB + sig * 64 + co0);
+            f32x4 kivv = kbv;
+            if constexpr (CS_NP == 2) kivv = *reinterpret_cast<const f32x4*>(k1i + sig * 64 + co0);
+            int aoff[3];
+            #pragma unroll
+            for (int tap = 0; tap < 3; ++tap) aoff[tap] = cs_off(8 + (tap - 1) + l15, g4);
+            const int roff = cs_off(14 + l15, g4);
+            const int wbase = (sig * C1_NC + (co0 >> 5)) * PLANE + cs_off(8 + l15, (co0 & 31) >> 3) + (co0 & 7) * 2;
+            #pragma unroll
+            for (int j0 = 0; j0 < NTL; j0 += 2) {
+                f32x4 acc[2] = {kbv, kbv};
+                #pragma unroll
+                for (int tap = 0; tap < 3; ++tap)
+                    #pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const CsFrag a = cs_read(xact, aoff[tap] + (j0 + ii) * 16 * CS_ROW, lo_off);
+                        acc[ii] = cs_prod<true>(WA[tap], a, acc[ii]);
+                    }
+                #pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const CsFrag a = cs_read(xraw, roff + (j0 + ii) * 16 * CS_ROW, lo_off);
+                    racc[j0 + ii] = cs_prod<true>(WA[3], a, rbv);
+                }
+                #pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const unsigned keep = (unsigned)(t0 - 16 + 8 + l15 + 16 * (j0 + ii)) < (unsigned)Tv ? 0xffffffffu : 0u;
+                    f32x4 v = acc[ii];
+                    if constexpr (CS_NP == 2) v = v * kivv;
+                    cs_store4_masked(bufA + wbase + (j0 + ii) * 16 * CS_ROW, lo_off, cs_lrelu4(v), keep);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P2: c2 = lrelu(conv3_d2(c1) + b2) -> B ----
+        load_layer(WA, 1);
+        c1_layer<NTL, C1_NC, 0>(bufA + sig * C1_NC * PLANE, bufB, lo_off, PLANE, WB, 2, 10, klb + 0 * TAB + sig * 64, kli + 0 * TAB + sig * 64,
+                                nullptr, nullptr, sig, m, t0, Tv, lane);
+        __syncthreads();
+        // ---- P3: h = conv3_d4(c2) + b3 + r -> A ----
+        load_layer(WB, 2);
+        c1_layer<NTL, C1_NC, 1>(bufB + sig * C1_NC * PLANE, bufA, lo_off, PLANE, WA, 4, 14, klb + 1 * TAB + sig * 64, kli + 1 * TAB + sig * 64,
+                                racc, krr + sig * 64, sig, m, t0, Tv, lane);
+        __syncthreads();
+        // ---- P4: u = lrelu(conv3_d1(h) + b4) -> the 96-channel planes of B; h[::s'] -> hd; next input tile requested ----
+        load_heads(WA);
+        c1_layer<NTL, C1_NC, 2>(bufA + sig * C1_NC * PLANE, bufB, lo_off, PLANE, WB, 1, 15, klb + 2 * TAB + sig * 64, kli + 2 * TAB + sig * 64,
+                                nullptr, nullptr, sig, m, t0, Tv, lane);
+        if (p.hd) {
+            const int j_lo = (t0 + p.hd_s - 1) / p.hd_s;
+            const int j_hi = min((min(t0 + NT, Tv) + p.hd_s - 1) / p.hd_s, hdTv);
+            constexpr int NR = 2 * C1_C / C1_NWAVES;
+            for (int j = j_lo + lane; j < j_hi; j += 64) {
+                const int row = j * p.hd_s - t0 + 16;
+                const int rowb = (row ^ ((row >> 2) & 1)) * CS_ROW, rx16 = ((row >> 1) & 2) << 4;
+                const unsigned char* b01 = bufA + rowb + rx16;
+                const unsigned char* b23 = bufA + rowb - rx16;
+#ifdef FASTSVC_ACT_BF16
+                unsigned short v[NR];
+#else
+                float v[NR];
+                const float ih0 = 1.0f / sc[2][0], ih1 = 1.0f / sc[2][1];
+#endif
+                #pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int scn = wave + C1_NWAVES * k;
+                    const int s = scn >= C1_C ? 1 : 0, c = scn - s * C1_C;
+                    const int o = (c & 31) >> 3;
+                    const unsigned char* src = (o < 2 ? b01 : b23) + (s * C1_NC + (c >> 5)) * PLANE + (o << 4) + (c & 7) * 2;
+#ifdef FASTSVC_ACT_BF16
+                    v[k] = *reinterpret_cast<const unsigned short*>(src);
+#else
+                    v[k] = ((float)*reinterpret_cast<const _Float16*>(src) + (float)*reinterpret_cast<const _Float16*>(src + lo_off)) * (s ? ih1 : ih0);
+                    hmax[s] = fmaxf(hmax[s], fabsf(v[k]));
+#endif
+                }
+                #pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int scn = wave + C1_NWAVES * k;
+                    const int s = scn >= C1_C ? 1 : 0, c = scn - s * C1_C;
+#ifdef FASTSVC_ACT_BF16
+                    __builtin_amdgcn_raw_buffer_store_b16(v[k], s ? hdr1 : hdr0, j * 2, c * p.hd_ld * 2, 0);
+#else
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), s ? hdr1 : hdr0, j * 4, c * p.hd_ld * 4, 0);
+#endif
+                }
+            }
+        }
+        xfetch(t0 + NT);                                   // (past the last tile: out of range, nothing is fetched)
+        __syncthreads();
+        // ---- P5: [scale ; shift] = conv3_d1([u_lft ; u_sine]) + b5: wave = one of the six 16-channel output tiles ----
+        load_pair(WB);
+        {
+            int aoff[3];
+            #pragma unroll
+            for (int tap = 0; tap < 3; ++tap) aoff[tap] = cs_off(16 + (tap - 1) + l15, g4);
+            const float bias = k5b[wave * 16 + l15];
+            float oinv = 1.f;
+            if constexpr (CS_NP == 2) oinv = k5i[wave * 16 + l15];
+            unsigned char* srow = bufA + (wave * 16 + l15) * GEO::SP + (4 * g4) * (int)sizeof(act_t);
+            constexpr int G5 = 4;
+            #pragma unroll
+            for (int i0 = 0; i0 < NTO; i0 += G5) {
+                f32x4 acc[G5];
+                #pragma unroll
+                for (int ii = 0; ii < G5; ++ii) acc[ii] = f32x4{bias, bias, bias, bias};
+                #pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    #pragma unroll
+                    for (int tap = 0; tap < 3; ++tap)
+                        #pragma unroll
+                        for (int ii = 0; ii < G5; ++ii) {
+                            if (i0 + ii >= NTO) continue;
+                            const CsFrag a = cs_read(bufB + ch * PLANE, aoff[tap] + (i0 + ii) * 16 * CS_ROW, lo_off);
+                            acc[ii] = cs_prod<false>(WA[ch * 3 + tap], a, acc[ii]);
+                        }
+                #pragma unroll
+                for (int ii = 0; ii < G5; ++ii) {
+                    if (i0 + ii >= NTO) continue;
+                    f32x4 v = acc[ii];
+                    if constexpr (CS_NP == 2) v = v * oinv;
+                    unsigned char* dst = srow + (i0 + ii) * 16 * (int)sizeof(act_t);
+#ifdef FASTSVC_ACT_BF16
+                    *reinterpret_cast<cs4*>(dst) = __builtin_convertvector(v, cs4);
+#else
+                    *reinterpret_cast<f32x4*>(dst) = v;
+#endif
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P0 of the next tile (its input -> B: every reader of u is past the barrier), then P6: staged rows -> ss ----
+        xcommit();
+        {
+            constexpr int CH = NT * (int)sizeof(act_t) / 16;
+            constexpr int EPC = 16 / (int)sizeof(act_t);
+            constexpr int LPR = CH <= 16 ? 16 : CH <= 32 ? 32 : 64;
+            static_assert(CH <= 64, "chunks of a row fit the lanes that copy it");
+            constexpr int RPP = C1_NTHREADS / LPR;
+            static_assert((2 * C1_C) % RPP == 0, "whole passes over the staged rows");
+            const int k = tid % LPR, r0 = tid / LPR;
+            const int t = t0 + k * EPC;
+            const bool ok = k < CH && t < Tv;
+            const unsigned char* src = bufA + r0 * GEO::SP + k * 16;
+            const int o = ok ? (r0 * p.ld + t) * (int)sizeof(act_t) : OOB_OFF;
+            #pragma unroll
+            for (int i = 0; i < 2 * C1_C / RPP; ++i) {
+                const u32x4 w = *reinterpret_cast<const u32x4*>(src + i * RPP * GEO::SP);
+                __builtin_amdgcn_raw_buffer_store_b128(w, ssr, o, i * RPP * p.ld * (int)sizeof(act_t), 0);
+            }
+        }
+        __syncthreads();
+    };
+
+    CsW Wx[9], Wy[9];
+    xfetch(tile_begin * NT);
+    load_pair(Wx);
+    __syncthreads();                                       // tables
+    xcommit();
+    __syncthreads();
+    for (int tile = tile_begin; tile < tile_end; tile += 2) {
+        do_tile(Wx, Wy, tile);
+        if (tile + 1 < tile_end) do_tile(Wy, Wx, tile + 1);
+    }
+    if constexpr (CS_NP == 2) {
+        if (p.amax_hd && p.hd) {
+            #pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)wave_max_u32_lane63(__builtin_bit_cast(unsigned, hmax[s])), 63);
+                if (lane == 0 && a != 0u)
+                    atomicMax(reinterpret_cast<unsigned*>(p.amax_hd) + (s * p.B + b) * AMAX_ENTRY + ((blockIdx.x + wave) & (AMAX_W - 1)) * AMAX_STRIDE, a);
+            }
+        }
+    }
+}
+
+hipError_t launch_cond_stage1(const CondStage1Params& p, hipStream_t stream) {
+    constexpr int NTL = 8;
+    using GEO = C1Geom<NTL>;
+    if (p.C != C1_C || p.Cin != C1_CIN || (p.T % 8) != 0 || (p.ld % 8) != 0 || (p.ldx % 4) != 0 || (p.tpw & 0xffff) < 1 ||
+        (p.hd && p.hd_s < 2)) return hipErrorInvalidValue;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_stage1_kernel<NTL>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS);
+    if (attr != hipSuccess) return attr;
+    const int ntx = (p.T + GEO::NT - 1) / GEO::NT;
+    const int tpw = p.tpw & 0xffff;
+    dim3 grid((ntx + tpw - 1) / tpw, 1, p.B);
+    hipLaunchKernelGGL(cond_stage1_kernel<NTL>, grid, dim3(C1_NTHREADS), GEO::LDS, stream, p);
+    return hipGetLastError();
+}
+
+#ifndef FASTSVC_ACT_BF16
+int cond_stage1_tile_columns() { return C1Geom<8>::NT; }
 #endif
 
 #ifdef FASTSVC_ACT_BF16

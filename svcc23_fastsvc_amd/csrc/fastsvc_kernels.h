@@ -207,6 +207,38 @@ struct CondStage0Params {
     int tpw;                     // consecutive time tiles per workgroup
 };
 
+// A whole conditioning stage k >= 1 with C = 48 channels (C_in = 24) as ONE launch (fastsvc_cond.hip): the COMPACT decimated
+// output of the stage before (hd_k = h_{k-1}[..., ::s_k], written by the launch of stage k-1) -> [scale ; shift] of the
+// stage (ss) and the compact h_k[..., ::hd_s] for the stage after.  Index s = 0 loudness, 1 sine excitation.
+struct CondStage1Params {
+    const void* x;               // (2B, Cin, ldx) activation storage: signal s utterance b at (s * x_sig + b * x_b) elements
+    long x_sig, x_b;
+    int ldx;
+    int B, C, Cin, T, ld;        // T: padded columns at this stage's rate, ld: row pitch of ss (elements)
+    const int* lens;             // ragged batch: valid columns of utterance b = lens[b] * len_mul
+    int len_mul;
+    const void* w1[2];           // first k=3 conv + 1x1 residual conv (MODE_DEC2 fragments): [slot w0 w1 w2 | w1x1][tile][piece]
+    const float* b1[2];          // bias of the k=3 conv
+    const float* br[2];          // bias of the 1x1 conv
+    const float* winv1[2];       // float32 storage: inverse weight scales [k=3 conv | 1x1 conv], 16 * ntiles each
+    const void* w[3][2];         // c2 / c3 / film.conv: [32-channel chunk][tap][tile][piece]
+    const float* bias[3][2];
+    const float* winv[3][2];
+    const float* bnd[4][2];      // float32 storage: (l1, bmax) of c1, c2, c3, film.conv
+    const float* bnd_r[2];
+    const void* w5;              // heads 2C -> 2C: [group of 3 tiles][chunk][tap][tile][piece]
+    const float* b5;
+    const float* winv5;
+    const float* amax_in;        // float32 storage: amax entries of x [s * B + b]
+    float* amax_hd;              // float32 storage: amax entries of hd
+    void* ss;                    // (B, 2C, ld)
+    long ss_b;
+    void* hd;                    // (2B, C, hd_ld) compact h[..., ::hd_s]; null: not written
+    long hd_sig, hd_b;
+    int hd_ld, hd_s;
+    int tpw;
+};
+
 enum : int { DBG_NO_LOAD = 1, DBG_NO_MFMA = 2, DBG_NO_EPILOGUE = 4, DBG_NO_COMMIT = 8, DBG_NO_WEIGHTS = 16 };
 // The switches exist only in the diagnostic build (-DFASTSVC_DEBUG_SWITCHES: `build --timeline`).  A run-time branch
 // around a pipeline stage is not free even when never taken: hipcc's wait-count bookkeeping merges the path that
@@ -277,6 +309,8 @@ hipError_t launch_pointwise_out(const float* x, const float* w, const float* bia
 
 hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream);
 int cond_stage0_tile_columns();
+hipError_t launch_cond_stage1(const CondStage1Params& p, hipStream_t stream);
+int cond_stage1_tile_columns();
 
 // speaker bias for all up blocks: p[blk][b][c] = bias + W[c] . (e / max(||e||, 1e-12))
 struct SpkBlock {
@@ -302,6 +336,7 @@ hipError_t launch_pointwise_out(const float* x, const float* w, const float* bia
                                 int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream);
 hipError_t launch_act_convert(const float* src, float* dst_bf16, long n, hipStream_t stream);
 hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream);
+hipError_t launch_cond_stage1(const CondStage1Params& p, hipStream_t stream);
 }  // namespace bf16
 
 }  // namespace fastsvc

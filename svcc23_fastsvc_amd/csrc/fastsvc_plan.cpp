@@ -1097,6 +1097,7 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
         ws.add("down_h." + s, 2 * B, d.C, Tk, ae);               // [lft batch ; sine batch]
         // h_0[..., ::s_1] compact: what the whole-stage launch of stage 0 hands to stage 1 instead of h_0 (run_cond_stage0)
         if (k == 0 && n > 1) ws.add("down_hd.1", 2 * B, d.C, Tk / P.down[1].scale, ae);
+        if (k == 1 && n > 2) ws.add("down_hd.2", 2 * B, d.C, Tk / P.down[2].scale, ae);     // ... and of stage 1 (run_cond_stage1)
         if (k + 1 < n) add_shared("film_u", "film_u." + s, B, 2 * d.C, Tk, ae);     // channels [lft ; sine]
         else ws.add("film_u." + s, B, 2 * d.C, Tk, ae);          // (last stage: on the caller's stream)
         ws.add("ss." + s, B, 2 * d.C, Tk, ae);                   // channels [scale ; shift]
@@ -1549,7 +1550,7 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
     static const int cond_env = std::getenv("FASTSVC_COND") ? std::atoi(std::getenv("FASTSVC_COND")) : 1;
     static const int tpw_env = std::getenv("FASTSVC_COND_TPW") ? std::atoi(std::getenv("FASTSVC_COND_TPW")) : 0;
     // (float32 storage needs the measured maxima of the raw signals: not with FASTSVC_NO_AMAX_SCAN)
-    if (!cond_env || P.n < 2 || g_exact_f32 || (P.storage == 0 && (!amax_in || !amax_hd))) return hipSuccess;
+    if (!cond_env || P.n < 2 || g_exact_f32 || (P.storage == 0 && (!amax_in || !amax_hd))) return hipSuccess;      // FASTSVC_COND=0: separate launches (A/B)
     const DownStage& d = P.down[0];
     const DownStage& d1 = P.down[1];
     if (d.C != 24 || !d.c2[0].hx || !d.c3[0].hx || !d.film[0].hx || !d.heads.hx || d.c2[0].MW != 2 || d.heads.MW != 3 ||
@@ -1625,6 +1626,73 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
             }
         }
         return e;
+    }
+    return launch();
+}
+
+// Stage 1 of the conditioning nets (C = 48) as ONE launch (fastsvc_cond.hip): the compact decimated output of stage 0 ->
+// ss.1 and the compact h_1[..., ::s_2].  `done` = false when this call has no such variant.
+hipError_t run_cond_stage1(const fastsvc_plan& P, const float* blob, const float* x, int B, long T1, int F, const int* lengths,
+                           float* ss, float* hd, const float* amax_in, float* amax_hd, hipStream_t stream, Profiler* prof,
+                           bool& done) {
+    done = false;
+    static const int cond_env = std::getenv("FASTSVC_COND") ? std::atoi(std::getenv("FASTSVC_COND")) : 1;
+    static const int tpw_env = std::getenv("FASTSVC_COND1_TPW") ? std::atoi(std::getenv("FASTSVC_COND1_TPW")) : 0;
+    if (!(cond_env & 2) && cond_env != 1) return hipSuccess;                 // FASTSVC_COND: 0 none, 1 all, 4 stage 0 only
+    if (P.n < 3 || g_exact_f32 || (P.storage == 0 && (!amax_in || !amax_hd))) return hipSuccess;
+    const DownStage& d = P.down[1];
+    const DownStage& d2 = P.down[2];
+    if (d.C != 48 || d.Cin != 24 || !d.rc1[0].dec2 || !d.rc1[0].hx || d.rc1[0].MW != 3 || !d.c2[0].hx || !d.c3[0].hx ||
+        !d.film[0].hx || d.c2[0].MW != 3 || d.c2[0].nch32 != 2 || !d.heads.hx || d.heads.MW != 3 || d.heads.nch32 != 3 ||
+        d.heads.ngroups != 2 || !d2.rc1[0].dec2 || (T1 % 8) != 0 || T1 % d2.scale != 0 || (T1 / d2.scale) % 4 != 0)
+        return hipSuccess;
+    const int prec = P.storage == 1 ? 1 : 0;
+    CondStage1Params q;
+    std::memset(&q, 0, sizeof(q));
+    q.x = x; q.ldx = (int)T1; q.x_b = (long)d.Cin * T1; q.x_sig = (long)B * q.x_b;
+    q.B = B; q.C = d.C; q.Cin = d.Cin; q.T = (int)T1; q.ld = (int)T1;
+    q.lens = lengths; q.len_mul = (int)(T1 / F);
+    const PackedConv* layers[3] = {d.c2, d.c3, d.film};
+    for (int s = 0; s < 2; ++s) {
+        q.w1[s] = blob + d.rc1[s].hx_off[prec]; q.b1[s] = blob + d.rc1[s].b_off; q.br[s] = blob + d.rc1[s].b2_off;
+        q.winv1[s] = blob + d.rc1[s].hx_inv_off;
+        for (int l = 0; l < 3; ++l) {
+            q.w[l][s] = blob + layers[l][s].hx_off[prec];
+            q.bias[l][s] = blob + layers[l][s].b_off;
+            q.winv[l][s] = blob + layers[l][s].hx_inv_off;
+            q.bnd[l + 1][s] = blob + layers[l][s].bnd_off;
+        }
+        q.bnd[0][s] = blob + d.c1[s].bnd_off;
+        q.bnd_r[s] = blob + d.r[s].bnd_off;
+    }
+    q.w5 = blob + d.heads.hx_off[prec]; q.b5 = blob + d.heads.b_off; q.winv5 = blob + d.heads.hx_inv_off;
+    q.amax_in = P.storage == 0 ? amax_in : nullptr; q.amax_hd = P.storage == 0 ? amax_hd : nullptr;
+    q.ss = ss; q.ss_b = 2L * d.C * T1;
+    q.hd = hd; q.hd_ld = (int)(T1 / d2.scale); q.hd_s = d2.scale;
+    q.hd_b = (long)d.C * q.hd_ld; q.hd_sig = (long)B * q.hd_b;
+    const int NT = cond_stage1_tile_columns();
+    const long ntx = (T1 + NT - 1) / NT;
+    if (tpw_env > 0) q.tpw = tpw_env;
+    else {
+        const long slots = P.storage == 1 ? 512 : 256, total = ntx * B;
+        const long rounds = std::max<long>(1, (total + slots * 32 - 1) / (slots * 32));
+        long tpw = std::max<long>(1, (total + slots * rounds - 1) / (slots * rounds));
+        while (tpw < ntx && ((ntx + tpw - 1) / tpw) * B > slots * rounds) ++tpw;
+        q.tpw = (int)std::min<long>(tpw, ntx);
+    }
+    done = true;
+    auto launch = [&]() { return P.storage == 1 ? bf16::launch_cond_stage1(q, stream) : launch_cond_stage1(q, stream); };
+    if (prof) {
+        const double C = d.C, Ci = d.Cin, cols = (double)T1 * B;
+        const double flops = (2.0 * (2.0 * (3.0 * Ci * C + Ci * C) + 2.0 * 3.0 * 3.0 * C * C) + 2.0 * 3.0 * 4.0 * C * C) * cols;
+        const double ae = P.storage == 1 ? 2.0 : 4.0;
+        const double bytes = (2.0 * Ci * ae + 2.0 * C * ae + 2.0 * C * ae / d2.scale) * cols +
+                             4.0 * (double)(2 * (d.rc1[0].w_floats + d.c2[0].w_floats + d.c3[0].w_floats + d.film[0].w_floats) + d.heads.w_floats);
+        hipError_t e = prof->begin(stream, "cond.1", P.storage == 1 ? "cond_stage1<x1>" : "cond_stage1<x3>", flops, bytes);
+        if (e != hipSuccess) return e;
+        e = launch();
+        if (e != hipSuccess) return e;
+        return prof->end();
     }
     return launch();
 }
@@ -2309,6 +2377,15 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                                     (P.storage == 0 && !no_scan) ? amax_inb : nullptr, am("down_h.0"), stream, prof, whole));
             if (whole) {
                 hprev = buf("down_hd.1"); Cprev = d.C; Tprev = Tk / P.down[1].scale; hprev_compact = true;
+                continue;
+            }
+        }
+        if (k == 1 && P.compact && hprev_compact && n > 2) {
+            bool whole = false;
+            HIP_TRY(run_cond_stage1(P, blob, hprev, B, Tk, F, lengths, buf("ss.1"), buf("down_hd.2"),
+                                    P.storage == 0 ? am("down_h.0") : nullptr, am("down_h.1"), stream, prof, whole));
+            if (whole) {
+                hprev = buf("down_hd.2"); Cprev = d.C; Tprev = Tk / P.down[2].scale; hprev_compact = true;
                 continue;
             }
         }

@@ -875,10 +875,10 @@ def test_single_frame_member_of_a_longer_ragged_batch(dev):
 
 @pytest.mark.parametrize("storage", ["float32", "bfloat16"])
 def test_whole_stage_conditioning_launch_taps_vs_oracle(dev, storage):
-    """Conditioning stage 0 as ONE launch (csrc/fastsvc_cond.hip; compact-workspace plans - what the module and
-    bench.py run): its two outputs against the oracle's taps - ss.0 = summed FiLM scale / shift of both signals
-    (fastsvc.py:129-130,220-232) and down_hd.1 = h_0[..., ::5] of both chains (fastsvc.py:164-193; Squeeze2d,
-    upsample.py:53-74) - on a batch whose rows end inside a 240-column tile, then ragged on a poisoned workspace with
+    """Conditioning stages 0 and 1 as ONE launch each (csrc/fastsvc_cond.hip; compact-workspace plans - what the module
+    and bench.py run): their outputs against the oracle's taps - ss.k = summed FiLM scale / shift of both signals
+    (fastsvc.py:129-130,220-232) and down_hd.(k+1) = h_k[..., ::s] of both chains (fastsvc.py:164-193; Squeeze2d,
+    upsample.py:53-74) - on a batch whose rows end inside a workgroup tile, then ragged on a poisoned workspace with
     garbage behind the inputs' row ends; the waveform against the oracle; and that the launch really ran."""
     O = _oracle()
     cfg = S.FULL_CONFIG
@@ -895,14 +895,16 @@ def test_whole_stage_conditioning_launch_taps_vs_oracle(dev, storage):
     y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), workspace=ws, profile=recs)
     layers = [r["layer"] for r in recs]
     assert "cond.0" in layers and "down.0.c123" not in layers and "film.0.chain" not in layers
-    ss = plan.tap("ss.0", B, F, ws).float().cpu()
-    want = torch.cat([taps["scale.0"], taps["shift.0"]], dim=1)
-    assert float((ss - want).abs().max()) <= tol_t * max(1.0, float(want.abs().max()))
-    hd = plan.tap("down_hd.1", B, F, ws).float().cpu()
-    for sig, sl in (("lft", slice(0, B)), ("sine", slice(B, 2 * B))):
-        wh = taps[f"down_{sig}.0"][..., ::5]
-        assert tuple(hd[sl].shape) == tuple(wh.shape)
-        assert float((hd[sl] - wh).abs().max()) <= tol_t * max(1.0, float(wh.abs().max())), sig
+    assert "cond.1" in layers and "down.1.c1_res1x1" not in layers and "film.1.chain" not in layers     # stage 1 (C = 48) likewise
+    for k, dec in ((0, 5), (1, 4)):
+        ss = plan.tap(f"ss.{k}", B, F, ws).float().cpu()
+        want = torch.cat([taps[f"scale.{k}"], taps[f"shift.{k}"]], dim=1)
+        assert float((ss - want).abs().max()) <= tol_t * max(1.0, float(want.abs().max())), k
+        hd = plan.tap(f"down_hd.{k + 1}", B, F, ws).float().cpu()
+        for sig, sl in (("lft", slice(0, B)), ("sine", slice(B, 2 * B))):
+            wh = taps[f"down_{sig}.{k}"][..., ::dec]
+            assert tuple(hd[sl].shape) == tuple(wh.shape)
+            assert float((hd[sl] - wh).abs().max()) <= tol_t * max(1.0, float(wh.abs().max())), (k, sig)
     e = (y.cpu() - ref).abs()
     assert float(e.max()) <= tol_y and (storage == "float32" or float(e.mean()) <= 2e-2)
     # ragged: every utterance as if alone (lengths 52, 31, 4 frames: the last one is a single partial tile), with

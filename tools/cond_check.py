@@ -42,6 +42,10 @@ for name in names:
     ssf, sss = fused.tap("ss.0", B, F, wsf).float(), sep.tap("ss.0", B, F, wss).float()
     hdf = fused.tap("down_hd.1", B, F, wsf).float()
     hds = sep.tap("down_h.0", B, F, wss).float()[..., ::5]
+    s1f, s1s = fused.tap("ss.1", B, F, wsf).float(), sep.tap("ss.1", B, F, wss).float()
+    h2f, h2s = fused.tap("down_hd.2", B, F, wsf).float(), sep.tap("down_h.1", B, F, wss).float()[..., ::4]
+    print(f"{name} {storage}: stage 1: ss.1 max|d| {float((s1f - s1s).abs().max()):.3e} (max {float(s1s.abs().max()):.3f}, mean|d| "
+          f"{float((s1f - s1s).abs().mean()):.2e})  hd.2 max|d| {float((h2f - h2s).abs().max()):.3e} (max {float(h2s.abs().max()):.3f})")
     print(f"{name} {storage}: ss.0 max|d| {float((ssf - sss).abs().max()):.3e} (max|ss| {float(sss.abs().max()):.3f}, "
           f"mean|d| {float((ssf - sss).abs().mean()):.2e})  hd max|d| {float((hdf - hds).abs().max()):.3e} "
           f"(max {float(hds.abs().max()):.3f})  y max|d| {float((yf - ys).abs().max()):.3e} mean|d| "

@@ -17,8 +17,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob("$out/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "cond_stage0" not in k: continue
-        acc[r["Counter_Name"]]["v"] += float(r["Counter_Value"]); acc[r["Counter_Name"]]["n"] += 1
+        if "cond_stage" not in k: continue
+        k = k.split("(")[0][-28:]
+        acc[(k, r["Counter_Name"])]["v"] += float(r["Counter_Value"]); acc[(k, r["Counter_Name"])]["n"] += 1
 for c, d in sorted(acc.items()):
-    print(f"{c:28s} {d['v'] / d['n']:16.0f}  (per launch, {int(d['n'])} launches)")
+    print(f"{str(c):60s} {d['v'] / d['n']:16.0f}  (per launch, {int(d['n'])} launches)")
 PY
