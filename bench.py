@@ -172,7 +172,7 @@ def kernel_peak_tflops(kernel: str) -> float:
     return PEAK_FP32_MFMA_TFLOPS
 
 
-def roofline(plan, blob, args_dev, ms_per_step, n_prof=3, lengths=None):
+def roofline(plan, blob, args_dev, ms_per_step, n_prof=3, lengths=None, pmc_file=None):
     """Per-kernel-symbol aggregation of hipEvent-timed launches.  fastsvc_forward_profile runs the
     forward on ONE stream (no helper streams) so that each kernel is timed running alone;
     `profiles/*_kernel_stats_serial.csv` is rocprofv3's view of the same thing (FASTSVC_SERIAL=1),
@@ -205,14 +205,18 @@ def roofline(plan, blob, args_dev, ms_per_step, n_prof=3, lengths=None):
     # HBM bytes per launch from the PMC counters: they need separate rocprofv3 --pmc passes (tools/pmc.sh), so the
     # figure comes from the committed summary of the same command, not from this run - `traffic_source` says which
     traffic, traffic_source = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get(kern)
-            traffic_source = ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of `bench.py`, tools/pmc.sh + "
-                              "tools/pmc_summary.py; regenerated whenever a kernel changes) - not measured by this run")
-        except Exception:
-            traffic = None
+    for name in (pmc_file, "pmc_traffic.json"):
+        pmc = os.path.join(ROOT, "profiles", name) if name else None
+        if pmc and os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(kern)
+            except Exception:
+                traffic = None
+            if traffic is not None:
+                traffic_source = (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload, "
+                                  "tools/collect_cfg3.sh + tools/summarize_profiles.py; FETCH_SIZE doubled per the guide's gfx950 "
+                                  "correction; regenerated whenever a kernel changes) - not measured by this run")
+                break
     if t_mfma >= t_hbm:
         out = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf}
     else:
@@ -283,7 +287,7 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
     elapsed = time_steps(lambda i: plan.forward(blob, *args_dev, out=out, workspace=ws),
                          torch.cuda.synchronize, steps, warmup, None, dev)
     ms = elapsed / steps * 1e3
-    roof = roofline(plan, blob, args_dev, ms, n_prof=n_prof)
+    roof = roofline(plan, blob, args_dev, ms, n_prof=n_prof, pmc_file=f"r4_{name}_{storage}_pmc_traffic.json")
     top = sorted(roof["per_kernel"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]
     res = {"workload": f"{name}: {wl['desc']}, F={F}, T={T}", "storage": storage,
            "dtype": plan.arithmetic, "ms_per_step": ms, "value": B * T * steps / elapsed, "unit": "samples/s",
@@ -648,7 +652,8 @@ def main():
         if args_dev is None:
             args_dev = roofline_batch()
         batch_share = B * T / (float(sum(n_frames[i] for i in mine)) * cfg.hop) if strong else 1.0
-        roof = roofline(plan, blob, args_dev, ms_per_step * batch_share)
+        roof = roofline(plan, blob, args_dev, ms_per_step * batch_share,
+                        pmc_file=f"r4_{'cfg3' if strong else args.workload}_{args.storage}_pmc_traffic.json")
         secondary = None
         if world == 1 and not args.no_secondary and default_workload:
             del ws

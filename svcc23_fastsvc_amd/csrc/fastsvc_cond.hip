@@ -61,9 +61,14 @@ constexpr int CS_NM = 2;                 // 16-channel output tiles of a C -> C 
 constexpr int CS_NWAVES = 2 * CS_NM * CS_NQ;
 constexpr int CS_NTHREADS = CS_NWAVES * 64;
 
-// same row / slot swizzle as fastsvc_hx.hip (conflict-free ds_read_b128 at any row offset)
+// LDS byte offset of 16-byte slot `oct` of tile row `row`: the slot index is XORed with row bits 1..2.  Searched
+// exhaustively over the per-row slot permutations (tools: the 4^8 tables indexed by row & 7): ds_read_b128 of a
+// fragment (lanes = 16 consecutive rows x 4 slots) is conflict-free at ANY row offset, the 16-byte row stores of the
+// staging phases (8 consecutive rows, one slot) are conflict-free, and the 8-byte epilogue stores (16 consecutive rows,
+// one half slot) are 2-way - the floor for a 64-byte row pitch; with the swizzle of fastsvc_hx.hip (row pairs swapped,
+// slot ^= (row >> 1) & 2) they were 4-way and bank conflicts 35-45 % of this file's LDS cycles (SQ_LDS_BANK_CONFLICT).
 __device__ __forceinline__ int cs_off(int row, int oct) {
-    return ((row ^ ((row >> 2) & 1)) * CS_ROW) + ((oct ^ ((row >> 1) & 2)) << 4);
+    return row * CS_ROW + ((oct ^ ((row >> 1) & 3)) << 4);
 }
 
 struct CsFrag { cs8 p[CS_NP]; };
@@ -428,17 +433,16 @@ void cond_stage0_kernel(const CondStage0Params p) {
         // ---- P4: u = lrelu(conv3_d1(h) + b4) -> [lft ; sine] channel planes; h[::s'] -> hd ----
         if (!(dbg & 4)) cs_layer<NTL, 2>(bufA + sig * PLANE, bufB, lo_off, PLANE, W4, 1, 15, kbias + (2 * 2 + sig) * 32, kinv + (2 * 2 + sig) * 32, nullptr, nullptr, sig, mt, q, t0, Tv, lane);
         if (p.hd && !(dbg & 8)) {
-            // lane = decimated column, wave = the (signal, channel) rows sc = wave, wave + 4, ...: every LDS read of a
-            // lane issued before the first store; addresses = one per-lane base + immediates (the slot swizzle moves
-            // octets 0 / 1 up and 2 / 3 down by 32 bytes in rows whose bit 2 is set: two bases)
+            // lane = decimated column, wave = the (signal, channel) rows sc = wave, wave + 8, ...: every LDS read of a
+            // lane issued before the first store; addresses = four per-lane slot bases + immediates
             const int j_lo = (t0 + p.hd_s - 1) / p.hd_s;
             const int j_hi = min((min(t0 + NT, Tv) + p.hd_s - 1) / p.hd_s, hdTv);
             constexpr int NR = 2 * CS_C / CS_NWAVES;
             for (int j = j_lo + lane; j < j_hi; j += 64) {
                 const int row = j * p.hd_s - t0 + 16;
-                const int rowb = (row ^ ((row >> 2) & 1)) * CS_ROW, rx16 = ((row >> 1) & 2) << 4;
-                const unsigned char* b01 = bufA + rowb + rx16;
-                const unsigned char* b23 = bufA + rowb - rx16;
+                const unsigned char* bo[4];                  // the row's four slots (swizzled): immediates do the rest
+                #pragma unroll
+                for (int o = 0; o < 4; ++o) bo[o] = bufA + cs_off(row, o);
 #ifdef FASTSVC_ACT_BF16
                 unsigned short v[NR];
 #else
@@ -449,7 +453,7 @@ void cond_stage0_kernel(const CondStage0Params p) {
                 for (int k = 0; k < NR; ++k) {
                     const int sc = wave + CS_NWAVES * k;               // (wave-uniform)
                     const int s = sc >= CS_C ? 1 : 0, c = sc - s * CS_C;
-                    const unsigned char* src = ((c >> 3) < 2 ? b01 : b23) + s * PLANE + ((c >> 3) << 4) + (c & 7) * 2;
+                    const unsigned char* src = bo[c >> 3] + s * PLANE + (c & 7) * 2;
 #ifdef FASTSVC_ACT_BF16
                     v[k] = *reinterpret_cast<const unsigned short*>(src);
 #else
@@ -880,9 +884,9 @@ void cond_stage1_kernel(const CondStage1Params p) {
             constexpr int NR = 2 * C1_C / C1_NWAVES;
             for (int j = j_lo + lane; j < j_hi; j += 64) {
                 const int row = j * p.hd_s - t0 + 16;
-                const int rowb = (row ^ ((row >> 2) & 1)) * CS_ROW, rx16 = ((row >> 1) & 2) << 4;
-                const unsigned char* b01 = bufA + rowb + rx16;
-                const unsigned char* b23 = bufA + rowb - rx16;
+                const unsigned char* bo[4];                  // the row's four slots (swizzled): immediates do the rest
+                #pragma unroll
+                for (int o = 0; o < 4; ++o) bo[o] = bufA + cs_off(row, o);
 #ifdef FASTSVC_ACT_BF16
                 unsigned short v[NR];
 #else
@@ -893,8 +897,7 @@ void cond_stage1_kernel(const CondStage1Params p) {
                 for (int k = 0; k < NR; ++k) {
                     const int scn = wave + C1_NWAVES * k;
                     const int s = scn >= C1_C ? 1 : 0, c = scn - s * C1_C;
-                    const int o = (c & 31) >> 3;
-                    const unsigned char* src = (o < 2 ? b01 : b23) + (s * C1_NC + (c >> 5)) * PLANE + (o << 4) + (c & 7) * 2;
+                    const unsigned char* src = bo[(c & 31) >> 3] + (s * C1_NC + (c >> 5)) * PLANE + (c & 7) * 2;
 #ifdef FASTSVC_ACT_BF16
                     v[k] = *reinterpret_cast<const unsigned short*>(src);
 #else

@@ -10,7 +10,7 @@ wl = S.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
 cfg = S.FULL_CONFIG
 dev = torch.device("cuda:0")
 storage = sys.argv[2] if len(sys.argv) > 2 else "float32"
-plan = A.Plan(cfg, storage=storage)
+plan = A.Plan(cfg, storage=storage, compact_workspace=os.environ.get("FASTSVC_PROFILE_COMPACT", "1") != "0")   # (the layout the module and bench.py run)
 blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
 if wl["B"] * wl["F"] > 20000:                       # large workloads: generate on the device
     ins = list(S.device_batch(cfg, wl["B"], wl["F"], wl["seed"], dev))

@@ -56,6 +56,10 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
         n0 = merged.get(key, 0)
         js[key] = (js.get(key, 0.0) * n0 + hbm * fetch[k][1]) / (n0 + fetch[k][1])
         merged[key] = n0 + fetch[k][1]
+    # whole-stage conditioning launches (csrc/fastsvc_cond.hip)
+    m = re.search(r"cond_stage(\d)_kernel<", k)
+    if m:
+        js["cond_stage%s<%s>" % (m.group(1), "x1" if "bf16::" in k else "x3")] = hbm
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
     if m:
         js["conv_mfma<%s,%s,%s,%s>" % m.groups()] = hbm
