@@ -101,18 +101,6 @@ __device__ __forceinline__ f32x4 cs_prod(const CsW& w, const CsFrag& a, f32x4 ac
     return acc;
 }
 
-// 4 consecutive channels of one time step -> the 8-byte slot of a time-major tile row
-__device__ __forceinline__ void cs_store4(unsigned char* dst, int lo_off, f32x4 v) {
-    const cs4 h = __builtin_convertvector(v, cs4);
-    *reinterpret_cast<cs4*>(dst) = h;
-    if constexpr (CS_NP == 2) {
-        cs4 l;
-        #pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = (cs_t)(v[e] - (float)h[e]);
-        *reinterpret_cast<cs4*>(dst + lo_off) = l;
-    }
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // LeakyReLU(0.2) = max(v, 0.2 v), the multiply as packed float32 (two values per instruction)
 __device__ __forceinline__ f32x4 cs_lrelu4(f32x4 v) {
@@ -121,19 +109,33 @@ __device__ __forceinline__ f32x4 cs_lrelu4(f32x4 v) {
     return f32x4{fmaxf(a.x, ta.x), fmaxf(a.y, ta.y), fmaxf(b.x, tb.x), fmaxf(b.y, tb.y)};
 }
 
+// Low pieces of a pair of values: lo = f16(e - (float)hi) as ONE mixed-precision FMA each (binary16 source from either
+// half of the packed hi register, float32 addend, binary16 result into the low / high half) - bit-identical to convert
+// back, subtract, convert (e - hi is exact in float32), 1 instruction per value instead of 2.5 (same as hx_lo_pair of
+// fastsvc_hx.hip; the split is 40 % of a float32-storage epilogue's VALU work).
+__device__ __forceinline__ unsigned cs_lo_pair(unsigned hi_pair, float e0, float e1) {
+#ifdef FASTSVC_ACT_BF16
+    (void)hi_pair; (void)e0; (void)e1;
+    return 0u;
+#else
+    unsigned d;
+    const float minus1 = -1.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi_pair), "s"(minus1), "v"(e0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi_pair), "s"(minus1), "v"(e1));
+    return d;
+#endif
+}
+
 __device__ __forceinline__ void cs_store4_masked(unsigned char* dst, int lo_off, f32x4 v, unsigned keep) {
     const cs4 h = __builtin_convertvector(v, cs4);
     cs_u2 hp = __builtin_bit_cast(cs_u2, h);
-    hp.x &= keep; hp.y &= keep;
-    *reinterpret_cast<cs_u2*>(dst) = hp;
     if constexpr (CS_NP == 2) {
-        cs4 l;
-        #pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = (cs_t)(v[e] - (float)h[e]);
-        cs_u2 lp = __builtin_bit_cast(cs_u2, l);
+        cs_u2 lp = {cs_lo_pair(hp.x, v[0], v[1]), cs_lo_pair(hp.y, v[2], v[3])};
         lp.x &= keep; lp.y &= keep;
         *reinterpret_cast<cs_u2*>(dst + lo_off) = lp;
     }
+    hp.x &= keep; hp.y &= keep;
+    *reinterpret_cast<cs_u2*>(dst) = hp;
 }
 
 // 8 consecutive channels of one time step -> the 16-byte slot of a time-major tile row (one store per piece)
@@ -142,11 +144,8 @@ __device__ __forceinline__ void cs_store8_masked(unsigned char* dst, int lo_off,
     const cs_u2 pa = __builtin_bit_cast(cs_u2, ha), pb = __builtin_bit_cast(cs_u2, hb);
     *reinterpret_cast<u32x4*>(dst) = u32x4{pa.x & keep, pa.y & keep, pb.x & keep, pb.y & keep};
     if constexpr (CS_NP == 2) {
-        cs4 la, lb;
-        #pragma unroll
-        for (int e = 0; e < 4; ++e) { la[e] = (cs_t)(a[e] - (float)ha[e]); lb[e] = (cs_t)(b[e] - (float)hb[e]); }
-        const cs_u2 qa = __builtin_bit_cast(cs_u2, la), qb = __builtin_bit_cast(cs_u2, lb);
-        *reinterpret_cast<u32x4*>(dst + lo_off) = u32x4{qa.x & keep, qa.y & keep, qb.x & keep, qb.y & keep};
+        *reinterpret_cast<u32x4*>(dst + lo_off) = u32x4{cs_lo_pair(pa.x, a[0], a[1]) & keep, cs_lo_pair(pa.y, a[2], a[3]) & keep,
+                                                        cs_lo_pair(pb.x, b[0], b[1]) & keep, cs_lo_pair(pb.y, b[2], b[3]) & keep};
     }
 }
 
@@ -381,12 +380,12 @@ void cond_stage0_kernel(const CondStage0Params p) {
         // ---- P1: c1 = lrelu(conv3(lrelu(x)) + b1) on the VALU, rows 8 .. NT + 24: thread = row, one (signal, octet of 8
         // channels) per step, whose taps are wave-uniform LDS reads ----
         if (!(dbg & 2)) {
-            static_assert(2 * 16 * NTL == CS_NTHREADS, "one (signal, c1 row) per thread");
+            static_assert(2 * 16 * NTL <= CS_NTHREADS && (16 * NTL) % 64 == 0, "one (signal, c1 row) per thread, a wave = one signal");
             const int r = 8 + (tid & (16 * NTL - 1));
             const int t = t0 - 16 + r;
             const unsigned keep = (unsigned)t < (unsigned)Tv ? 0xffffffffu : 0u;    // outside the utterance: c2's zero padding
-            {
-                const int s1 = wave / (CS_NWAVES / 2);
+            if (tid < 2 * 16 * NTL) {
+                const int s1 = wave / (16 * NTL / 64);
                 const float* xrow = xs + s1 * ROWS;
                 float xa = xrow[r - 1], xb = xrow[r], xc = xrow[r + 1];
                 xa = fmaxf(xa, xa * LRELU_SLOPE); xb = fmaxf(xb, xb * LRELU_SLOPE); xc = fmaxf(xc, xc * LRELU_SLOPE);
@@ -564,10 +563,9 @@ void cond_stage0_kernel(const CondStage0Params p) {
     }
 }
 
-hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream) {
-    constexpr int NTL = 16;
+template <int NTL>
+static hipError_t cond_stage0_instance(const CondStage0Params& p, hipStream_t stream) {
     using GEO = CsGeom<NTL>;
-    if (p.C != CS_C || (p.T % 8) != 0 || (p.ld % 8) != 0 || (p.tpw & 0xffff) < 1) return hipErrorInvalidValue;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_stage0_kernel<NTL>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS);
     if (attr != hipSuccess) return attr;
@@ -578,8 +576,14 @@ hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// p.small: the 112-column tile variant (more, shorter workgroups: batches that do not fill the chip with 240-column tiles)
+hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream) {
+    if (p.C != CS_C || (p.T % 8) != 0 || (p.ld % 8) != 0 || (p.tpw & 0xffff) < 1) return hipErrorInvalidValue;
+    return p.small ? cond_stage0_instance<8>(p, stream) : cond_stage0_instance<16>(p, stream);
+}
+
 #ifndef FASTSVC_ACT_BF16
-int cond_stage0_tile_columns() { return CsGeom<16>::NT; }
+int cond_stage0_tile_columns(int small) { return small ? CsGeom<8>::NT : CsGeom<16>::NT; }
 #endif
 
 
@@ -1005,11 +1009,9 @@ void cond_stage1_kernel(const CondStage1Params p) {
     }
 }
 
-hipError_t launch_cond_stage1(const CondStage1Params& p, hipStream_t stream) {
-    constexpr int NTL = 8;
+template <int NTL>
+static hipError_t cond_stage1_instance(const CondStage1Params& p, hipStream_t stream) {
     using GEO = C1Geom<NTL>;
-    if (p.C != C1_C || p.Cin != C1_CIN || (p.T % 8) != 0 || (p.ld % 8) != 0 || (p.ldx % 4) != 0 || (p.tpw & 0xffff) < 1 ||
-        (p.hd && p.hd_s < 2)) return hipErrorInvalidValue;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_stage1_kernel<NTL>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS);
     if (attr != hipSuccess) return attr;
@@ -1020,8 +1022,14 @@ hipError_t launch_cond_stage1(const CondStage1Params& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+hipError_t launch_cond_stage1(const CondStage1Params& p, hipStream_t stream) {
+    if (p.C != C1_C || p.Cin != C1_CIN || (p.T % 8) != 0 || (p.ld % 8) != 0 || (p.ldx % 4) != 0 || (p.tpw & 0xffff) < 1 ||
+        (p.hd && p.hd_s < 2)) return hipErrorInvalidValue;
+    return p.small ? cond_stage1_instance<4>(p, stream) : cond_stage1_instance<8>(p, stream);
+}
+
 #ifndef FASTSVC_ACT_BF16
-int cond_stage1_tile_columns() { return C1Geom<8>::NT; }
+int cond_stage1_tile_columns(int small) { return small ? C1Geom<4>::NT : C1Geom<8>::NT; }
 #endif
 
 #ifdef FASTSVC_ACT_BF16

@@ -205,6 +205,7 @@ struct CondStage0Params {
     long hd_sig, hd_b;
     int hd_ld, hd_s;
     int tpw;                     // consecutive time tiles per workgroup
+    int small;                   // 1: the short-tile instance (more workgroups for small batches)
 };
 
 // A whole conditioning stage k >= 1 with C = 48 channels (C_in = 24) as ONE launch (fastsvc_cond.hip): the COMPACT decimated
@@ -237,6 +238,7 @@ struct CondStage1Params {
     long hd_sig, hd_b;
     int hd_ld, hd_s;
     int tpw;
+    int small;
 };
 
 enum : int { DBG_NO_LOAD = 1, DBG_NO_MFMA = 2, DBG_NO_EPILOGUE = 4, DBG_NO_COMMIT = 8, DBG_NO_WEIGHTS = 16 };
@@ -308,9 +310,9 @@ hipError_t launch_pointwise_out(const float* x, const float* w, const float* bia
                                 int B, int C, int O, int T, const int* lens, int len_mul, hipStream_t stream);
 
 hipError_t launch_cond_stage0(const CondStage0Params& p, hipStream_t stream);
-int cond_stage0_tile_columns();
+int cond_stage0_tile_columns(int small);
 hipError_t launch_cond_stage1(const CondStage1Params& p, hipStream_t stream);
-int cond_stage1_tile_columns();
+int cond_stage1_tile_columns(int small);
 
 // speaker bias for all up blocks: p[blk][b][c] = bias + W[c] . (e / max(||e||, 1e-12))
 struct SpkBlock {

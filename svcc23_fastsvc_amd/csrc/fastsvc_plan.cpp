@@ -1582,7 +1582,14 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
     q.hd_b = (long)d.C * q.hd_ld; q.hd_sig = (long)B * q.hd_b;
     // tiles per workgroup: the grid runs in whole rounds of the 2 x 256 resident workgroups, at most ~32 tiles each
     // (a workgroup's start - 24 KB of weight fragments per wave, zeroed tiles - costs about two tiles)
-    const int NT = cond_stage0_tile_columns();
+    // short tiles where the long ones would leave CUs without a workgroup (a batch below one round of them)
+    const long slots_all = P.storage == 1 ? 512 : 256;
+    static const int small_env = std::getenv("FASTSVC_COND_SMALL") ? std::atoi(std::getenv("FASTSVC_COND_SMALL")) : -1;
+    {
+        const int NTb = cond_stage0_tile_columns(0);
+        q.small = small_env >= 0 ? small_env : (((T + NTb - 1) / NTb) * B < slots_all ? 1 : 0);
+    }
+    const int NT = cond_stage0_tile_columns(q.small);
     const long ntx = (T + NT - 1) / NT;
     if (tpw_env > 0) q.tpw = tpw_env;
     else {
@@ -1670,7 +1677,14 @@ hipError_t run_cond_stage1(const fastsvc_plan& P, const float* blob, const float
     q.ss = ss; q.ss_b = 2L * d.C * T1;
     q.hd = hd; q.hd_ld = (int)(T1 / d2.scale); q.hd_s = d2.scale;
     q.hd_b = (long)d.C * q.hd_ld; q.hd_sig = (long)B * q.hd_b;
-    const int NT = cond_stage1_tile_columns();
+    // short tiles where the long ones would leave CUs without a workgroup (a batch below one round of them)
+    const long slots_all = P.storage == 1 ? 512 : 256;
+    static const int small_env = std::getenv("FASTSVC_COND_SMALL") ? std::atoi(std::getenv("FASTSVC_COND_SMALL")) : -1;
+    {
+        const int NTb = cond_stage1_tile_columns(0);
+        q.small = small_env >= 0 ? small_env : (((T1 + NTb - 1) / NTb) * B < slots_all ? 1 : 0);
+    }
+    const int NT = cond_stage1_tile_columns(q.small);
     const long ntx = (T1 + NT - 1) / NT;
     if (tpw_env > 0) q.tpw = tpw_env;
     else {
