@@ -1176,6 +1176,7 @@ struct ExecCtx {
     std::vector<hipEvent_t> ev;
     std::mutex busy;                   // one forward at a time enqueues through a context
     bool pays = false;                 // a fork + join through these streams is cheap enough to use them (measured once)
+    bool measured = false;             // measure_fork_join has run (not under stream capture: tried again on the next forward)
     float fork_join_us = 0.f;
 };
 
@@ -1255,9 +1256,17 @@ ExecCtx* exec_ctx_for(hipStream_t stream) {
     c->ev.resize(nev);
     for (int i = 0; i < nev; ++i)
         if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
-    (void)measure_fork_join(stream, c);
+    // (the fork + join calibration synchronises the stream: it runs OUTSIDE this global lock, under the context's own
+    // `busy` lock - ensure_measured - so that first forwards on other streams / devices are not held up behind it)
     g_ctxs[key] = c;
     return c;
+}
+
+// under c->busy: calibrate once; while the stream is being captured the context stays unmeasured (helper streams
+// unused) and the next uncaptured forward measures it
+void ensure_measured(hipStream_t stream, ExecCtx* c) {
+    if (c->measured) return;
+    if (measure_fork_join(stream, c)) c->measured = true;
 }
 
 // fastsvc_stream_release: the context of (current device, stream) is drained and destroyed.  The helper
@@ -2184,9 +2193,12 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     int streams_mask = serial ? 0 : streams_env >= 0 ? (streams_env & 3) : ((int64_t)B * F * hop_all >= 150000 ? 2 : 0);
     // per-launch profiling and autotuning run on ONE stream so that every kernel is timed alone
     ExecCtx* ctx = (streams_mask == 0 || g_tune.tuning || prof) ? nullptr : exec_ctx_for(stream);
-    if (ctx && streams_env < 0 && !ctx->pays) { ctx = nullptr; streams_mask = 0; }
     std::unique_lock<std::mutex> ctx_lock;
-    if (ctx) ctx_lock = std::unique_lock<std::mutex>(ctx->busy);
+    if (ctx) {
+        ctx_lock = std::unique_lock<std::mutex>(ctx->busy);
+        ensure_measured(stream, ctx);
+        if (streams_env < 0 && !ctx->pays) { ctx_lock.unlock(); ctx_lock = std::unique_lock<std::mutex>(); ctx = nullptr; streams_mask = 0; }
+    }
     hipStream_t s_film = (ctx && (streams_mask & 2)) ? ctx->aux[0] : stream;      // FiLM nets of stages 0..n-2
     hipStream_t s_side = (ctx && (streams_mask & 1)) ? ctx->aux[1] : stream;      // 1x1 / stretch residual convs
     int evi = 0;
@@ -2652,8 +2664,11 @@ void fastsvc_split_half(const float* x, int64_t n, uint16_t* f16_hi, uint16_t* f
 }
 
 int fastsvc_stream_prepare(void* stream) {
-    return exec_ctx_for(static_cast<hipStream_t>(stream)) ? FASTSVC_OK
-                                                          : fail(FASTSVC_E_HIP, "could not create the helper streams / events");
+    ExecCtx* c = exec_ctx_for(static_cast<hipStream_t>(stream));
+    if (!c) return fail(FASTSVC_E_HIP, "could not create the helper streams / events");
+    std::lock_guard<std::mutex> busy(c->busy);
+    ensure_measured(static_cast<hipStream_t>(stream), c);
+    return FASTSVC_OK;
 }
 
 int fastsvc_stream_release(void* stream) { return exec_ctx_release(static_cast<hipStream_t>(stream)); }

@@ -465,16 +465,28 @@ class Plan:
             # staging set.  Autotuning tunes the padded shape (launch shapes are keyed by the padded row lengths).
             Fp = self.padded_frames(F)
             hop = cfg.hop
-            key = (B, Fp, str(dev))
-            if getattr(self, "_pad_key", None) != key:
-                self._pad_bufs = (torch.zeros((B, cfg.in_channels, Fp), dtype=torch.float32, device=dev),
-                                  torch.zeros((B, 1, Fp * hop), dtype=torch.float32, device=dev),
-                                  torch.zeros((B, 1, Fp * hop), dtype=torch.float32, device=dev),
-                                  torch.empty((B, cfg.out_channels, Fp * hop), dtype=torch.float32, device=dev))
-                self._pad_key = key
-            pp, ps, pl, py = self._pad_bufs
-            pp[..., :F].copy_(ppg); ps[..., :T].copy_(sine); pl[..., :T].copy_(lft)      # (the padding stays zero)
-            ok_ws = workspace is not None and workspace.numel() >= self.workspace_bytes(B, Fp)
+            if lengths is not None and not (isinstance(lengths, torch.Tensor) and lengths.is_cuda):
+                lh = torch.as_tensor(lengths, dtype=torch.int64, device="cpu").reshape(-1)
+                if lh.numel() != B or int(lh.min()) < 1 or int(lh.max()) > F:        # (against the caller's F, not the padded one)
+                    raise ValueError(f"lengths must hold {B} frame counts in [1, {F}]")
+            if workspace is not None and workspace.numel() < self.workspace_bytes(B, Fp):
+                raise ValueError(f"workspace too small for the padded batch: size it with workspace_bytes({B}, padded_frames({F}) = {Fp})")
+            # one staging set per (shape, device, STREAM): forwards of one plan on different streams must not share it
+            key = (B, Fp, str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
+            sets = self.__dict__.setdefault("_pad_sets", {})
+            if key not in sets:
+                if len(sets) >= 8:
+                    sets.pop(next(iter(sets)))
+                sets[key] = [torch.zeros((B, cfg.in_channels, Fp), dtype=torch.float32, device=dev),
+                             torch.zeros((B, 1, Fp * hop), dtype=torch.float32, device=dev),
+                             torch.zeros((B, 1, Fp * hop), dtype=torch.float32, device=dev),
+                             torch.empty((B, cfg.out_channels, Fp * hop), dtype=torch.float32, device=dev), F]
+            pp, ps, pl, py, lastF = sets[key]
+            pp[..., :F].copy_(ppg); ps[..., :T].copy_(sine); pl[..., :T].copy_(lft)
+            if lastF > F:                                    # a longer batch used this set: its tail is not padding
+                pp[..., F:lastF].zero_(); ps[..., T:lastF * hop].zero_(); pl[..., T:lastF * hop].zero_()
+            sets[key][4] = F
+            ok_ws = workspace is not None
             if autotune:
                 if lengths is not None:
                     raise ValueError("autotune times full-length batches: call it without lengths")

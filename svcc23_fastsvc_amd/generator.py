@@ -320,8 +320,10 @@ class FastSVCGenerator(nn.Module):
                 b1 = min(B, b0 + step)
                 plan.forward(blob, x[b0:b1], s[b0:b1], l[b0:b1],
                              None if spk_emb is None else spk_emb[b0:b1], out=y[b0:b1], workspace=ws,
-                             lengths=None if lengths is None else list(lengths)[b0:b1])
-        return y.to(x.dtype) if x.dtype != torch.float32 else y
+                             lengths=None if lengths is None else
+                             (lengths[b0:b1] if isinstance(lengths, torch.Tensor) else list(lengths)[b0:b1]))
+        # (`out=` given: the caller's float32 buffer IS the result - no cast copy behind its back)
+        return y.to(x.dtype) if (x.dtype != torch.float32 and out is None) else y
 
     def inference(self, x, f0, l, signal_generator, pad_fn, spk_emb=None):
         """Time-major single-utterance entry used by decode_fastsvc.py:187-189

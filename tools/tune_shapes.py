@@ -19,6 +19,7 @@ REPS = int(os.environ.get("TUNE_REPS", "3"))
 names = sys.argv[1:] or ["cfg1", "cfg2"]          # "cfg3:bf16" tunes the bfloat16-storage entries (keys end in "|b"); "32x1500": B x F
 cfg = S.FULL_CONFIG
 dev = torch.device("cuda:0")
+COMPACT = os.environ.get("TUNE_COMPACT", "1") != "0"        # the layout the module and bench.py run (whole-stage conditioning launches, compact decimated inputs)
 ROUNDS = int(os.environ.get("TUNE_ROUNDS", "3"))          # independent tunings per workload; the table that runs the whole forward fastest is kept
 sig = None
 table = {}
@@ -52,7 +53,7 @@ for name in names:
     for rnd in range(ROUNDS):
         votes = collections.defaultdict(collections.Counter)
         for rep in range(REPS):
-            plan = A.Plan(cfg, load_shipped_table=False, storage=storage)
+            plan = A.Plan(cfg, load_shipped_table=False, storage=storage, compact_workspace=COMPACT)
             sig = plan.config_signature()
             blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
             ws = torch.empty(plan.workspace_bytes(wl["B"], wl["F"]), dtype=torch.uint8, device=dev)
@@ -61,7 +62,7 @@ for name in names:
             for k, v in plan.tuned_shapes().items():
                 votes[k][tuple(v)] += 1
         cand = {k: list(c.most_common(1)[0][0]) for k, c in sorted(votes.items())}
-        plan = A.Plan(cfg, load_shipped_table=False, storage=storage)
+        plan = A.Plan(cfg, load_shipped_table=False, storage=storage, compact_workspace=COMPACT)
         plan.load_tuned(cand)
         ms = time_forward(plan, blob, ins, ws)
         print(f"{name} ({storage}) tuning {rnd}: {plan.last_autotune_trials or ''} forward {ms:.4f} ms", file=sys.stderr)
