@@ -932,7 +932,11 @@ void conv_hx_kernel(const ConvParams p0) {
                 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const int r = it_oct[i] * 8 + c;
-                    if constexpr (DEC2) {
+                    if constexpr (DEC2 && S == 2) {
+                        // the input IS the compact decimated copy h[..., ::s] a whole-stage launch wrote (fastsvc_cond.hip):
+                        // unit stride, one vector load per channel like any direct window
+                        px[i][c] = act_load4(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
+                    } else if constexpr (DEC2) {
                         // x[..., ::s] (Squeeze2d): four strided elements; negative t lies before the tensor -> 0
                         const int o = (tok && r < rows_left) ? (r * p.ldx + t * p.s) * 4 : OOB_OFF;
                         px[i][c].x = act_load1(xr, o, soff);
@@ -1451,6 +1455,8 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
 #undef FASTSVC_HXC
         return hipErrorInvalidValue;
     } else if constexpr (MODE == MODE_DEC2) {
+        // S = 2: compact input (p.s == 1, rows a multiple of 4 long, 16-byte aligned) - vector window loads
+        if (p.s == 1 && (p.ldx & 3) == 0) return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 2>(grid, smem, stream, p);
         return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 1>(grid, smem, stream, p);
     } else if constexpr (MODE == MODE_POLY) {
 #define FASTSVC_HXP(sv) \
