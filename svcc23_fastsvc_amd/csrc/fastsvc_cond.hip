@@ -290,11 +290,16 @@ void cond_stage0_kernel(const CondStage0Params p) {
         #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const float ax = amax_read(p.amax_in, s * p.B + b);
-            const float b1 = ax * p.bnd[0][s][0] + p.bnd[0][s][1];
-            const float b2 = b1 * p.bnd[1][s][0] + p.bnd[1][s][1];
-            const float bh = b2 * p.bnd[2][s][0] + p.bnd[2][s][1] + ax * p.bnd_r[s][0] + p.bnd_r[s][1];
-            bu = fmaxf(bu, bh * p.bnd[3][s][0] + p.bnd[3][s][1]);
-            sc[0][s] = hx_scale_for(b1); sc[1][s] = hx_scale_for(b2); sc[2][s] = hx_scale_for(bh);
+            // per-channel bounds alpha[c] * ax + beta[c] (packer), the tile's scale from the largest of them: lane = channel,
+            // a wave-wide max (every wave computes the same: no exchange through LDS, no barrier)
+            float bt[4];
+            #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = lane < CS_C ? p.cbnd[s][(t * 2 + 0) * CS_C + lane] * ax + p.cbnd[s][(t * 2 + 1) * CS_C + lane] : 0.f;
+                bt[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)wave_max_u32_lane63(__builtin_bit_cast(unsigned, fmaxf(v, 0.f))), 63));
+            }
+            bu = fmaxf(bu, bt[3]);
+            sc[0][s] = hx_scale_for(bt[0]); sc[1][s] = hx_scale_for(bt[1]); sc[2][s] = hx_scale_for(bt[2]);
         }
         sc[3][0] = sc[3][1] = hx_scale_for(bu);
     }
@@ -702,12 +707,17 @@ void cond_stage1_kernel(const CondStage1Params p) {
         #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const float ax = amax_read(p.amax_in, s * p.B + b);
-            const float b1 = ax * p.bnd[0][s][0] + p.bnd[0][s][1];
-            const float b2 = b1 * p.bnd[1][s][0] + p.bnd[1][s][1];
-            const float bh = b2 * p.bnd[2][s][0] + p.bnd[2][s][1] + ax * p.bnd_r[s][0] + p.bnd_r[s][1];
-            bu = fmaxf(bu, bh * p.bnd[3][s][0] + p.bnd[3][s][1]);
+            // per-channel bounds alpha[c] * ax + beta[c] (packer), the tile's scale from the largest of them: lane = channel,
+            // a wave-wide max (every wave computes the same: no exchange through LDS, no barrier)
+            float bt[4];
+            #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = lane < C1_C ? p.cbnd[s][(t * 2 + 0) * C1_C + lane] * ax + p.cbnd[s][(t * 2 + 1) * C1_C + lane] : 0.f;
+                bt[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)wave_max_u32_lane63(__builtin_bit_cast(unsigned, fmaxf(v, 0.f))), 63));
+            }
+            bu = fmaxf(bu, bt[3]);
             sx[s] = hx_scale_for(ax);
-            sc[0][s] = hx_scale_for(b1); sc[1][s] = hx_scale_for(b2); sc[2][s] = hx_scale_for(bh);
+            sc[0][s] = hx_scale_for(bt[0]); sc[1][s] = hx_scale_for(bt[1]); sc[2][s] = hx_scale_for(bt[2]);
         }
         sc[3][0] = sc[3][1] = hx_scale_for(bu);
     }

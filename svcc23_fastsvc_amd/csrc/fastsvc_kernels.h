@@ -194,6 +194,7 @@ struct CondStage0Params {
     const float* winv[3][2];     // float32 storage: inverse per-channel weight scales of those fragments
     const float* bnd[4][2];      // float32 storage: (l1, bmax) of c1, c2, c3, film.conv (bounds of the LDS-resident tensors)
     const float* bnd_r[2];       //   ... and of the 1x1 residual conv
+    const float* cbnd[2];        // float32 storage: per-channel bounds [tensor c1 c2 h u][alpha | beta][C]: |t[c]| <= alpha amax + beta (packer)
     const void* w5;              // heads: [32-channel chunk][tap][16-channel tile][piece][lane][8]
     const float* b5;             // (2C): lft + sine biases summed
     const float* winv5;
@@ -227,6 +228,7 @@ struct CondStage1Params {
     const float* winv[3][2];
     const float* bnd[4][2];      // float32 storage: (l1, bmax) of c1, c2, c3, film.conv
     const float* bnd_r[2];
+    const float* cbnd[2];        // float32 storage: per-channel bounds [c1 c2 h u][alpha | beta][C] (packer)
     const void* w5;              // heads 2C -> 2C: [group of 3 tiles][chunk][tap][tile][piece]
     const float* b5;
     const float* winv5;

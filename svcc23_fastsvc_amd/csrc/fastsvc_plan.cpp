@@ -119,6 +119,10 @@ struct DownStage {
     PackedConv film[2];
     PackedConv heads;
     PackedConv filmc;            // film conv (both signals, block-diagonal 2C -> 2C) -> heads as ONE launch (MODE_CHAIN)
+    // whole-stage launches (fastsvc_cond.hip), float32 storage: per-channel bounds of the LDS-resident tensors c1, c2, h,
+    // u as affine functions of the stage input's measured maximum, |t[c]| <= alpha[c] * amax + beta[c]:
+    // [tensor 0..3][alpha | beta][C] floats per signal (0 = the plan has none)
+    size_t cbnd_off[2] = {0, 0};
 };
 
 struct UpStage {
@@ -202,6 +206,7 @@ struct fastsvc_plan {
     struct UpHeadJob { PackedConv* c; std::string first, res, up; int cin, C; };
     std::vector<UpHeadJob> up_head_jobs;
     std::vector<RawParam*> raw_jobs;
+    std::vector<int> cond_bound_jobs;   // conditioning stages with cbnd tables
     double flops_per_sample = 0.0;
     int storage = 0;                    // activation storage in the workspace: 0 float32, 1 bfloat16
     bool compact = false;               // workspace layout: intermediates of different stages share buffers (fastsvc_plan_set_workspace_mode)
@@ -438,6 +443,10 @@ int build_plan(fastsvc_plan& P) {
         {
             const std::string convs[2] = {fl + ".conv", fs + ".conv"};
             P.add_film_chain(d.filmc, d.heads, d.C, convs, heads);
+        }
+        if (k < 2) {
+            for (int i = 0; i < 2; ++i) d.cbnd_off[i] = P.alloc((size_t)4 * 2 * d.C);
+            P.cond_bound_jobs.push_back(k);
         }
         // 2*MAC per column: 1x1 + k3 first + two k3 (C->C) + three FiLM k3 convs, two signals
         const double per_col = 2.0 * ((double)cin * d.C + 3.0 * cin * d.C + 2.0 * 3.0 * d.C * d.C + 3.0 * 3.0 * d.C * d.C);
@@ -926,6 +935,56 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             bmax = std::max(bmax, std::fabs(LF.b[co]));
         }
         cst[0] = l1; cst[1] = bmax; cst[2] = 0.f; cst[3] = 0.f;
+        return FASTSVC_OK;
+    });
+    task_names.insert(task_names.end(), plan->cond_bound_jobs.size(), "cond_bounds");
+    for (int k_ : plan->cond_bound_jobs) tasks.emplace_back([&, k = k_]() -> int {
+        // |c1| <= A1 x, |c2| <= M2 |c1| + |b2|, |h| <= M3 |c2| + |b3| + |r|, |u| <= M4 |h| + |b4| (LeakyReLU only shrinks),
+        // M[co][ci] = sum over taps of |w|: carried as per-channel (alpha, beta) pairs, bound = alpha * amax(x) + beta.
+        // The max over channels of these is what the launch scales a tile by: orders of magnitude tighter than chaining
+        // (largest row sum) x (largest input) layer by layer when weight_g differs across channels by decades.
+        const DownStage& d = plan->down[k];
+        const int C = d.C, Cin = d.Cin;
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const std::string pre = std::string("downsampling_") + (sgn ? "sine." : "lft.") + std::to_string(k);
+            const std::string fpre = std::string("film_") + (sgn ? "sine." : "lft.") + std::to_string(k);
+            HostLayer L1, LR, L2, L3, L4;
+            int rc = fetch_layer(sd, pre + ".downsample_block.2", C, (size_t)Cin * 3, L1); if (rc != FASTSVC_OK) return rc;
+            rc = fetch_layer(sd, pre + ".residual_block.0", C, (size_t)Cin, LR); if (rc != FASTSVC_OK) return rc;
+            rc = fetch_layer(sd, pre + ".downsample_block.4", C, (size_t)C * 3, L2); if (rc != FASTSVC_OK) return rc;
+            rc = fetch_layer(sd, pre + ".downsample_block.6", C, (size_t)C * 3, L3); if (rc != FASTSVC_OK) return rc;
+            rc = fetch_layer(sd, fpre + ".conv", C, (size_t)C * 3, L4); if (rc != FASTSVC_OK) return rc;
+            std::vector<double> a(C), b(C), a2(C), b2(C);
+            float* out = blob + d.cbnd_off[sgn];
+            auto emit = [&](int t) { for (int c = 0; c < C; ++c) { out[(t * 2 + 0) * C + c] = (float)(a[c] * 1.0000005); out[(t * 2 + 1) * C + c] = (float)(b[c] * 1.0000005); } };
+            for (int c = 0; c < C; ++c) {
+                double sum = 0.0;
+                for (size_t i = 0; i < (size_t)Cin * 3; ++i) sum += std::fabs((double)L1.w[c * Cin * 3 + i]);
+                a[c] = sum; b[c] = std::fabs((double)L1.b[c]);
+            }
+            emit(0);
+            auto through = [&](const HostLayer& L) {
+                for (int co = 0; co < C; ++co) {
+                    double sa = 0.0, sb = 0.0;
+                    for (int ci = 0; ci < C; ++ci) {
+                        const float* w = &L.w[((size_t)co * C + ci) * 3];
+                        const double m = std::fabs((double)w[0]) + std::fabs((double)w[1]) + std::fabs((double)w[2]);
+                        sa += m * a[ci]; sb += m * b[ci];
+                    }
+                    a2[co] = sa; b2[co] = sb + std::fabs((double)L.b[co]);
+                }
+                a.swap(a2); b.swap(b2);
+            };
+            through(L2); emit(1);
+            through(L3);
+            for (int c = 0; c < C; ++c) {                     // + the 1x1 residual conv of the stage's input
+                double sum = 0.0;
+                for (int i = 0; i < Cin; ++i) sum += std::fabs((double)LR.w[c * Cin + i]);
+                a[c] += sum; b[c] += std::fabs((double)LR.b[c]);
+            }
+            emit(2);
+            through(L4); emit(3);
+        }
         return FASTSVC_OK;
     });
     task_names.insert(task_names.end(), plan->raw_jobs.size(), "raw");
@@ -1583,6 +1642,7 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
         }
         q.bnd[0][s] = blob + d.c1_raw[s].bnd_off;
         q.bnd_r[s] = blob + d.r_raw[s].bnd_off;
+        q.cbnd[s] = d.cbnd_off[s] ? blob + d.cbnd_off[s] : nullptr;
     }
     q.w5 = blob + d.heads.hx_off[prec]; q.b5 = blob + d.heads.b_off; q.winv5 = blob + d.heads.hx_inv_off;
     q.amax_in = P.storage == 0 ? amax_in : nullptr; q.amax_hd = P.storage == 0 ? amax_hd : nullptr;
@@ -1680,6 +1740,7 @@ hipError_t run_cond_stage1(const fastsvc_plan& P, const float* blob, const float
         }
         q.bnd[0][s] = blob + d.c1[s].bnd_off;
         q.bnd_r[s] = blob + d.r[s].bnd_off;
+        q.cbnd[s] = d.cbnd_off[s] ? blob + d.cbnd_off[s] : nullptr;
     }
     q.w5 = blob + d.heads.hx_off[prec]; q.b5 = blob + d.heads.b_off; q.winv5 = blob + d.heads.hx_inv_off;
     q.amax_in = P.storage == 0 ? amax_in : nullptr; q.amax_hd = P.storage == 0 ? amax_hd : nullptr;
