@@ -434,7 +434,8 @@ def run_cfg5(args, dist, world, rank, dev):
     gen.activation_storage = args.storage
     gen = gen.to(dev).train()
     disc = TRN.MelGANMultiScaleDiscriminator(**TRN.RECIPE["discriminator_params"]).to(dev).train()
-    trainer = TRN.TrainStep(gen, disc, dict(discriminator_train_start_steps=0), steps=1)
+    bf16 = args.storage == "bfloat16"
+    trainer = TRN.TrainStep(gen, disc, dict(discriminator_train_start_steps=0, autocast_dtype="bfloat16" if bf16 else None), steps=1)
     ppg, sine, lft, emb = S.device_batch(cfg, B, F, 5000 + rank, dev)
     g = torch.Generator(device=dev)
     g.manual_seed(77 + rank)
@@ -468,10 +469,14 @@ def run_cfg5(args, dist, world, rank, dev):
         "metric": "audio samples/sec (24 kHz) FastSVC training step", "value": world * B * T * args.steps / elapsed,
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"generator forward: {gen.plan.arithmetic}; backward / discriminator / losses: f32 PyTorch-ROCm",
+        "dtype": f"generator forward: {gen.plan.arithmetic}; " + ("generator backward: PyTorch-ROCm under bf16 autocast (f32 master weights, optimizer "
+                 "state, InstanceNorm statistics); discriminator, STFT and adversarial losses f32 (MIOpen's bf16 backward-data of the "
+                 "discriminator's first conv faults intermittently on this ROCm: training.py)" if bf16 else
+                 "backward / discriminator / losses: f32 PyTorch-ROCm"),
         "data": "synthetic",
         "config": {"workload": f"cfg5: full train step (generator fwd + bwd, MelGAN multi-scale discriminator, MR-STFT x6 + adversarial "
-                               f"losses, RAdam), batch {B} x {T} samples per GPU, data-parallel x{world} with a flat-bucket gradient all-reduce",
+                               f"losses, RAdam), batch {B} x {T} samples per GPU, data-parallel x{world} with a flat-bucket gradient all-reduce"
+                               + (", bfloat16 (BASELINE config 5's dtype)" if bf16 else ", float32 (--storage bfloat16: config 5's dtype)"),
                    "global_batch": world * B, "utterance_samples": T, "parallelism": f"data-parallel x{world}",
                    "generator_params": n_g, "discriminator_params": n_d,
                    "hip_path": "generator forward only (two per step); hand-written backward kernels are not built"},

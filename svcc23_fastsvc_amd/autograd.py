@@ -18,6 +18,7 @@ fallback for it: without the HIP library the forward raises as everywhere else.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, Optional
 
 import torch
@@ -125,14 +126,19 @@ class GeneratorFunction(torch.autograd.Function):
         emb = saved[3] if ctx.has_emb else None
         params = saved[4:] if ctx.has_emb else saved[3:]
         needs = ctx.needs_input_grad            # (module, names, x, s, l, spk_emb, *params)
-        with torch.enable_grad():
+        # bfloat16 activation storage (BASELINE config 5's dtype): the restatement runs under bf16 autocast - bf16
+        # convolutions / linears with float32 accumulation, float32 InstanceNorm - i.e. the precision the forward computed
+        # in; gradients come back in the float32 of the master parameters
+        amp = (torch.autocast(device_type="cuda", dtype=torch.bfloat16)
+               if getattr(ctx.module, "activation_storage", "float32") == "bfloat16" and x.is_cuda else contextlib.nullcontext())
+        with torch.enable_grad(), amp:
             ins = [t.detach().requires_grad_(needs[2 + i]) for i, t in enumerate((x, s, l))]
             e = None if emb is None else emb.detach().requires_grad_(needs[5])
             leaves = [p.detach().requires_grad_(needs[6 + i]) for i, p in enumerate(params)]
             w = folded_weights(dict(zip(ctx.names, leaves)))
             y = _forward_torch(w, ctx.module.upsampling_scales, ins[0], ins[1], ins[2], e)
             wanted = [t for t in ins + ([e] if e is not None else []) + leaves if t.requires_grad]
-            grads = torch.autograd.grad(y, wanted, grad_y, allow_unused=True) if wanted else []
+            grads = torch.autograd.grad(y, wanted, grad_y.to(y.dtype), allow_unused=True) if wanted else []
         it = iter(grads)
         out = [None, None]
         for t in ins:

@@ -24,6 +24,8 @@ against the LIVE reference by ``tests/golden/train_step.npz`` (``tests/golden/ma
 """
 from __future__ import annotations
 
+import contextlib
+
 import math
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -298,6 +300,23 @@ class TrainStep:
         self.opt_d = RAdam(discriminator.parameters(), **cfg["discriminator_optimizer_params"])
         self.sched_g = torch.optim.lr_scheduler.StepLR(self.opt_g, **cfg["generator_scheduler_params"])
         self.sched_d = torch.optim.lr_scheduler.StepLR(self.opt_d, **cfg["discriminator_scheduler_params"])
+        # BASELINE config 5's dtype: `autocast_dtype: "bfloat16"` runs the forward computations of the step - generator
+        # (HIP forward in bfloat16 activation storage when the module says so; its PyTorch backward re-evaluates the
+        # dataflow under the same autocast, see autograd.py), discriminator, adversarial losses - under
+        # torch.autocast; master weights, optimizer state, InstanceNorm statistics and the STFT loss stay float32
+        # (the reference has no AMP: train_fastsvc.py:157-240 - this is what "bf16 train step" can mean for it).
+        # The DISCRIMINATOR stays float32 unless `autocast_discriminator: True`: on this ROCm (7.0 / MIOpen of torch 2.10)
+        # the bf16 backward-data of the MelGAN discriminator's first conv (1 -> 16 channels, k = 15:
+        # `MIOpenDriver convbfp16 -n 32 -c 1 -W 4014 -k 16 -x 15 -F 2`) intermittently dies with a GPU memory access
+        # fault, depending on which solver MIOpen's find step picked (caught with MIOPEN_ENABLE_LOGGING_CMD=1)
+        ac = cfg.get("autocast_dtype")
+        self.autocast_dtype = getattr(torch, ac) if isinstance(ac, str) else ac
+
+    def _autocast(self, discriminator: bool = False):
+        dev = next(self.generator.parameters()).device
+        if self.autocast_dtype is None or dev.type != "cuda" or (discriminator and not self.config.get("autocast_discriminator", False)):
+            return contextlib.nullcontext()
+        return torch.autocast(device_type="cuda", dtype=self.autocast_dtype)
 
     def step(self, batch, log: bool = True) -> Dict[str, float]:
         """batch = ((ppg, sine, lft[, spk_emb]), y) - the Collater's layout (train_fastsvc.py:537-551).
@@ -307,14 +326,16 @@ class TrainStep:
         logd: Dict[str, torch.Tensor] = {}
         train_d = self.steps > cfg["discriminator_train_start_steps"]
         if self.steps > cfg.get("generator_train_start_steps", 0):
-            y_ = self.generator(*x)
-            sc, mag = self.stft(y_, y)
+            with self._autocast():
+                y_ = self.generator(*x)
+            sc, mag = self.stft(y_.float(), y.float())
             gen_loss = (sc + mag) * cfg.get("lambda_aux", 1.0)
             logd["spectral_convergence_loss"], logd["log_stft_magnitude_loss"] = sc.detach(), mag.detach()
             if train_d:
-                adv = generator_adversarial_loss(self.discriminator(y_))
+                with self._autocast(discriminator=True):
+                    adv = generator_adversarial_loss(self.discriminator(y_))
                 logd["adversarial_loss"] = adv.detach()
-                gen_loss = gen_loss + cfg["lambda_adv"] * adv
+                gen_loss = gen_loss + cfg["lambda_adv"] * adv.float()
             logd["generator_loss"] = gen_loss.detach()
             self.opt_g.zero_grad()
             gen_loss.backward()
@@ -326,8 +347,9 @@ class TrainStep:
         if train_d:
             with torch.no_grad():
                 y_ = self.generator(*x)                  # second forward, with the updated generator
-            real, fake = discriminator_adversarial_loss(self.discriminator(y_.detach()), self.discriminator(y))
-            dis_loss = real + fake
+            with self._autocast(discriminator=True):
+                real, fake = discriminator_adversarial_loss(self.discriminator(y_.detach()), self.discriminator(y))
+            dis_loss = real.float() + fake.float()
             logd["real_loss"], logd["fake_loss"], logd["discriminator_loss"] = real.detach(), fake.detach(), dis_loss.detach()
             self.opt_d.zero_grad()
             dis_loss.backward()
