@@ -360,3 +360,22 @@ def device_batch(cfg: GeneratorConfig, B: int, F: int, seed: int, device, sample
     lft = lft.repeat_interleave(64, dim=2)[:, :, :T].contiguous()
     emb = torch.randn((B, cfg.spk_emb_size), generator=g, device=device, dtype=torch.float32) * 5.0
     return ppg.contiguous(), sine.contiguous(), lft, emb
+
+
+def fill_module_from_hash(module, seed: int) -> None:
+    """Deterministic, library-independent parameter values for ANY torch module, by parameter NAME (a discriminator of the
+    recipe has 4.35 M parameters: too large for a fixture, and framework initialisers are not reproducible across
+    versions): weight_g = 1 + 0.1 n, biases 0.01 n, everything else 0.1 n, n = hash_normalish of the name's stream.
+    Used on both sides of the recipe-size training golden (tests/golden/make_golden.py train_recipe: the reference's
+    discriminator; tests/test_training.py: this package's)."""
+    import torch
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            n = hash_normalish(seed, stream_id("fill." + name), p.numel()).reshape(tuple(p.shape))
+            if name.endswith("weight_g"):
+                v = 1.0 + 0.1 * n
+            elif name.endswith("bias"):
+                v = 0.01 * n
+            else:
+                v = 0.1 * n
+            p.copy_(torch.from_numpy(v.astype(np.float32)))

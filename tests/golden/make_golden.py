@@ -19,6 +19,9 @@ Fixtures written:
   weight_norm_fold.npz  torch ``remove_weight_norm`` result for three layers (g, v -> w)
   tiny_grads.npz        autograd of the reference generator in train() mode (tiny width): d sum(r*y) / d every
                         parameter (weight_g / weight_v / bias) and input, with / without speaker embedding
+  train_recipe.npz      one Trainer._train_step at the recipe's own size (yaml-width generator + the yaml's discriminator,
+                        batch 32 x 16000): loss values, per-parameter step norms and 4-element slices (`train_recipe`, ~2 min
+                        of CPU; not in the default list)
   train_step.npz        MR-STFT / adversarial loss values, a small MelGAN multi-scale discriminator's outputs, eight
                         RAdam steps, and two full Trainer._train_step calls (train_fastsvc.py:157-240): every
                         generator / discriminator parameter after each step
@@ -306,6 +309,67 @@ def train(M):
     print("train_step.npz:", len(out), "arrays")
 
 
+def train_recipe(M):
+    """train_recipe.npz: ONE full `Trainer._train_step` of the reference (train_fastsvc.py:157-240) at the RECIPE's size -
+    yaml-width generator, the yaml's MelGAN multi-scale discriminator (4.35 M parameters), batch 32 x 16000 samples
+    (fastsvc.yaml:71-72), both sub-networks training - BASELINE config 5 at its own size.  Weights, inputs and target are
+    regenerated on both sides from the integer-hash generator; the fixture holds the loss values, and per generator /
+    discriminator parameter the norm of the step it took plus a 4-element slice of the stepped tensor."""
+    import types
+    from harana.losses import MultiResolutionSTFTLoss, GeneratorAdversarialLoss, DiscriminatorAdversarialLoss
+    from harana.optimizers import RAdam
+    import yaml
+    with open(os.path.join(ROOT_REF, "egs/svcc23/fastsvc1/conf/fastsvc.yaml")) as f:
+        recipe = yaml.safe_load(f)
+    from oracle.refimport import _placeholder
+    for name in ("tensorboardX", "soundfile"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                _placeholder(name)
+    if not hasattr(sys.modules["tensorboardX"], "SummaryWriter"):
+        sys.modules["tensorboardX"].SummaryWriter = lambda *a, **k: None
+    from harana.bin import train_fastsvc as TR
+    cfg = S.FULL_CONFIG
+    B, F = int(recipe["batch_size"]), int(recipe["batch_length"]) // cfg.hop
+    T = F * cfg.hop
+    seed_w, seed_x, seed_d, seed_t = 301, 302, 303, 304
+    g, sd = build_reference(M, cfg, seed_w)
+    g.train()
+    D = M.MelGANMultiScaleDiscriminator(**recipe["discriminator_params"])
+    S.fill_module_from_hash(D, seed_d)
+    D.train()
+    conf = dict(recipe)
+    conf.update(discriminator_train_start_steps=0, use_stft_loss=True, lambda_aux=1.0, outdir="/tmp",
+                train_max_steps=10 ** 9, log_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, save_interval_steps=10 ** 9)
+    crit = {"gen_adv": GeneratorAdversarialLoss(), "dis_adv": DiscriminatorAdversarialLoss(),
+            "stft": MultiResolutionSTFTLoss(**recipe["stft_loss_params"])}
+    opt = {"generator": RAdam(g.parameters(), **recipe["generator_optimizer_params"]),
+           "discriminator": RAdam(D.parameters(), **recipe["discriminator_optimizer_params"])}
+    sch = {k: torch.optim.lr_scheduler.StepLR(opt[k], **recipe[k + "_scheduler_params"]) for k in opt}
+    tr = TR.Trainer(steps=1, epochs=0, data_loader={}, sampler={"train": None}, model={"generator": g, "discriminator": D},
+                    criterion=crit, optimizer=opt, scheduler=sch, config=conf, device=torch.device("cpu"))
+    tr.tqdm = types.SimpleNamespace(update=lambda n: None)
+    tr._check_train_finish = lambda: None
+    b = S.synth_batch(cfg, B, F, seed_x)
+    target = torch.from_numpy((0.3 * S.hash_normalish(seed_t, S.stream_id("train.target"), B * T)).reshape(B, 1, T).astype(np.float32))
+    x = tuple(torch.from_numpy(a) for a in (b.ppg, b.sine, b.lft, b.spk_emb))
+    before = {"g": {k: v.detach().clone() for k, v in g.state_dict().items()},
+              "d": {k: v.detach().clone() for k, v in D.state_dict().items()}}
+    out = {"meta": np.array([seed_w, seed_x, seed_d, seed_t, B, F], dtype=np.int64)}
+    tr.total_train_loss.clear()
+    tr._train_step((x, target))
+    for k, v in tr.total_train_loss.items():
+        out[f"loss/{k.split('/')[-1]}"] = np.float64(v)
+    for tag, module in (("g", g), ("d", D)):
+        for k, v in module.state_dict().items():
+            out[f"{tag}/step_norm/{k}"] = np.float64((v.detach() - before[tag][k]).double().norm())
+            out[f"{tag}/head/{k}"] = v.detach().flatten()[:4].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "train_recipe.npz"), **out)
+    print("train_recipe.npz:", len(out), "arrays", {k: float(v) for k, v in out.items() if k.startswith("loss/")})
+
+
 def fold(M):
     cfg = S.TINY_CONFIG
     g, sd = build_reference(M, cfg, 101)
@@ -325,7 +389,7 @@ if __name__ == "__main__":
     todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain", "grads", "train"]
     for name in todo:
         {"tiny": tiny, "full": full, "inference": inference, "fold": fold, "decode_chain": decode_chain, "grads": grads,
-         "train": train}[name](M)
+         "train": train, "train_recipe": train_recipe}[name](M)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
