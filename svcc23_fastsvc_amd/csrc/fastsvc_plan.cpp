@@ -1092,6 +1092,38 @@ struct Workspace {
     }
 };
 
+// Which conditioning stages run as ONE launch each (run_cond_stage0 / run_cond_stage1) - a function of the plan and
+// the frame count alone, so that the compact layout can leave out what those launches never write (h_k, r_k, c1 / c2,
+// film_u of the stage) and the forward can insist on the launch instead of falling back into missing buffers.
+int cond_env_mode() {
+    static const int v = std::getenv("FASTSVC_COND") ? std::atoi(std::getenv("FASTSVC_COND")) : 1;     // 0 none, 1 all, 4 stage 0 only
+    return v;
+}
+bool amax_scan_disabled() {
+    static const bool v = std::getenv("FASTSVC_NO_AMAX_SCAN") != nullptr;    // A/B timing only: inputs then count as unit-scale
+    return v;
+}
+bool cond_stage_whole(const fastsvc_plan& P, int k, int F) {
+    const int mode = cond_env_mode();
+    if (!P.compact || !mode || P.n < k + 2) return false;
+    if (P.storage == 0 && (F <= 4 || amax_scan_disabled())) return false;    // exact-f32 mode / no measured maxima
+    int64_t hop = 1;
+    for (int i = 0; i < P.n; ++i) hop *= P.cfg.upsampling_scales[i];
+    const int64_t T = hop * F;
+    const DownStage& d0 = P.down[0];
+    const DownStage& d1 = P.down[1];
+    if (d0.scale != 1 || d0.C != 24 || !d0.c2[0].hx || !d0.c3[0].hx || !d0.film[0].hx || !d0.heads.hx || d0.c2[0].MW != 2 ||
+        d0.heads.MW != 3 || d0.heads.nch32 != 2 || !d1.rc1[0].dec2 || (T % 8) != 0 || T % d1.scale != 0 || (T / d1.scale) % 4 != 0)
+        return false;
+    if (k == 0) return true;
+    if (k != 1 || (!(mode & 2) && mode != 1)) return false;
+    const DownStage& d2 = P.down[2];
+    const int64_t T1 = T / d1.scale;
+    return d1.C == 48 && d1.Cin == 24 && d1.rc1[0].hx && d1.rc1[0].MW == 3 && d1.c2[0].hx && d1.c3[0].hx && d1.film[0].hx &&
+           d1.c2[0].MW == 3 && d1.c2[0].nch32 == 2 && d1.heads.hx && d1.heads.MW == 3 && d1.heads.nch32 == 3 &&
+           d1.heads.ngroups == 2 && d2.rc1[0].dec2 && (T1 % 8) == 0 && T1 % d2.scale == 0 && (T1 / d2.scale) % 4 == 0;
+}
+
 // Default layout: every intermediate has its own buffer, all taps stay readable after a forward.
 // Compact layout (fastsvc_plan_set_workspace_mode): buffers whose lifetimes cannot overlap share one slot sized for
 // the largest user -
@@ -1121,10 +1153,14 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
     const int64_t T = hop * F;
     const size_t ae = P.storage == 1 ? 2 : sizeof(float);      // activation element size
     if (P.storage == 1) ws.add("ppg_act", B, P.cfg.in_channels, F, ae);
+    // stages that run as whole-stage launches keep their intermediates in LDS: zero-sized placeholders (the amax rows
+    // are indexed by buffer, taps of those names are empty)
+    const bool whole[2] = {cond_stage_whole(P, 0, F), cond_stage_whole(P, 0, F) && cond_stage_whole(P, 1, F)};
     if (P.compact) {
         int64_t down_max = 0, up_max = 0, a_max = 0, u_max = 0, Td = T, Ti = F;
         for (int k = 0; k < n; ++k) {
             Td /= P.down[k].scale;
+            if (k < 2 && whole[k]) continue;
             down_max = std::max<int64_t>(down_max, 2LL * B * P.down[k].C * Td);
             if (k + 1 < n) u_max = std::max<int64_t>(u_max, 2LL * B * P.down[k].C * Td);
         }
@@ -1143,21 +1179,22 @@ Workspace layout_workspace(const fastsvc_plan& P, int B, int F) {
         const char* ups[5] = {"xr", "u1", "xmid", "u2", "u3"};
         for (int j = 0; j < 5; ++j) slot_off[ups[j]] = base + aa + j * up;
         // film_u of the stages whose FiLM net runs on the helper stream: written and read there, one after the other
-        if (u_max > 0) slot_off["film_u"] = ws.add("shared.film_u", 1, 1, u_max, ae);
+        slot_off["film_u"] = ws.add("shared.film_u", 1, 1, u_max, ae);
     }
     int64_t Tk = T;
     for (int k = 0; k < n; ++k) {
         const DownStage& d = P.down[k];
         Tk = Tk / d.scale;
         const std::string s = std::to_string(k);
-        if (k > 0) ws.add("down_r." + s, 2 * B, d.C, Tk, ae);
-        add_shared("c1", "down_c1." + s, 2 * B, d.C, Tk, ae);
-        add_shared("c2", "down_c2." + s, 2 * B, d.C, Tk, ae);
-        ws.add("down_h." + s, 2 * B, d.C, Tk, ae);               // [lft batch ; sine batch]
+        const int64_t Bk = (k < 2 && whole[k]) ? 0 : B;
+        if (k > 0) ws.add("down_r." + s, 2 * Bk, d.C, Tk, ae);
+        add_shared("c1", "down_c1." + s, 2 * Bk, d.C, Tk, ae);
+        add_shared("c2", "down_c2." + s, 2 * Bk, d.C, Tk, ae);
+        ws.add("down_h." + s, 2 * Bk, d.C, Tk, ae);              // [lft batch ; sine batch]
         // h_0[..., ::s_1] compact: what the whole-stage launch of stage 0 hands to stage 1 instead of h_0 (run_cond_stage0)
         if (k == 0 && n > 1) ws.add("down_hd.1", 2 * B, d.C, Tk / P.down[1].scale, ae);
         if (k == 1 && n > 2) ws.add("down_hd.2", 2 * B, d.C, Tk / P.down[2].scale, ae);     // ... and of stage 1 (run_cond_stage1)
-        if (k + 1 < n) add_shared("film_u", "film_u." + s, B, 2 * d.C, Tk, ae);     // channels [lft ; sine]
+        if (k + 1 < n) add_shared("film_u", "film_u." + s, Bk, 2 * d.C, Tk, ae);    // channels [lft ; sine]
         else ws.add("film_u." + s, B, 2 * d.C, Tk, ae);          // (last stage: on the caller's stream)
         ws.add("ss." + s, B, 2 * d.C, Tk, ae);                   // channels [scale ; shift]
     }
@@ -1615,15 +1652,11 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
                            const int* lengths, float* ss, float* hd, const float* amax_in, float* amax_hd, hipStream_t stream,
                            Profiler* prof, bool& done) {
     done = false;
-    static const int cond_env = std::getenv("FASTSVC_COND") ? std::atoi(std::getenv("FASTSVC_COND")) : 1;
     static const int tpw_env = std::getenv("FASTSVC_COND_TPW") ? std::atoi(std::getenv("FASTSVC_COND_TPW")) : 0;
     // (float32 storage needs the measured maxima of the raw signals: not with FASTSVC_NO_AMAX_SCAN)
-    if (!cond_env || P.n < 2 || g_exact_f32 || (P.storage == 0 && (!amax_in || !amax_hd))) return hipSuccess;      // FASTSVC_COND=0: separate launches (A/B)
+    if (!cond_stage_whole(P, 0, F) || g_exact_f32 || (P.storage == 0 && (!amax_in || !amax_hd))) return hipSuccess;
     const DownStage& d = P.down[0];
     const DownStage& d1 = P.down[1];
-    if (d.C != 24 || !d.c2[0].hx || !d.c3[0].hx || !d.film[0].hx || !d.heads.hx || d.c2[0].MW != 2 || d.heads.MW != 3 ||
-        d.heads.nch32 != 2 || !d1.rc1[0].dec2 || (T % 8) != 0 || (T / d1.scale) % 4 != 0 || T % d1.scale != 0)
-        return hipSuccess;
     const int prec = P.storage == 1 ? 1 : 0;
     CondStage0Params q;
     std::memset(&q, 0, sizeof(q));
@@ -1712,16 +1745,10 @@ hipError_t run_cond_stage1(const fastsvc_plan& P, const float* blob, const float
                            float* ss, float* hd, const float* amax_in, float* amax_hd, hipStream_t stream, Profiler* prof,
                            bool& done) {
     done = false;
-    static const int cond_env = std::getenv("FASTSVC_COND") ? std::atoi(std::getenv("FASTSVC_COND")) : 1;
     static const int tpw_env = std::getenv("FASTSVC_COND1_TPW") ? std::atoi(std::getenv("FASTSVC_COND1_TPW")) : 0;
-    if (!(cond_env & 2) && cond_env != 1) return hipSuccess;                 // FASTSVC_COND: 0 none, 1 all, 4 stage 0 only
-    if (P.n < 3 || g_exact_f32 || (P.storage == 0 && (!amax_in || !amax_hd))) return hipSuccess;
+    if (!cond_stage_whole(P, 1, F) || g_exact_f32 || (P.storage == 0 && (!amax_in || !amax_hd))) return hipSuccess;
     const DownStage& d = P.down[1];
     const DownStage& d2 = P.down[2];
-    if (d.C != 48 || d.Cin != 24 || !d.rc1[0].dec2 || !d.rc1[0].hx || d.rc1[0].MW != 3 || !d.c2[0].hx || !d.c3[0].hx ||
-        !d.film[0].hx || d.c2[0].MW != 3 || d.c2[0].nch32 != 2 || !d.heads.hx || d.heads.MW != 3 || d.heads.nch32 != 3 ||
-        d.heads.ngroups != 2 || !d2.rc1[0].dec2 || (T1 % 8) != 0 || T1 % d2.scale != 0 || (T1 / d2.scale) % 4 != 0)
-        return hipSuccess;
     const int prec = P.storage == 1 ? 1 : 0;
     CondStage1Params q;
     std::memset(&q, 0, sizeof(q));
@@ -2309,7 +2336,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
     const std::ptrdiff_t sig_bytes = reinterpret_cast<const char*>(sine) - reinterpret_cast<const char*>(lft);
     if (sig_bytes % (std::ptrdiff_t)sizeof(float) != 0) return fail(FASTSVC_E_INVALID, "sine / lft must be 4-byte aligned");
     const long sig_stride = (long)(sig_bytes / (std::ptrdiff_t)sizeof(float));
-    static const bool no_scan = std::getenv("FASTSVC_NO_AMAX_SCAN") != nullptr;    // A/B timing only: inputs then count as unit-scale
+    const bool no_scan = amax_scan_disabled();                     // A/B timing only: inputs then count as unit-scale
     if (P.storage == 0 && !no_scan) {
         // float32 storage: largest magnitudes of the inputs (scales of the split-binary16 staging) and zeroed amax
         // rows of the intermediates - ONE small launch, first thing on the caller's stream (everything else is
@@ -2466,6 +2493,8 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                 hprev = buf("down_hd.1"); Cprev = d.C; Tprev = Tk / P.down[1].scale; hprev_compact = true;
                 continue;
             }
+            // (the layout left this stage's buffers out: there is nothing to fall back into)
+            if (cond_stage_whole(P, 0, F)) return fail(FASTSVC_E_HIP, "whole-stage launch of stage 0 declined at run time");
         }
         if (k == 1 && P.compact && hprev_compact && n > 2) {
             bool whole = false;
@@ -2475,6 +2504,7 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
                 hprev = buf("down_hd.2"); Cprev = d.C; Tprev = Tk / P.down[2].scale; hprev_compact = true;
                 continue;
             }
+            if (cond_stage_whole(P, 1, F)) return fail(FASTSVC_E_HIP, "whole-stage launch of stage 1 declined at run time");
         }
         // Stage 0 as ONE launch where it has the variant (MODE_CHAIN1): the staging waves compute the 1 -> C conv
         // from the raw signal, so neither c1 nor c2 reaches memory; a tuning pass times it against the other path

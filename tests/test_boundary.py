@@ -42,6 +42,26 @@ def test_plan_sizes_and_flops():
     assert plan.launch_count(True) == plan.launch_count(False) + 1
 
 
+def test_compact_layout_leaves_out_what_the_whole_stage_launches_keep_in_lds():
+    """Compact plans run conditioning stages 0 and 1 as one launch each (csrc/fastsvc_cond.hip): h_k, r_k, c1 / c2 and
+    film_u of those stages never reach memory, so the layout holds zero-sized placeholders for them (the names stay valid
+    taps) - except in the exact-float32 mode of very short inputs (F <= 4), which runs the separate launches."""
+    full = A.Plan(S.FULL_CONFIG)
+    for storage in ("float32", "bfloat16"):
+        plan = A.Plan(S.FULL_CONFIG, storage=storage, compact_workspace=True)
+        B, F = 64, 1500
+        for name in ("down_h.0", "down_h.1", "down_r.1", "down_c1.0", "down_c2.1", "film_u.0", "film_u.1"):
+            assert plan.tap_info(name, B, F)[1] == 0, name
+            assert full.tap_info(name, B, F)[1] > 0, name
+        for name in ("down_hd.1", "down_hd.2", "ss.0", "ss.1", "down_h.2", "down_r.2", "film_u.2", "down_h.3"):
+            assert plan.tap_info(name, B, F)[1] == full.tap_info(name, B, F)[1] > 0, name
+        # cfg3 (64 x 10 s): 18.7 GB float32 / 9.4 GB bfloat16, below 45 % of the one-buffer-per-tensor float32 layout
+        frac = plan.workspace_bytes(B, F) / full.workspace_bytes(B, F)
+        assert frac < (0.45 if storage == "float32" else 0.23), frac
+    short = A.Plan(S.FULL_CONFIG, compact_workspace=True)
+    assert short.tap_info("down_h.0", 2, 4)[1] == 4 * 24 * 4 * S.FULL_CONFIG.hop
+
+
 def test_plan_rejects_bad_config():
     with pytest.raises(ValueError):
         A.Plan(S.GeneratorConfig(in_channels=0))

@@ -219,7 +219,7 @@ def test_compact_workspace_same_waveform_less_memory(dev):
     cfg = S.FULL_CONFIG
     sd = S.synth_state_dict(cfg, 33)
     full, compact = A.Plan(cfg), A.Plan(cfg, compact_workspace=True)
-    assert compact.workspace_bytes(64, 1500) < 0.66 * full.workspace_bytes(64, 1500)
+    assert compact.workspace_bytes(64, 1500) < 0.45 * full.workspace_bytes(64, 1500)
     blob = full.pack(sd).to(dev)
     B, F = 3, 120
     ins = list(S.device_batch(cfg, B, F, 34, dev))
