@@ -239,6 +239,28 @@ size_t fastsvc_loudness_scratch_bytes(int32_t B, int32_t T, int32_t hop);
 int fastsvc_loudness_extract(const float* audio, float* out, void* scratch, int32_t B, int32_t T, int32_t hop,
                              float sample_rate, void* stream);
 
+/* ---- the multi-resolution STFT loss of the training step, forward and backward ----
+ * Replaces MultiResolutionSTFTLoss.forward(x, y) (harana/losses/stft_loss.py:131-180; STFTLoss :100-128, the magnitude
+ * stft() :21-51, SpectralConvergenceLoss :54-74, LogSTFTMagnitudeLoss :77-97) and the gradient autograd derives from
+ * it for the predicted signal x (the call site: harana/bin/train_fastsvc.py:163-170):
+ *   x, y      (B, T) device float32: predicted / ground-truth waveforms, one per row
+ *   n_res resolutions: fft_sizes[i] (a power of two in [8, 2048]: anything else FASTSVC_E_UNSUPPORTED), hop_sizes[i],
+ *             win_lengths[i] <= fft_sizes[i] (HOST arrays); windows[i] = device pointer to win_lengths[i] window values
+ *             (HOST array of pointers: whatever getattr(torch, window)(win_length) gives; centred in the frame)
+ *   frames are centred with reflect padding (fft_size / 2 < T, else FASTSVC_E_INVALID - torch raises there too)
+ *   loss      device float32 [2]: (spectral convergence, log STFT magnitude), each averaged over the resolutions
+ *   scratch   fastsvc_stft_loss_scratch_bytes(...) device bytes; the forward leaves the per-resolution sums there,
+ *             the backward of the SAME (x, y) reads them and uses the rest for the frame gradients
+ *   grad_loss device float32 [2]: incoming gradients of (sc, mag);  grad_x (B, T): d(grad_loss . loss) / dx
+ * No atomics: loss and gradient are bit-reproducible.  Asynchronous on `stream`. */
+size_t fastsvc_stft_loss_scratch_bytes(int32_t B, int32_t T, int32_t n_res, const int32_t* fft_sizes, const int32_t* hop_sizes);
+int fastsvc_stft_loss_forward(const float* x, const float* y, int32_t B, int32_t T, int32_t n_res, const int32_t* fft_sizes,
+                              const int32_t* hop_sizes, const int32_t* win_lengths, const float* const* windows,
+                              float* loss, void* scratch, void* stream);
+int fastsvc_stft_loss_backward(const float* x, const float* y, int32_t B, int32_t T, int32_t n_res, const int32_t* fft_sizes,
+                               const int32_t* hop_sizes, const int32_t* win_lengths, const float* const* windows,
+                               const float* grad_loss, float* grad_x, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

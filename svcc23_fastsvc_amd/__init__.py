@@ -5,6 +5,7 @@ from .engine import FastSVCError, Plan, load_library, library_path, gather_padde
 from .generator import FastSVCGenerator, install_into_harana  # noqa: F401
 from .signal import SignalGenerator  # noqa: F401
 from .loudness import loudness_extract  # noqa: F401
+from .stft_loss import MultiResolutionSTFTLoss  # noqa: F401
 
-__all__ = ["FastSVCGenerator", "SignalGenerator", "loudness_extract", "GeneratorConfig", "Plan", "FastSVCError", "install_into_harana",
+__all__ = ["FastSVCGenerator", "SignalGenerator", "loudness_extract", "MultiResolutionSTFTLoss", "GeneratorConfig", "Plan", "FastSVCError", "install_into_harana",
            "load_library", "library_path", "gather_padded", "FULL_CONFIG", "TINY_CONFIG"]

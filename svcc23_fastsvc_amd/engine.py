@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "fastsvc_stream_prepare", "fastsvc_stream_release", "fastsvc_split_half", "fastsvc_plan_set_workspace_mode",
     "fastsvc_loudness_frames", "fastsvc_loudness_scratch_bytes", "fastsvc_loudness_extract",
     "fastsvc_gather_padded",
+    "fastsvc_stft_loss_scratch_bytes", "fastsvc_stft_loss_forward", "fastsvc_stft_loss_backward",
 )
 
 
@@ -104,6 +105,12 @@ def load_library():
     lib.fastsvc_loudness_scratch_bytes.restype = sz
     lib.fastsvc_loudness_extract.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp]
     lib.fastsvc_loudness_extract.restype = ctypes.c_int
+    lib.fastsvc_stft_loss_scratch_bytes.argtypes = [i32, i32, i32, vp, vp]
+    lib.fastsvc_stft_loss_scratch_bytes.restype = sz
+    lib.fastsvc_stft_loss_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.fastsvc_stft_loss_forward.restype = ctypes.c_int
+    lib.fastsvc_stft_loss_backward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.fastsvc_stft_loss_backward.restype = ctypes.c_int
     lib.fastsvc_split_half.argtypes = [vp, i64, vp, vp, vp]
     lib.fastsvc_split_half.restype = None
     lib.fastsvc_stream_prepare.argtypes = [vp]

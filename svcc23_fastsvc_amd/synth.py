@@ -379,3 +379,34 @@ def fill_module_from_hash(module, seed: int) -> None:
             else:
                 v = 0.1 * n
             p.copy_(torch.from_numpy(v.astype(np.float32)))
+
+
+# ---------------------------------------------------------------------------
+# Multi-resolution STFT loss test signals (tests/golden/stft_loss.npz: the expected values come from the reference)
+# ---------------------------------------------------------------------------
+def stft_loss_cases(recipe_params: Dict) -> List[Tuple[str, np.ndarray, np.ndarray, Dict]]:
+    """(tag, x, y, constructor kwargs): predicted / target waveforms (B, T) float32 from the integer-hash generator.
+    ``recipe``: the yaml's six resolutions; ``default``: the class defaults (window shorter than the frame, hops that do
+    not divide it, odd length); ``floor``: a silent and a very quiet prediction, a target with a silent stretch (bins
+    at the 1e-7 power floor, where clamp passes no gradient)."""
+    def noise(seed, B, T, amp):
+        return (hash_normalish(seed, 7, B * T).reshape(B, T) * amp).astype(np.float32)
+
+    def tone(B, T, f):
+        t = np.arange(T, dtype=np.float64)[None, :]
+        return (0.4 * np.sin(2 * np.pi * f * (1.0 + 0.1 * np.arange(B)[:, None]) * t / 24000.0)).astype(np.float32)
+
+    recipe = dict(recipe_params)
+    default = dict(fft_sizes=[1024, 2048, 512], hop_sizes=[120, 240, 50], win_lengths=[600, 1200, 240], window="hann_window")
+    cases = []
+    y = tone(2, 4000, 220.0) + noise(31, 2, 4000, 0.05)
+    cases.append(("recipe", (y + noise(32, 2, 4000, 0.1)).astype(np.float32), y, recipe))
+    y = tone(2, 3001, 330.0) + noise(33, 2, 3001, 0.1)
+    cases.append(("default", (0.8 * y + noise(34, 2, 3001, 0.05)).astype(np.float32), y, default))
+    y = tone(3, 2500, 440.0) + noise(35, 3, 2500, 0.02)
+    y[1, 700:1900] = 0.0
+    x = (y + noise(36, 3, 2500, 0.1)).astype(np.float32)
+    x[0] = 0.0
+    x[1] = noise(37, 1, 2500, 1e-5)[0]
+    cases.append(("floor", x, y.astype(np.float32), recipe))
+    return cases

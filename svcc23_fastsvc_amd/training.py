@@ -295,7 +295,14 @@ class TrainStep:
         self.group = group
         self.steps = int(steps)
         dev = next(generator.parameters()).device
-        self.stft = MultiResolutionSTFTLoss(**cfg["stft_loss_params"]).to(dev)
+        # on the GPU the criterion is the HIP one (stft_loss.py: forward and backward kernels, csrc/fastsvc_stftloss.hip);
+        # the torch composition below serves the CPU host-logic / gloo tests and `stft_loss_impl: "torch"` A/B runs
+        impl = cfg.get("stft_loss_impl", "hip" if dev.type == "cuda" else "torch")
+        if impl == "hip":
+            from .stft_loss import MultiResolutionSTFTLoss as HipMultiResolutionSTFTLoss
+            self.stft = HipMultiResolutionSTFTLoss(**cfg["stft_loss_params"]).to(dev)
+        else:
+            self.stft = MultiResolutionSTFTLoss(**cfg["stft_loss_params"]).to(dev)
         self.opt_g = RAdam(generator.parameters(), **cfg["generator_optimizer_params"])
         self.opt_d = RAdam(discriminator.parameters(), **cfg["discriminator_optimizer_params"])
         self.sched_g = torch.optim.lr_scheduler.StepLR(self.opt_g, **cfg["generator_scheduler_params"])

@@ -25,6 +25,10 @@ Fixtures written:
   train_step.npz        MR-STFT / adversarial loss values, a small MelGAN multi-scale discriminator's outputs, eight
                         RAdam steps, and two full Trainer._train_step calls (train_fastsvc.py:157-240): every
                         generator / discriminator parameter after each step
+  stft_loss.npz         the reference MultiResolutionSTFTLoss (stft_loss.py:131-180) on three small cases - the recipe's six
+                        resolutions, the class defaults (window shorter than the frame, hop not dividing it) and a batch
+                        with a silent and a very quiet prediction (bins at the 1e-7 floor): sc, mag and autograd's
+                        d sc / dx, d mag / dx
   decode_chain.npz      decode_fastsvc.py:160-189 per utterance for three utterances of different
                         length: F0Statistics.estimate / .convert (features.py:41-108, std forced to 1),
                         then ``inference()`` with the converted F0 (noise_amp=0)
@@ -384,12 +388,34 @@ def fold(M):
     np.savez_compressed(os.path.join(HERE, "weight_norm_fold.npz"), **out)
 
 
+def stft_loss(M):
+    """stft_loss.npz: inputs are regenerated from seeds (numpy default_rng) by the tests; expected values stored."""
+    from harana.losses import MultiResolutionSTFTLoss
+    import yaml
+    with open(os.path.join(ROOT_REF, "egs/svcc23/fastsvc1/conf/fastsvc.yaml")) as f:
+        recipe = yaml.safe_load(f)
+    out = {}
+    for tag, x, y, params in S.stft_loss_cases(recipe["stft_loss_params"]):
+        crit = MultiResolutionSTFTLoss(**params)
+        for which in (0, 1):
+            xt = torch.from_numpy(x).clone().requires_grad_(True)
+            losses = crit(xt, torch.from_numpy(y))
+            losses[which].backward()
+            out[f"{tag}/grad_{('sc', 'mag')[which]}"] = xt.grad.numpy().copy()
+        out[f"{tag}/sc"], out[f"{tag}/mag"] = np.float64(losses[0]), np.float64(losses[1])
+        for k, v in params.items():
+            if k != "window":
+                out[f"{tag}/{k}"] = np.asarray(v, np.int64)
+    np.savez_compressed(os.path.join(HERE, "stft_loss.npz"), **out)
+    print("stft_loss.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     M = import_reference()
-    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain", "grads", "train"]
+    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain", "grads", "train", "stft_loss"]
     for name in todo:
         {"tiny": tiny, "full": full, "inference": inference, "fold": fold, "decode_chain": decode_chain, "grads": grads,
-         "train": train, "train_recipe": train_recipe}[name](M)
+         "train": train, "train_recipe": train_recipe, "stft_loss": stft_loss}[name](M)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
