@@ -261,6 +261,24 @@ int fastsvc_stft_loss_backward(const float* x, const float* y, int32_t B, int32_
                                const int32_t* hop_sizes, const int32_t* win_lengths, const float* const* windows,
                                const float* grad_loss, float* grad_x, void* scratch, void* stream);
 
+/* ---- the convolutions of the generator's backward pass (float32 matrix-core kernels) ----
+ * What autograd runs for every Conv1d / Conv2d(1 x k) of the generator when the reference trainer calls
+ * gen_loss.backward() (harana/bin/train_fastsvc.py:183; the layers: harana/layers/residual_block.py:27-48,
+ * harana/models/fastsvc.py:34-232 - all stride 1, "same" zero padding, k = 1 or 3, dilation d with (k / 2) d <= 27):
+ *   fastsvc_conv1d_forward   y[b, o, t] = bias[o] + sum_{i, k} w[o, i, k] x[b, i, t + (k - k/2) d]
+ *       x (B, Cin, T), y (B, Cout, T), w (Cout, Cin, K), bias (Cout) or NULL - device float32, contiguous.
+ *       transposed != 0: w is read as (Cin, Cout, K) with flipped taps - with x = dy and w the forward weight this IS the
+ *       backward-data convolution dx = conv_transpose(dy, w) (Cin = the forward's Cout, Cout = the forward's Cin).
+ *   fastsvc_conv1d_backward_weight   dw[o, i, k] = sum_{b, t} dy[b, o, t] x[b, i, t + (k - k/2) d],  dbias[o] = sum dy
+ *       (dbias may be NULL); both are overwritten.  scratch: fastsvc_conv1d_backward_weight_scratch_bytes(...) device
+ *       bytes (per-slab partial sums, added in a fixed order: bit-reproducible).
+ * Anything else (even k, k > 3, longer halos): FASTSVC_E_UNSUPPORTED.  Asynchronous on `stream`. */
+int fastsvc_conv1d_forward(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin, int32_t Cout,
+                           int32_t T, int32_t K, int32_t dilation, int32_t transposed, void* stream);
+size_t fastsvc_conv1d_backward_weight_scratch_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t T, int32_t K);
+int fastsvc_conv1d_backward_weight(const float* x, const float* dy, float* dw, float* dbias, void* scratch, int32_t B, int32_t Cin,
+                                   int32_t Cout, int32_t T, int32_t K, int32_t dilation, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,8 @@ import torch.nn.functional as F
 
 LRELU_SLOPE = 0.2
 IN_EPS = 1e-5
+# GPU: the convolutions of the differentiated dataflow are HIP graph nodes (False: MIOpen's, for A/B runs and tests)
+HIP_CONV_BACKWARD = True
 
 
 def folded_weights(named_params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -52,6 +54,10 @@ def folded_weights(named_params: Dict[str, torch.Tensor]) -> Dict[str, torch.Ten
 def _conv(x, w, prefix, dilation=1):
     weight = w[prefix + ".weight"]
     k = weight.shape[-1]
+    if x.is_cuda and HIP_CONV_BACKWARD:
+        # the graph node with the hand-written backward kernels (conv_grad.py: backward data / weight / bias in HIP)
+        from .conv_grad import conv1d
+        return conv1d(x, weight, w[prefix + ".bias"], dilation)
     return F.conv1d(x, weight, w[prefix + ".bias"], padding=(k // 2) * dilation, dilation=dilation)
 
 

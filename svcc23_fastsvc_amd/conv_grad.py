@@ -1,0 +1,96 @@
+"""``conv1d`` with hand-written HIP backward kernels - the convolution node of the generator's training graph
+(SURVEY.md §8 f2).  The reference trainer differentiates the generator with autograd
+(``harana/bin/train_fastsvc.py:157-205``); every convolution of the generator is a stride-1 "same" convolution with
+k = 1 or 3 (``harana/layers/residual_block.py:27-48``, ``harana/models/fastsvc.py:34-232``).  Here that node is
+
+* forward        ``fastsvc_conv1d_forward``            (float32 matrix-core kernel, ``csrc/fastsvc_convgrad.hip``)
+* backward data  the same kernel, weight read transposed with flipped taps
+* backward weight / bias   ``fastsvc_conv1d_backward_weight``
+
+instead of MIOpen's ``convolution_backward``.  float32 in, float32 out (master weights and gradients are float32);
+GPU tensors only - there is no CPU route."""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+from typing import Optional
+
+import torch
+
+from .engine import FastSVCError, load_library
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = load_library()
+    return _LIB
+
+
+def _guard(t: torch.Tensor):
+    """The kernels launch on the CURRENT device's stream: switch only when the tensor lives elsewhere (the context manager
+    costs ~10 us per call; the train step runs ~200 of these nodes)."""
+    return contextlib.nullcontext() if t.device.index == torch.cuda.current_device() else torch.cuda.device(t.device)
+
+
+def _launch_forward(x, w, bias, Cout: int, dilation: int, transposed: bool) -> torch.Tensor:
+    lib = _lib()
+    B, Cin, T = x.shape
+    K = w.shape[-1]
+    y = torch.empty((B, Cout, T), dtype=torch.float32, device=x.device)
+    with _guard(x):
+        rc = lib.fastsvc_conv1d_forward(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, Cin, Cout, T, K, int(dilation), int(transposed),
+                                        ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != 0:
+        raise FastSVCError(f"fastsvc_conv1d_forward failed ({rc}): B={B} Cin={Cin} Cout={Cout} T={T} K={K} dilation={dilation}")
+    return y
+
+
+class _Conv1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, dilation: int):
+        x = x.detach().to(torch.float32).contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.dilation, ctx.has_bias = int(dilation), bias is not None
+        return _launch_forward(x, w, b, w.shape[0], dilation, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.to(torch.float32).contiguous()
+        B, Cin, T = x.shape
+        Cout, _, K = w.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _launch_forward(dy, w, None, Cin, ctx.dilation, True)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            lib = _lib()
+            dw = torch.empty_like(w)
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            scratch = torch.empty(int(lib.fastsvc_conv1d_backward_weight_scratch_bytes(B, Cin, Cout, T, K)), dtype=torch.uint8,
+                                  device=x.device)
+            with _guard(x):
+                rc = lib.fastsvc_conv1d_backward_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(scratch), B, Cin, Cout, T, K, ctx.dilation,
+                                                        ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise FastSVCError(f"fastsvc_conv1d_backward_weight failed ({rc})")
+        return dx, dw, db, None
+
+
+def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1) -> torch.Tensor:
+    """``F.conv1d(x, weight, bias, padding=(k // 2) * dilation, dilation=dilation)`` for k = 1 or 3, differentiable with
+    respect to x, weight and bias through the HIP kernels."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and weight.is_cuda):
+        raise FastSVCError("conv1d (HIP) needs GPU tensors; there is no CPU fallback")
+    if x.dim() != 3 or weight.dim() != 3 or weight.shape[1] != x.shape[1]:
+        raise ValueError(f"conv1d: x {tuple(x.shape)} / weight {tuple(weight.shape)} do not fit")
+    return _Conv1dFn.apply(x, weight, bias, int(dilation))

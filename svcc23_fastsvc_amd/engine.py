@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "fastsvc_loudness_frames", "fastsvc_loudness_scratch_bytes", "fastsvc_loudness_extract",
     "fastsvc_gather_padded",
     "fastsvc_stft_loss_scratch_bytes", "fastsvc_stft_loss_forward", "fastsvc_stft_loss_backward",
+    "fastsvc_conv1d_forward", "fastsvc_conv1d_backward_weight", "fastsvc_conv1d_backward_weight_scratch_bytes",
 )
 
 
@@ -111,6 +112,12 @@ def load_library():
     lib.fastsvc_stft_loss_forward.restype = ctypes.c_int
     lib.fastsvc_stft_loss_backward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.fastsvc_stft_loss_backward.restype = ctypes.c_int
+    lib.fastsvc_conv1d_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.fastsvc_conv1d_forward.restype = ctypes.c_int
+    lib.fastsvc_conv1d_backward_weight_scratch_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.fastsvc_conv1d_backward_weight_scratch_bytes.restype = sz
+    lib.fastsvc_conv1d_backward_weight.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.fastsvc_conv1d_backward_weight.restype = ctypes.c_int
     lib.fastsvc_split_half.argtypes = [vp, i64, vp, vp, vp]
     lib.fastsvc_split_half.restype = None
     lib.fastsvc_stream_prepare.argtypes = [vp]

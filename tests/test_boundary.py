@@ -25,7 +25,7 @@ def _built():
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "fastsvc_hip.h")).read()
-    declared = set(re.findall(r"\b(fastsvc_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(fastsvc_[a-z0-9_]+)\s*\(", header))
     assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
     lib = ctypes.CDLL(A.library_path())
     for sym in declared:

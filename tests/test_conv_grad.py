@@ -1,0 +1,69 @@
+"""The convolution node of the generator's training graph: HIP forward / backward-data /
+backward-weight kernels (csrc/fastsvc_convgrad.hip, conv_grad.py) against float64 PyTorch convolutions on the CPU for every
+(channels, k, dilation) the generator has, ragged time lengths included.  Tolerance: float32 accumulation over
+Cin * k (forward, backward data) or B * T (backward weight) terms - 2e-5 of the result's largest magnitude."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import svcc23_fastsvc_amd as A
+from svcc23_fastsvc_amd import conv_grad as CG
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (and fail loudly without one)"
+    A.load_library()
+    return torch.device("cuda:0")
+
+
+def test_conv_grad_rejects_cpu_tensors_and_unsupported_shapes():
+    with pytest.raises(A.FastSVCError):
+        CG.conv1d(torch.zeros(1, 4, 16), torch.zeros(8, 4, 3))
+    lib = A.load_library()
+    one = ctypes.c_void_p(256)        # never dereferenced: the argument checks come first
+    assert lib.fastsvc_conv1d_forward(one, one, None, one, 1, 4, 8, 16, 5, 1, 0, None) == -5      # k = 5
+    assert lib.fastsvc_conv1d_forward(one, one, None, one, 1, 4, 8, 16, 3, 28, 0, None) == -5     # halo 28 > 27
+    assert lib.fastsvc_conv1d_forward(one, one, None, one, 1, 4, 8, 16, 2, 1, 0, None) == -1      # even k
+    assert lib.fastsvc_conv1d_backward_weight(one, one, one, None, one, 1, 4, 8, 0, 3, 1, None) == -1  # T = 0
+
+
+# (B, Cin, Cout, T, K, dilation): the generator's layer shapes (fastsvc.py:34-232 at the yaml widths) and odd sizes
+CASES = [
+    (2, 1, 24, 1000, 3, 1), (2, 1, 24, 1000, 1, 1), (2, 24, 24, 1000, 3, 2), (2, 24, 24, 777, 3, 4),
+    (2, 24, 48, 515, 3, 1), (2, 48, 96, 300, 1, 1), (2, 96, 96, 260, 3, 4), (3, 192, 192, 131, 3, 27),
+    (2, 192, 384, 75, 3, 1), (2, 144, 192, 50, 3, 1), (2, 24, 1, 1203, 3, 1), (1, 48, 48, 129, 3, 9),
+    (2, 96, 48, 400, 3, 3), (1, 7, 5, 33, 3, 2), (5, 20, 70, 128, 1, 1),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_forward_and_gradients_vs_float64(dev, case):
+    B, Cin, Cout, T, K, d = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn((B, Cin, T), generator=g)
+    w = torch.randn((Cout, Cin, K), generator=g) / np.sqrt(Cin * K)
+    b = torch.randn((Cout,), generator=g)
+    gy = torch.randn((B, Cout, T), generator=g)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    y64 = F.conv1d(x64, w64, b64, padding=(K // 2) * d, dilation=d)
+    y64.backward(gy.double())
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = CG.conv1d(xd, wd, bd, d)
+    y.backward(gy.to(dev))
+    for name, got, want in (("y", y.detach(), y64.detach()), ("dx", xd.grad, x64.grad), ("dw", wd.grad, w64.grad),
+                            ("db", bd.grad, b64.grad)):
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err <= 2e-5 * want.abs().max().item(), (name, err, want.abs().max().item())
+    # without a bias, and with only the input differentiated
+    x2 = x.to(dev).requires_grad_(True)
+    CG.conv1d(x2, w.to(dev), None, d).backward(gy.to(dev))
+    assert (x2.grad - xd.grad).abs().max().item() == 0.0
+    # slabs are added in a fixed order: the weight gradient is bit-reproducible
+    w3, b3 = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    CG.conv1d(x.to(dev), w3, b3, d).backward(gy.to(dev))
+    assert torch.equal(w3.grad, wd.grad) and torch.equal(b3.grad, bd.grad)
