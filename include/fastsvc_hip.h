@@ -279,6 +279,20 @@ size_t fastsvc_conv1d_backward_weight_scratch_bytes(int32_t B, int32_t Cin, int3
 int fastsvc_conv1d_backward_weight(const float* x, const float* dy, float* dw, float* dbias, void* scratch, int32_t B, int32_t Cin,
                                    int32_t Cout, int32_t T, int32_t K, int32_t dilation, void* stream);
 
+/* ---- FiLM affine + InstanceNorm + speaker bias + LeakyReLU of the up blocks, forward and backward ----
+ * `_feature_affine` with a speaker embedding (harana/models/fastsvc.py:115-139) followed by the LeakyReLU that opens the
+ * next conv block (fastsvc.py:60-83), as ONE node of the training graph:
+ *   out = lrelu((u - mean_t u) / sqrt(var_t u + eps) + bias[row]),  u = scale * x + shift
+ *   x, scale, shift, out (rows, T) device float32 with rows = B * C; bias (rows) = emb_projector(normalize(spk_emb));
+ *   mean, rstd (rows) are written by the forward and read by the backward of the same inputs
+ *   backward: dx, dscale, dshift (rows, T) and dbias (rows) from dout
+ * Asynchronous on `stream`. */
+int fastsvc_film_norm_forward(const float* x, const float* scale, const float* shift, const float* bias, float* out, float* mean,
+                              float* rstd, int32_t rows, int32_t T, float eps, float slope, void* stream);
+int fastsvc_film_norm_backward(const float* dout, const float* x, const float* scale, const float* shift, const float* bias,
+                               const float* mean, const float* rstd, float* dx, float* dscale, float* dshift, float* dbias,
+                               int32_t rows, int32_t T, float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,8 @@ import torch.nn.functional as F
 
 LRELU_SLOPE = 0.2
 IN_EPS = 1e-5
-# GPU: the convolutions of the differentiated dataflow are HIP graph nodes (False: MIOpen's, for A/B runs and tests)
+# GPU: the convolutions and the FiLM / InstanceNorm / LeakyReLU chains of the differentiated dataflow are HIP graph nodes
+# (False: MIOpen / aten ops, for A/B runs and tests)
 HIP_CONV_BACKWARD = True
 
 
@@ -102,13 +103,20 @@ def _forward_torch(w: Dict[str, torch.Tensor], scales, x, s, l, spk_emb: Optiona
                 return t
             return F.instance_norm(t, eps=IN_EPS) + bias       # (one fused kernel each way instead of six reductions / elementwise ops)
 
+        def aff_lrelu(t):
+            if bias is not None and t.is_cuda and HIP_CONV_BACKWARD:
+                # FiLM affine + InstanceNorm + speaker bias + LeakyReLU as ONE node, HIP forward and backward (conv_grad.py)
+                from .conv_grad import film_norm_lrelu
+                return film_norm_lrelu(t, sc, sh, bias, IN_EPS, LRELU_SLOPE)
+            return _lrelu(aff(t))
+
         a = _conv(y, w, f"{p}.conv_first")
         st = int(scales[i])
         xr = _conv(torch.repeat_interleave(a, st, dim=-1), w, f"{p}.residual_block.1")
         t = _lrelu(_conv(torch.repeat_interleave(_lrelu(a), st, dim=-1), w, f"{p}.upsample_block0.2"))
-        xm = _conv(_lrelu(aff(t)), w, f"{p}.conv_block1.1", 3) + xr
-        t = _conv(_lrelu(aff(xm)), w, f"{p}.conv_block2.1", 9)
-        y = _conv(_lrelu(aff(t)), w, f"{p}.conv_block3.1", 27) + xm
+        xm = _conv(aff_lrelu(t), w, f"{p}.conv_block1.1", 3) + xr
+        t = _conv(aff_lrelu(xm), w, f"{p}.conv_block2.1", 9)
+        y = _conv(aff_lrelu(t), w, f"{p}.conv_block3.1", 27) + xm
     return _conv(y, w, "conv_last")
 
 

@@ -94,3 +94,53 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if x.dim() != 3 or weight.dim() != 3 or weight.shape[1] != x.shape[1]:
         raise ValueError(f"conv1d: x {tuple(x.shape)} / weight {tuple(weight.shape)} do not fit")
     return _Conv1dFn.apply(x, weight, bias, int(dilation))
+
+
+class _FilmNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, bias, eps: float, slope: float):
+        x, scale, shift = (t.detach().to(torch.float32).contiguous() for t in (x, scale, shift))
+        B, C, T = x.shape
+        bias = bias.detach().to(torch.float32).reshape(B * C).contiguous()
+        lib = _lib()
+        out = torch.empty_like(x)
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        with _guard(x):
+            rc = lib.fastsvc_film_norm_forward(_ptr(x), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(out), _ptr(mean), _ptr(rstd), B * C, T,
+                                               ctypes.c_float(eps), ctypes.c_float(slope),
+                                               ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise FastSVCError(f"fastsvc_film_norm_forward failed ({rc})")
+        ctx.save_for_backward(x, scale, shift, bias, mean, rstd)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, scale, shift, bias, mean, rstd = ctx.saved_tensors
+        dout = dout.to(torch.float32).contiguous()
+        B, C, T = x.shape
+        lib = _lib()
+        dx, dsc, dsh = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        dbias = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        with _guard(x):
+            rc = lib.fastsvc_film_norm_backward(_ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(mean), _ptr(rstd),
+                                                _ptr(dx), _ptr(dsc), _ptr(dsh), _ptr(dbias), B * C, T, ctypes.c_float(ctx.slope),
+                                                ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise FastSVCError(f"fastsvc_film_norm_backward failed ({rc})")
+        return dx, dsc, dsh, dbias.view(B, C, 1), None, None
+
+
+def film_norm_lrelu(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
+                    slope: float = 0.2) -> torch.Tensor:
+    """``leaky_relu(instance_norm(scale * x + shift, eps) + bias, slope)`` - `_feature_affine` with a speaker embedding
+    (``fastsvc.py:115-139``) and the LeakyReLU behind it as one graph node with HIP forward and backward kernels
+    (``csrc/fastsvc_filmnorm.hip``).  x, scale, shift (B, C, T); bias (B, C, 1)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        raise FastSVCError("film_norm_lrelu (HIP) needs GPU tensors; there is no CPU fallback")
+    if x.dim() != 3 or scale.shape != x.shape or shift.shape != x.shape or bias.numel() != x.shape[0] * x.shape[1]:
+        raise ValueError(f"film_norm_lrelu: x {tuple(x.shape)}, scale {tuple(scale.shape)}, shift {tuple(shift.shape)}, "
+                         f"bias {tuple(bias.shape)} do not fit")
+    return _FilmNormFn.apply(x, scale, shift, bias, float(eps), float(slope))

@@ -67,3 +67,31 @@ def test_conv_forward_and_gradients_vs_float64(dev, case):
     w3, b3 = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
     CG.conv1d(x.to(dev), w3, b3, d).backward(gy.to(dev))
     assert torch.equal(w3.grad, wd.grad) and torch.equal(b3.grad, bd.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 24, 4000), (2, 48, 801), (4, 192, 50), (1, 5, 16001), (2, 7, 1)], ids=str)
+def test_film_norm_lrelu_node_vs_float64(dev, shape):
+    """`_feature_affine` with a speaker embedding + LeakyReLU (fastsvc.py:115-139, 60-83) as one HIP node: output and all four
+    gradients against the float64 composition on the CPU.  Rows with a large mean against a small spread included (the
+    two-pass variance): 1e-5 of each result's largest magnitude."""
+    B, C, T = shape
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = torch.randn(shape, generator=g)
+    sc = 1.0 + 0.3 * torch.randn(shape, generator=g)
+    sh = 0.2 * torch.randn(shape, generator=g)
+    sh[0, 0] += 300.0                                                     # mean >> spread in one row
+    bias = torch.randn((B, C, 1), generator=g)
+    gy = torch.randn(shape, generator=g)
+    leaves64 = [t.double().requires_grad_(True) for t in (x, sc, sh, bias)]
+    u = leaves64[1] * leaves64[0] + leaves64[2]
+    z = F.instance_norm(u, eps=1e-5) + leaves64[3] if T > 1 else (u - u.mean(-1, keepdim=True)) / (u.var(-1, unbiased=False, keepdim=True) + 1e-5).sqrt() + leaves64[3]
+    y64 = F.leaky_relu(z, 0.2)
+    y64.backward(gy.double())
+    leaves = [t.to(dev).requires_grad_(True) for t in (x, sc, sh, bias)]
+    y = CG.film_norm_lrelu(*leaves, 1e-5, 0.2)
+    y.backward(gy.to(dev))
+    for name, got, want in [("y", y.detach(), y64.detach())] + [(n, a.grad, b.grad) for n, a, b in zip("x sc sh bias".split(), leaves, leaves64)]:
+        err = (got.double().cpu() - want).abs().max().item()
+        # (the row with mean 300: u itself carries float32 rounding of 3e-5, divided by a spread of ~1)
+        assert err <= 1e-4 * max(want.abs().max().item(), 1.0), (name, err, want.abs().max().item())
