@@ -355,7 +355,25 @@ class Plan:
         27.0 ms against 22.5 ms for 64 x 1500 (tools/ragged_check.py) - so `Plan.forward` pads there too."""
         return F + ((-F) % 4)
 
-    def pack(self, state_dict: Mapping[str, object], reuse_pinned: bool = False) -> torch.Tensor:
+    def pack_prefetch(self, state_dict: Mapping[str, object]):
+        """Start the device-to-host copy of a state dict's device tensors (one gather, one asynchronous copy into a
+        page-locked buffer, one event on the current stream) and return a handle for ``pack(..., prefetched=handle)``.
+        A training step calls this right behind the optimizer update: the copy and the host-side packing then overlap
+        whatever the GPU is given next instead of draining the stream first."""
+        items = list(state_dict.items())
+        on_dev = [i for i, (_, v) in enumerate(items) if isinstance(v, torch.Tensor) and v.device.type != "cpu"]
+        if not on_dev:
+            return None
+        flat = torch.cat([items[i][1].detach().reshape(-1).to(torch.float32) for i in on_dev])
+        buf = getattr(self, "_pinned_params", None)
+        if buf is None or buf.numel() < flat.numel():
+            buf = self._pinned_params = torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True)
+        buf[: flat.numel()].copy_(flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flat.device))
+        return {"event": ev, "host": buf[: flat.numel()], "numels": [items[i][1].numel() for i in on_dev], "keep": flat}
+
+    def pack(self, state_dict: Mapping[str, object], reuse_pinned: bool = False, prefetched=None) -> torch.Tensor:
         """Fold weight-norm and pack a state dict (either key layout) into the kernel blob.
 
         Returns a CPU float32 tensor of ``blob_bytes`` bytes (upload or broadcast it).  Device tensors are gathered
@@ -366,7 +384,11 @@ class Plan:
         host = [None] * len(items)
         on_dev = [i for i, (_, v) in enumerate(items) if isinstance(v, torch.Tensor) and v.device.type != "cpu"]
         if on_dev:
-            flat = torch.cat([items[i][1].detach().reshape(-1).to(torch.float32) for i in on_dev]).cpu().numpy()
+            if prefetched is not None and prefetched["numels"] == [items[i][1].numel() for i in on_dev]:
+                prefetched["event"].synchronize()            # the copy issued by pack_prefetch (same tensors, same order)
+                flat = prefetched["host"].numpy()
+            else:
+                flat = torch.cat([items[i][1].detach().reshape(-1).to(torch.float32) for i in on_dev]).cpu().numpy()
             o = 0
             for i in on_dev:
                 n = items[i][1].numel()

@@ -182,6 +182,7 @@ class FastSVCGenerator(nn.Module):
         """Forget the packed device blob; the next forward folds and packs the parameters again."""
         self._blob = None
         self._blob_key = None
+        self._prefetch = None
 
     def _weights_key(self, device):
         key = (str(device),) + tuple((id(p), p._version) for p in self.parameters())
@@ -208,6 +209,7 @@ class FastSVCGenerator(nn.Module):
         state["_plan"] = None
         state["_blob"] = None
         state["_blob_key"] = None
+        state["_prefetch"] = None
         state["_tuned_shapes"] = set()
         return state
 
@@ -234,10 +236,28 @@ class FastSVCGenerator(nn.Module):
         key = self._weights_key(device)
         if self._blob is None or self._blob_key != key:
             on_gpu = torch.device(device).type != "cpu"
-            host = self._plan.pack(self.state_dict(), reuse_pinned=on_gpu)   # staging buffer: uploaded right here
+            pre = getattr(self, "_prefetch", None)
+            pre = pre[1] if (pre is not None and pre[0] == key) else None
+            host = self._plan.pack(self.state_dict(), reuse_pinned=on_gpu, prefetched=pre)   # staging buffer: uploaded right here
             self._blob = host.to(device)
             self._blob_key = key
+        self._prefetch = None
         return self._blob
+
+    def prefetch_packed_weights(self):
+        """Call right after an optimizer update: starts the asynchronous device-to-host copy of the parameters that the next
+        forward's re-pack needs (``Plan.pack_prefetch``), so that the host packs while the GPU works on whatever is
+        enqueued in between (the train step puts the discriminator's real-batch forward there) instead of draining the
+        stream at the next forward."""
+        p = next(self.parameters())
+        if not p.is_cuda:
+            return
+        if self._plan is None:
+            self._plan = Plan(self._cfg, storage=self.activation_storage, compact_workspace=True)
+        key = self._weights_key(p.device)
+        if self._blob is not None and self._blob_key == key:
+            return
+        self._prefetch = (key, self._plan.pack_prefetch(self.state_dict()))
 
     def load_packed_weights(self, blob: torch.Tensor):
         """Adopt an already packed device blob (e.g. received by RCCL broadcast)."""

@@ -351,11 +351,17 @@ class TrainStep:
                 torch.nn.utils.clip_grad_norm_(self.generator.parameters(), cfg["generator_grad_norm"])
             self.opt_g.step()
             self.sched_g.step()
+            if train_d and hasattr(self.generator, "prefetch_packed_weights"):
+                self.generator.prefetch_packed_weights()     # parameters -> host while the GPU runs the real batch below
         if train_d:
+            # (the real batch first: it does not depend on the generator, and the host re-packs the updated generator
+            # weights while the GPU is busy with it - same losses as `D(y_), D(y)` in the reference's order)
+            with self._autocast(discriminator=True):
+                p_real = self.discriminator(y)
             with torch.no_grad():
                 y_ = self.generator(*x)                  # second forward, with the updated generator
             with self._autocast(discriminator=True):
-                real, fake = discriminator_adversarial_loss(self.discriminator(y_.detach()), self.discriminator(y))
+                real, fake = discriminator_adversarial_loss(self.discriminator(y_.detach()), p_real)
             dis_loss = real.float() + fake.float()
             logd["real_loss"], logd["fake_loss"], logd["discriminator_loss"] = real.detach(), fake.detach(), dis_loss.detach()
             self.opt_d.zero_grad()
