@@ -417,6 +417,72 @@ def cpu_train_step_baseline(budget_s: float):
                       f"{len(times)} steps on {nt} threads", "ms_per_step": med * 1e3}
 
 
+def training_kernel_rooflines(dev, B, T, n=20):
+    """The hand-written kernels of the training step's backward side, timed live (HIP events on the launch stream, `n`
+    launches each) at the recipe batch's widest tensors - the top up block's 24-channel layers at the full sample rate -
+    and priced against their own rooflines: float32-operand MFMA (157.3 TFLOP/s dense) for the convolutions, 8 TB/s for the
+    FiLM / InstanceNorm node; the STFT loss is launch- and latency-bound (six resolutions, 0.5 M samples) and carries
+    its time only."""
+    import ctypes
+    from svcc23_fastsvc_amd import conv_grad as CG, training as TRN
+    lib = A.load_library()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3                     # us
+
+    C, K, d = 24, 3, 3
+    x = torch.randn((B, C, T), device=dev)
+    w = torch.randn((C, C, K), device=dev) / (C * K) ** 0.5
+    bias = torch.randn((C,), device=dev)
+    y, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(bias)
+    scratch = torch.empty(int(lib.fastsvc_conv1d_backward_weight_scratch_bytes(B, C, C, T, K)), dtype=torch.uint8, device=dev)
+    flops = 2.0 * B * C * C * K * T
+    byts = 2.0 * B * C * T * 4
+    out = {}
+    for name, fn in (
+            ("conv1d_forward", lambda: lib.fastsvc_conv1d_forward(vp(x), vp(w), vp(bias), vp(y), B, C, C, T, K, d, 0, st)),
+            ("conv1d_backward_data", lambda: lib.fastsvc_conv1d_forward(vp(x), vp(w), None, vp(y), B, C, C, T, K, d, 1, st)),
+            ("conv1d_backward_weight", lambda: lib.fastsvc_conv1d_backward_weight(vp(x), vp(y), vp(dw), vp(db), vp(scratch), B, C, C, T, K, d, st))):
+        us = timed(fn)
+        out[name] = {"shape": f"B{B} {C}->{C} T{T} k{K} d{d} float32", "us": us, "TFLOPs": flops / us / 1e6, "GBs": byts / us / 1e3,
+                     "bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": flops / us / 1e6 / PEAK_FP32_MFMA_TFLOPS,
+                     "hbm_frac": byts / us / 1e3 / PEAK_HBM_GBS}
+    sc, sh, o = torch.randn_like(x), torch.randn_like(x), torch.empty_like(x)
+    rb = torch.randn(B * C, device=dev)
+    mean, rstd = torch.empty_like(rb), torch.empty_like(rb)
+    dx, dsc, dsh, dbb = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(rb)
+    us = timed(lambda: lib.fastsvc_film_norm_forward(vp(x), vp(sc), vp(sh), vp(rb), vp(o), vp(mean), vp(rstd), B * C, T,
+                                                     ctypes.c_float(1e-5), ctypes.c_float(0.2), st))
+    fb = 4.0 * B * C * T * 4                                      # x, scale, shift read once; out written
+    out["film_norm_forward"] = {"shape": f"({B}, {C}, {T}) float32", "us": us, "GBs": fb / us / 1e3, "bound": "hbm",
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": fb / us / 1e3 / PEAK_HBM_GBS}
+    us = timed(lambda: lib.fastsvc_film_norm_backward(vp(y), vp(x), vp(sc), vp(sh), vp(rb), vp(mean), vp(rstd), vp(dx), vp(dsc), vp(dsh),
+                                                      vp(dbb), B * C, T, ctypes.c_float(0.2), st))
+    bb = 7.0 * B * C * T * 4                                      # dout, x, scale, shift read; dx, dscale, dshift written
+    out["film_norm_backward"] = {"shape": f"({B}, {C}, {T}) float32", "us": us, "GBs": bb / us / 1e3, "bound": "hbm",
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bb / us / 1e3 / PEAK_HBM_GBS}
+    crit = A.MultiResolutionSTFTLoss(**TRN.RECIPE["stft_loss_params"]).to(dev)
+    yt = torch.randn((B, 1, T), device=dev) * 0.2
+    xt = (yt * 0.9 + 0.05 * torch.randn_like(yt)).requires_grad_(True)
+
+    def loss_step():
+        a, b = crit(xt, yt)
+        torch.autograd.grad(a + b, xt)
+    out["stft_loss_forward_backward"] = {"shape": f"({B}, 1, {T}), 6 resolutions", "us": timed(loss_step),
+                                         "note": "14 launches (6 forward + fold, 6 backward + gather), through the autograd node"}
+    return out
+
+
 def run_cfg5(args, dist, world, rank, dev):
     """BASELINE config 5: the recipe's training step (train_fastsvc.py:157-240) per GPU on a batch of 32 crops of
     16000 samples (fastsvc.yaml:71-72), both sub-networks training, gradients averaged over the ranks (RCCL).
@@ -460,6 +526,10 @@ def run_cfg5(args, dist, world, rank, dev):
                                 "discriminator and losses are PyTorch-ROCm operators and count as time without roofline.")
     except Exception as e:
         roof = {"error": repr(e)}
+    try:
+        train_kernels = training_kernel_rooflines(dev, B, T)
+    except Exception as e:
+        train_kernels = {"error": repr(e)}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_train_step_baseline(args.cpu_seconds)
@@ -469,18 +539,21 @@ def run_cfg5(args, dist, world, rank, dev):
         "metric": "audio samples/sec (24 kHz) FastSVC training step", "value": world * B * T * args.steps / elapsed,
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"generator forward: {gen.plan.arithmetic}; " + ("generator backward: PyTorch-ROCm under bf16 autocast (f32 master weights, optimizer "
-                 "state, InstanceNorm statistics); discriminator, STFT and adversarial losses f32 (MIOpen's bf16 backward-data of the "
-                 "discriminator's first conv faults intermittently on this ROCm: training.py)" if bf16 else
-                 "backward / discriminator / losses: f32 PyTorch-ROCm"),
+        "dtype": f"generator forward: {gen.plan.arithmetic}; " + ("generator backward: float32 HIP convolution / FiLM-norm nodes (f32 master weights, optimizer state, "
+                 "InstanceNorm statistics), remaining ops under bf16 autocast; discriminator, STFT and adversarial losses f32 (MIOpen's bf16 "
+                 "backward-data of the discriminator's first conv faults intermittently on this ROCm: training.py)" if bf16 else
+                 "generator backward: float32 HIP convolution / FiLM-norm nodes (f32-operand MFMA); STFT loss f32 HIP; discriminator f32 PyTorch-ROCm"),
         "data": "synthetic",
         "config": {"workload": f"cfg5: full train step (generator fwd + bwd, MelGAN multi-scale discriminator, MR-STFT x6 + adversarial "
                                f"losses, RAdam), batch {B} x {T} samples per GPU, data-parallel x{world} with a flat-bucket gradient all-reduce"
                                + (", bfloat16 (BASELINE config 5's dtype)" if bf16 else ", float32 (--storage bfloat16: config 5's dtype)"),
                    "global_batch": world * B, "utterance_samples": T, "parallelism": f"data-parallel x{world}",
                    "generator_params": n_g, "discriminator_params": n_d,
-                   "hip_path": "generator forward only (two per step); hand-written backward kernels are not built"},
-        "roofline": roof, "cpu_baseline": cpu,
+                   "hip_path": "generator forward (two per step), the generator's backward convolutions (forward recompute, backward "
+                               "data, backward weight / bias), its FiLM + InstanceNorm + LeakyReLU nodes (forward and backward) and the "
+                               "multi-resolution STFT loss (forward and backward); discriminator, adversarial losses, RAdam and the "
+                               "remaining elementwise ops of the generator's graph are PyTorch-ROCm"},
+        "roofline": roof, "training_kernels": train_kernels, "cpu_baseline": cpu,
     }
 
 

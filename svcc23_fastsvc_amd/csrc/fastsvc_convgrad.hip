@@ -11,7 +11,7 @@
 // in float32 (master weights and gradients are float32).  Both run on the matrix cores with float32 operands
 // (v_mfma_f32_16x16x4_f32: exact float32 products, float32 accumulation - the arithmetic of an fmaf chain):
 //
-//  conv1d_fwd_kernel   one workgroup = 128 time steps x 16 ... 64 output channels of one utterance.  The input window
+//  conv1d_fwd_kernel   one workgroup = 128 time steps x 16 ... 48 output channels of one utterance.  The input window
 //      (16 channels at a time, halo included) and the matching weight slice sit in LDS; a wave owns 32 time steps and
 //      all the workgroup's channel tiles: per 4-deep reduction step one LDS read per operand row, 2 x (up to 4) MFMAs.
 //      `transposed` reads the weight as [in][out][k] with flipped taps: backward data without a transposed copy.
@@ -35,13 +35,15 @@ constexpr int CG_THREADS = 256;
 constexpr int CG_TT = 128;             // time steps per workgroup tile
 // weight LDS row pitch for NCT 16-channel tiles: = 17 (mod 32) - odd (staging writes run down a column), and the 2 x 16 lanes
 // of an operand read (rows r, r + 1) land on 32 different banks but one
-constexpr int cg_ws(int nct) { return nct <= 1 ? 17 : (nct <= 3 ? 49 : 81); }
+constexpr int cg_ws(int nct) { return nct <= 1 ? 17 : 49; }
 constexpr int CG_MAX_HALO = 27;        // (k / 2) * dilation
 constexpr int CG_XS = CG_TT + 2 * CG_MAX_HALO + 2;     // 184
 
 // CC = input channels per staged chunk: 16, or 24 for the 24-channel layers (no zero rows), or 8 for fewer than 16
+// (three waves per SIMD = three workgroups per CU: left alone the compiler hoists every LDS read of the unrolled reduction
+// and takes 192 ... 260 registers, i.e. one or two workgroups per CU with nothing to hide a workgroup's fetch behind)
 template <int K, int CC, int NCT>
-__global__ __launch_bounds__(CG_THREADS)
+__global__ __launch_bounds__(CG_THREADS, 3)
 void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                        float* __restrict__ y, int Cin, int Cout, int T, int dil, int transposed, int tpw) {
     constexpr int RC = CC * K;                          // reduction rows per chunk
@@ -107,9 +109,9 @@ void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
         __syncthreads();
         const bool last = chunk + 1 == nchunk;
         if (it + 1 < ntile * nchunk) fetch(last ? tile + 1 : tile, last ? 0 : (chunk + 1) * CC);
-        // straight-line: the channel-tile count is a template argument (a wave-uniform branch per tile kept every LDS
-        // read's latency in front of its two MFMAs)
-        #pragma unroll
+        // the channel-tile count is a template argument (a wave-uniform branch per tile kept every LDS read's latency in
+        // front of its two MFMAs); three steps in flight (fully unrolled the LDS reads of all steps are hoisted and spill)
+        #pragma unroll 3
         for (int r0 = 0; r0 < RC; r0 += 4) {
             const int r = r0 + kk;
             const int cil = r / K, k = r - cil * K;
@@ -302,13 +304,13 @@ void launch_fwd3(hipStream_t stream, const float* x, const float* w, const float
 template <int K, int CC>
 void launch_fwd2(hipStream_t stream, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int T,
                  int dil, int transposed) {
-    // output channels per workgroup: the 16-channel tiles split evenly over the fewest groups of at most four
-    const int tiles16 = (Cout + 15) / 16, groups = (tiles16 + 3) / 4, nct = (tiles16 + groups - 1) / groups;
+    // output channels per workgroup: the 16-channel tiles split evenly over the fewest groups of at most three (four
+    // tiles per wave do not fit 168 registers next to the prefetched chunk: three workgroups per CU matter more)
+    const int tiles16 = (Cout + 15) / 16, groups = (tiles16 + 2) / 3, nct = (tiles16 + groups - 1) / groups;
     switch (nct) {
         case 1: launch_fwd3<K, CC, 1>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed, groups); break;
         case 2: launch_fwd3<K, CC, 2>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed, groups); break;
-        case 3: launch_fwd3<K, CC, 3>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed, groups); break;
-        default: launch_fwd3<K, CC, 4>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed, groups); break;
+        default: launch_fwd3<K, CC, 3>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed, groups); break;
     }
 }
 
