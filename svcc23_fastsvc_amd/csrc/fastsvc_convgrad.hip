@@ -40,10 +40,10 @@ constexpr int CG_MAX_HALO = 27;        // (k / 2) * dilation
 constexpr int CG_XS = CG_TT + 2 * CG_MAX_HALO + 2;     // 184
 
 // CC = input channels per staged chunk: 16, or 24 for the 24-channel layers (no zero rows), or 8 for fewer than 16
-// (three waves per SIMD = three workgroups per CU: left alone the compiler hoists every LDS read of the unrolled reduction
+// (four waves per SIMD = four workgroups per CU, with buffer loads whose row offsets are scalars: left alone the compiler hoists every LDS read of the unrolled reduction
 // and takes 192 ... 260 registers, i.e. one or two workgroups per CU with nothing to hide a workgroup's fetch behind)
 template <int K, int CC, int NCT>
-__global__ __launch_bounds__(CG_THREADS, 3)
+__global__ __launch_bounds__(CG_THREADS, 4)
 void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                        float* __restrict__ y, int Cin, int Cout, int T, int dil, int transposed, int tpw) {
     constexpr int RC = CC * K;                          // reduction rows per chunk
@@ -67,17 +67,26 @@ void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
         #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the next (tile, chunk) travels global -> registers while the matrix cores work on the current one
+    // (buffer loads: one lane offset per 64-column group for ALL rows - the row is a scalar offset - and one 32-bit offset
+    // per weight value; lanes outside the utterance carry an offset beyond the descriptor's range and read 0)
     float xr[XR][3], wr[WQ];
+    constexpr int OOB = 0x7fffff00;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, Cin * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, Cin * Cout * K * 4, 0x00020000);
     auto fetch = [&](int tile, int ci0) {
         const int t0 = tile * CG_TT;
+        int voff[3];
+        #pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int col = lane + 64 * c, t = t0 - halo + col;
+            voff[c] = (col < xw && t >= 0 && t < T) ? t * 4 : OOB;
+        }
         #pragma unroll
         for (int rr = 0; rr < XR; ++rr) {
-            const int ci = ci0 + wave + 4 * rr;
+            const int ci = __builtin_amdgcn_readfirstlane(ci0 + wave + 4 * rr);
             #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int col = lane + 64 * c, t = t0 - halo + col;
-                xr[rr][c] = (col < xw && ci < Cin && t >= 0 && t < T) ? xb[(long)ci * T + t] : 0.f;
-            }
+            for (int c = 0; c < 3; ++c)
+                xr[rr][c] = ci < Cin ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, voff[c], ci * T * 4, 0)) : 0.f;
         }
         #pragma unroll
         for (int q = 0; q < WQ; ++q) {
@@ -85,10 +94,8 @@ void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
             const int co = idx / RC, j = idx - co * RC;
             const int cil = j / K, k = j - cil * K;
             const int ci = ci0 + cil, o = co0 + co;
-            float v = 0.f;
-            if (idx < CT * RC && ci < Cin && o < Cout)
-                v = transposed ? w[((long)ci * Cout + o) * K + (K - 1 - k)] : w[((long)o * Cin + ci) * K + k];
-            wr[q] = v;
+            const int off = transposed ? ((ci * Cout + o) * K + (K - 1 - k)) * 4 : ((o * Cin + ci) * K + k) * 4;
+            wr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wres, (idx < CT * RC && ci < Cin && o < Cout) ? off : OOB, 0, 0));
         }
     };
     fetch(tile0, 0);
@@ -317,8 +324,11 @@ void launch_fwd2(hipStream_t stream, const float* x, const float* w, const float
 template <int K>
 void launch_fwd(hipStream_t stream, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int T,
                 int dil, int transposed) {
-    if (Cin % 16 != 0 && Cin % 24 == 0) launch_fwd2<K, 24>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed);
-    else if (Cin <= 8) launch_fwd2<K, 8>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed);
+    // 24-channel inputs: one 24-row chunk (no zero rows) where the wave holds at most two channel tiles - with three the
+    // prefetched chunk no longer fits 128 registers and three 8-row chunks do better
+    const int tiles16 = (Cout + 15) / 16, groups = (tiles16 + 2) / 3, nct = (tiles16 + groups - 1) / groups;
+    if (Cin % 16 != 0 && Cin % 24 == 0 && nct <= 2) launch_fwd2<K, 24>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed);
+    else if (Cin <= 8 || Cin % 16 != 0) launch_fwd2<K, 8>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed);
     else launch_fwd2<K, 16>(stream, x, w, bias, y, B, Cin, Cout, T, dil, transposed);
 }
 
