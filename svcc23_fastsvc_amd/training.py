@@ -354,14 +354,26 @@ class TrainStep:
             if train_d and hasattr(self.generator, "prefetch_packed_weights"):
                 self.generator.prefetch_packed_weights()     # parameters -> host while the GPU runs the real batch below
         if train_d:
-            # (the real batch first: it does not depend on the generator, and the host re-packs the updated generator
-            # weights while the GPU is busy with it - same losses as `D(y_), D(y)` in the reference's order)
-            with self._autocast(discriminator=True):
-                p_real = self.discriminator(y)
-            with torch.no_grad():
-                y_ = self.generator(*x)                  # second forward, with the updated generator
-            with self._autocast(discriminator=True):
-                real, fake = discriminator_adversarial_loss(self.discriminator(y_.detach()), p_real)
+            if cfg.get("batch_discriminator_inputs", True):
+                # fake and real batch through the discriminator as ONE batch of 2B: it has no cross-sample operator (weight-norm
+                # convolutions, LeakyReLU, average pooling), so the outputs are those of two calls - and the step, which is bound
+                # by the host's launch path once the generator's kernels are hand-written, issues half as many discriminator
+                # launches (MIOpen's convolution_backward costs the host 0.2 ms a call)
+                with torch.no_grad():
+                    y_ = self.generator(*x)              # second forward, with the updated generator
+                nb = y.shape[0]
+                with self._autocast(discriminator=True):
+                    finals = _final(self.discriminator(torch.cat([y_.detach(), y], dim=0)))
+                    real, fake = discriminator_adversarial_loss([o[:nb] for o in finals], [o[nb:] for o in finals])
+            else:
+                # (the real batch first: it does not depend on the generator, and the host re-packs the updated generator
+                # weights while the GPU is busy with it - same losses as `D(y_), D(y)` in the reference's order)
+                with self._autocast(discriminator=True):
+                    p_real = self.discriminator(y)
+                with torch.no_grad():
+                    y_ = self.generator(*x)              # second forward, with the updated generator
+                with self._autocast(discriminator=True):
+                    real, fake = discriminator_adversarial_loss(self.discriminator(y_.detach()), p_real)
             dis_loss = real.float() + fake.float()
             logd["real_loss"], logd["fake_loss"], logd["discriminator_loss"] = real.detach(), fake.detach(), dis_loss.detach()
             self.opt_d.zero_grad()
