@@ -293,6 +293,17 @@ int fastsvc_film_norm_backward(const float* dout, const float* x, const float* s
                                const float* mean, const float* rstd, float* dx, float* dscale, float* dshift, float* dbias,
                                int32_t rows, int32_t T, float slope, void* stream);
 
+/* ---- weight normalisation w = g * v / ||v|| of up to 56 layers in ONE launch, forward and backward ----
+ * torch.nn.utils.weight_norm as the reference applies it to every conv (harana/models/fastsvc.py:354-362; norm over all
+ * dims but 0) and what autograd derives from it.  HOST arrays of n device pointers / sizes:
+ *   v[i] (rows[i], cols[i]), g[i] (rows[i]);  forward writes w[i] (rows, cols) and norm[i] (rows);
+ *   backward reads dw[i], norm[i] and writes dv[i] (rows, cols), dg[i] (rows).   n > 56: FASTSVC_E_UNSUPPORTED (call again for the rest). */
+int fastsvc_weight_norm_forward(int32_t n, const float* const* v, const float* const* g, float* const* w, float* const* norm,
+                                const int32_t* rows, const int32_t* cols, void* stream);
+int fastsvc_weight_norm_backward(int32_t n, const float* const* v, const float* const* g, const float* const* dw,
+                                 const float* const* norm, float* const* dv, float* const* dg, const int32_t* rows,
+                                 const int32_t* cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

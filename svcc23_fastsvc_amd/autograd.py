@@ -36,9 +36,20 @@ def folded_weights(named_params: Dict[str, torch.Tensor]) -> Dict[str, torch.Ten
     legacy weight-norm ``w = g * v / ||v||`` (norm over all dims but 0; ``fastsvc.py:342-362``);
     Conv2d (Cout, Cin, 1, 3) kernels are viewed as Conv1d (Cout, Cin, 3)."""
     out: Dict[str, torch.Tensor] = {}
+    bases = [k[: -len("_v")] for k in named_params if k.endswith(".weight_v")]
+    if bases and HIP_CONV_BACKWARD and all(named_params[b + "_v"].is_cuda for b in bases):
+        # all layers in ONE launch each way (conv_grad.weight_norm_fold) instead of ~8 small aten launches per layer and direction
+        from .conv_grad import weight_norm_fold
+        ws = weight_norm_fold([named_params[b + "_v"] for b in bases], [named_params[b + "_g"] for b in bases])
+        fused = dict(zip(bases, ws))
+    else:
+        fused = {}
     for k, v in named_params.items():
         if k.endswith(".weight_v"):
             base = k[: -len("_v")]
+            if base in fused:
+                out[base] = fused[base]
+                continue
             g = named_params[base + "_g"]
             norm = v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
             out[base] = v * (g / norm)

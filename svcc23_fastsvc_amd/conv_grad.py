@@ -144,3 +144,65 @@ def film_norm_lrelu(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, b
         raise ValueError(f"film_norm_lrelu: x {tuple(x.shape)}, scale {tuple(scale.shape)}, shift {tuple(shift.shape)}, "
                          f"bias {tuple(bias.shape)} do not fit")
     return _FilmNormFn.apply(x, scale, shift, bias, float(eps), float(slope))
+
+
+_WN_MAX = 56
+
+
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+class _WeightNormFn(torch.autograd.Function):
+    """w_i = g_i * v_i / ||v_i|| for a list of layers: ONE launch forward, ONE backward (per 56 layers)."""
+
+    @staticmethod
+    def forward(ctx, n: int, *vg):
+        vs = [t.detach().to(torch.float32).contiguous() for t in vg[:n]]
+        gs = [t.detach().to(torch.float32).contiguous() for t in vg[n:]]
+        lib = _lib()
+        ws = [torch.empty_like(v) for v in vs]
+        norms = [torch.empty(v.shape[0], dtype=torch.float32, device=v.device) for v in vs]
+        rows = [v.shape[0] for v in vs]
+        cols = [v.numel() // v.shape[0] for v in vs]
+        st = ctypes.c_void_p(torch.cuda.current_stream(vs[0].device).cuda_stream)
+        with _guard(vs[0]):
+            for a in range(0, n, _WN_MAX):
+                b = min(n, a + _WN_MAX)
+                rc = lib.fastsvc_weight_norm_forward(b - a, _ptr_array(vs[a:b]), _ptr_array(gs[a:b]), _ptr_array(ws[a:b]),
+                                                     _ptr_array(norms[a:b]), (ctypes.c_int32 * (b - a))(*rows[a:b]),
+                                                     (ctypes.c_int32 * (b - a))(*cols[a:b]), st)
+                if rc != 0:
+                    raise FastSVCError(f"fastsvc_weight_norm_forward failed ({rc})")
+        ctx.n, ctx.rows, ctx.cols = n, rows, cols
+        ctx.save_for_backward(*vs, *gs, *norms)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        n, rows, cols = ctx.n, ctx.rows, ctx.cols
+        saved = ctx.saved_tensors
+        vs, gs, norms = saved[:n], saved[n:2 * n], saved[2 * n:]
+        dws = [torch.zeros_like(v) if d is None else d.to(torch.float32).contiguous() for d, v in zip(dws, vs)]
+        lib = _lib()
+        dvs = [torch.empty_like(v) for v in vs]
+        dgs = [torch.empty_like(g) for g in gs]
+        st = ctypes.c_void_p(torch.cuda.current_stream(vs[0].device).cuda_stream)
+        with _guard(vs[0]):
+            for a in range(0, n, _WN_MAX):
+                b = min(n, a + _WN_MAX)
+                rc = lib.fastsvc_weight_norm_backward(b - a, _ptr_array(vs[a:b]), _ptr_array(gs[a:b]), _ptr_array(dws[a:b]),
+                                                      _ptr_array(norms[a:b]), _ptr_array(dvs[a:b]), _ptr_array(dgs[a:b]),
+                                                      (ctypes.c_int32 * (b - a))(*rows[a:b]), (ctypes.c_int32 * (b - a))(*cols[a:b]), st)
+                if rc != 0:
+                    raise FastSVCError(f"fastsvc_weight_norm_backward failed ({rc})")
+        return (None, *dvs, *dgs)
+
+
+def weight_norm_fold(vs, gs):
+    """``[g * v / ||v|| for v, g in zip(vs, gs)]`` (norm over all dims but 0: ``torch.nn.utils.weight_norm``, as the reference
+    applies it, ``fastsvc.py:354-362``), differentiable with respect to every v and g, one HIP launch each way."""
+    vs, gs = list(vs), list(gs)
+    if not vs or not all(t.is_cuda for t in vs + gs):
+        raise FastSVCError("weight_norm_fold (HIP) needs GPU tensors; there is no CPU fallback")
+    return list(_WeightNormFn.apply(len(vs), *vs, *gs))

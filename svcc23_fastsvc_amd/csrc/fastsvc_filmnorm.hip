@@ -108,3 +108,106 @@ int fastsvc_film_norm_backward(const float* dout, const float* x, const float* s
 }
 
 }  // extern "C"
+
+// ---- weight normalisation of ALL layers in one launch each way ----
+// The reference parametrises every conv as w = g * v / ||v|| (torch.nn.utils.weight_norm, norm over all dims but 0:
+// harana/models/fastsvc.py:354-362) and autograd differentiates it layer by layer: for the generator's 54 layers that is
+// ~430 launches forward and as many backward per step (norm, div, mul and their backward nodes), each a few hundred
+// values.  Here: one wave per output-channel row of any layer (a table of up to 56 layers travels in the kernel arguments),
+//   forward   n = ||v_r||,  w_r = (g_r / n) v_r                      (n saved)
+//   backward  dg_r = <dw_r, v_r> / n,   dv_r = (g_r / n) (dw_r - v_r <dw_r, v_r> / n^2)
+namespace {
+
+constexpr int WN_MAX_LAYERS = 56;       // 56 x 64 bytes of table: inside the 4 KB of kernel arguments
+
+struct WnLayer {
+    const float* v;      // (rows, cols)
+    const float* g;      // (rows)
+    float* w;            // forward: out (rows, cols); backward: dv
+    float* aux;          // forward: norm out (rows); backward: dg
+    const float* dw;     // backward only
+    const float* norm;   // backward only
+    int rows, cols, row0;
+    int pad;
+};
+
+struct WnTable {
+    WnLayer l[WN_MAX_LAYERS];
+    int n, total_rows;
+};
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256)
+void weight_norm_kernel(WnTable tab) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= tab.total_rows) return;
+    int li = 0;
+    while (li + 1 < tab.n && tab.l[li + 1].row0 <= row) ++li;          // wave-uniform
+    const WnLayer& L = tab.l[li];
+    const int r = row - L.row0, cols = L.cols;
+    const float* v = L.v + (long)r * cols;
+    if (!BACKWARD) {
+        float ss = 0.f;
+        for (int c = lane; c < cols; c += 64) ss = fmaf(v[c], v[c], ss);
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float n = sqrtf(ss), sc = L.g[r] / n;
+        float* w = L.w + (long)r * cols;
+        for (int c = lane; c < cols; c += 64) w[c] = sc * v[c];
+        if (lane == 0) L.aux[r] = n;
+    } else {
+        const float* dw = L.dw + (long)r * cols;
+        float dot = 0.f;
+        for (int c = lane; c < cols; c += 64) dot = fmaf(dw[c], v[c], dot);
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        const float n = L.norm[r], sc = L.g[r] / n, k = dot / (n * n);
+        float* dv = L.w + (long)r * cols;
+        for (int c = lane; c < cols; c += 64) dv[c] = sc * (dw[c] - v[c] * k);
+        if (lane == 0) L.aux[r] = dot / n;
+    }
+}
+
+int wn_fill(WnTable& tab, int32_t n, const float* const* v, const float* const* g, float* const* w, float* const* aux,
+            const float* const* dw, const float* const* norm, const int32_t* rows, const int32_t* cols) {
+    if (n < 1 || !v || !g || !w || !aux || !rows || !cols) return FASTSVC_E_INVALID;
+    if (n > WN_MAX_LAYERS) return FASTSVC_E_UNSUPPORTED;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!v[i] || !g[i] || !w[i] || !aux[i] || rows[i] < 1 || cols[i] < 1) return FASTSVC_E_INVALID;
+        WnLayer& L = tab.l[i];
+        L.v = v[i]; L.g = g[i]; L.w = w[i]; L.aux = aux[i];
+        L.dw = dw ? dw[i] : nullptr; L.norm = norm ? norm[i] : nullptr;
+        L.rows = rows[i]; L.cols = cols[i]; L.row0 = total; L.pad = 0;
+        total += rows[i];
+    }
+    tab.n = n; tab.total_rows = total;
+    return FASTSVC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fastsvc_weight_norm_forward(int32_t n, const float* const* v, const float* const* g, float* const* w, float* const* norm,
+                                const int32_t* rows, const int32_t* cols, void* stream_) {
+    WnTable tab;
+    const int rc = wn_fill(tab, n, v, g, w, norm, nullptr, nullptr, rows, cols);
+    if (rc != FASTSVC_OK) return rc;
+    hipLaunchKernelGGL(weight_norm_kernel<false>, dim3((tab.total_rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), tab);
+    return hipGetLastError() == hipSuccess ? FASTSVC_OK : FASTSVC_E_HIP;
+}
+
+int fastsvc_weight_norm_backward(int32_t n, const float* const* v, const float* const* g, const float* const* dw,
+                                 const float* const* norm, float* const* dv, float* const* dg, const int32_t* rows,
+                                 const int32_t* cols, void* stream_) {
+    if (!dw || !norm) return FASTSVC_E_INVALID;
+    WnTable tab;
+    const int rc = wn_fill(tab, n, v, g, dv, dg, dw, norm, rows, cols);
+    if (rc != FASTSVC_OK) return rc;
+    for (int i = 0; i < n; ++i) if (!dw[i] || !norm[i]) return FASTSVC_E_INVALID;
+    hipLaunchKernelGGL(weight_norm_kernel<true>, dim3((tab.total_rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), tab);
+    return hipGetLastError() == hipSuccess ? FASTSVC_OK : FASTSVC_E_HIP;
+}
+
+}  // extern "C"

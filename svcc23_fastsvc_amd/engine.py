@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "fastsvc_gather_padded",
     "fastsvc_stft_loss_scratch_bytes", "fastsvc_stft_loss_forward", "fastsvc_stft_loss_backward",
     "fastsvc_conv1d_forward", "fastsvc_conv1d_backward_weight", "fastsvc_conv1d_backward_weight_scratch_bytes",
-    "fastsvc_film_norm_forward", "fastsvc_film_norm_backward",
+    "fastsvc_film_norm_forward", "fastsvc_film_norm_backward", "fastsvc_weight_norm_forward", "fastsvc_weight_norm_backward",
 )
 
 
@@ -123,6 +123,10 @@ def load_library():
     lib.fastsvc_film_norm_forward.restype = ctypes.c_int
     lib.fastsvc_film_norm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, ctypes.c_float, vp]
     lib.fastsvc_film_norm_backward.restype = ctypes.c_int
+    lib.fastsvc_weight_norm_forward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.fastsvc_weight_norm_forward.restype = ctypes.c_int
+    lib.fastsvc_weight_norm_backward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.fastsvc_weight_norm_backward.restype = ctypes.c_int
     lib.fastsvc_split_half.argtypes = [vp, i64, vp, vp, vp]
     lib.fastsvc_split_half.restype = None
     lib.fastsvc_stream_prepare.argtypes = [vp]

@@ -95,3 +95,28 @@ def test_film_norm_lrelu_node_vs_float64(dev, shape):
         err = (got.double().cpu() - want).abs().max().item()
         # (the row with mean 300: u itself carries float32 rounding of 3e-5, divided by a spread of ~1)
         assert err <= 1e-4 * max(want.abs().max().item(), 1.0), (name, err, want.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_weight_norm_fold_all_layers_in_one_launch_vs_torch(dev):
+    """w = g v / ||v|| (torch.nn.utils.weight_norm, fastsvc.py:354-362) for 60 layers of mixed shapes (more than one table of
+    56), values and both gradients against float64 autograd."""
+    g = torch.Generator().manual_seed(9)
+    shapes = [(24, 1, 3), (24, 24, 3), (48, 24, 1), (192, 192, 1, 3), (1, 24, 3), (96, 48, 3), (384, 192, 3), (5, 7, 1)] * 8
+    shapes = shapes[:60]
+    vs = [torch.randn(s, generator=g) for s in shapes]
+    gs = [torch.rand((s[0],) + (1,) * (len(s) - 1), generator=g) + 0.5 for s in shapes]
+    grads = [torch.randn(s, generator=g) for s in shapes]
+    v64 = [v.double().requires_grad_(True) for v in vs]
+    g64 = [t.double().requires_grad_(True) for t in gs]
+    w64 = [v * (gg / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))) for v, gg in zip(v64, g64)]
+    torch.autograd.backward(w64, [d.double() for d in grads])
+    vd = [v.to(dev).requires_grad_(True) for v in vs]
+    gd = [t.to(dev).requires_grad_(True) for t in gs]
+    wd = CG.weight_norm_fold(vd, gd)
+    torch.autograd.backward(wd, [d.to(dev) for d in grads])
+    for i in range(len(shapes)):
+        for name, got, want in (("w", wd[i].detach(), w64[i].detach()), ("dv", vd[i].grad, v64[i].grad), ("dg", gd[i].grad, g64[i].grad)):
+            assert got.shape == want.shape
+            err = (got.double().cpu() - want).abs().max().item()
+            assert err <= 2e-6 * max(want.abs().max().item(), 1e-3), (i, name, err)
