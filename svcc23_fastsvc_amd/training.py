@@ -339,8 +339,21 @@ class TrainStep:
             gen_loss = (sc + mag) * cfg.get("lambda_aux", 1.0)
             logd["spectral_convergence_loss"], logd["log_stft_magnitude_loss"] = sc.detach(), mag.detach()
             if train_d:
-                with self._autocast(discriminator=True):
-                    adv = generator_adversarial_loss(self.discriminator(y_))
+                # the generator's adversarial term needs d loss / d y_ only: the reference's backward also fills the
+                # DISCRIMINATOR's parameter gradients here and zeroes them before they are used (train_fastsvc.py:183,
+                # 224: optimizer["discriminator"].zero_grad() precedes dis_loss.backward()) - a third of the discriminator's
+                # backward work (its weight gradients) and as many launches; frozen for this one call, same updates
+                # (HIP-graph replay of the discriminator's own update, torch.cuda.make_graphed_callables, was measured
+                # too: 53.6 ms against 52.0 ms launch by launch - not kept)
+                d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+                for p in d_params:
+                    p.requires_grad_(False)
+                try:
+                    with self._autocast(discriminator=True):
+                        adv = generator_adversarial_loss(self.discriminator(y_))
+                finally:
+                    for p in d_params:
+                        p.requires_grad_(True)
                 logd["adversarial_loss"] = adv.detach()
                 gen_loss = gen_loss + cfg["lambda_adv"] * adv.float()
             logd["generator_loss"] = gen_loss.detach()
