@@ -619,10 +619,122 @@ __device__ __forceinline__ void hx_epilogue_poly8(const ConvParams& p, const Epi
         }
     }
 }
+// Polyphase + FiLM-affine epilogue through the wave's own LDS patch (bfloat16 storage, round 4).  In hx_epilogue_poly8 a lane
+// owns 4 S consecutive output samples of ONE channel row: its 16-byte pieces sit 8 S bytes apart (40 for S = 5: every
+// other one misaligned, plus an 8-byte tail), 16 rows per instruction - the stretched FiLM layers ran at 2.2-3.1 TB/s where the
+// direct ones reach 4-4.6.  Here the finished (LeakyReLU'd, bfloat16) tile goes to LDS in that layout and comes back
+// row-major: four lanes = 64 contiguous bytes of a row, sixteen rows per instruction, for the scale / shift loads, the
+// affine, its InstanceNorm sums and both stores.  LDS executes a wave's accesses in order: no barrier, a wave fence.
+template <int MW, int NW, int S> constexpr int hx_poly_patch_bytes() { return MW * 16 * (NW * 16 * S * 2 + 16); }
+template <int MW, int NW, int EPI, int S, class KT>
+__device__ __forceinline__ void hx_epilogue_poly_staged(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[3][NW][MW],
+                                                        float (&s1)[MW], float (&s2)[MW], int mg, int tcol0, bool active, int lane,
+                                                        const KT& K, unsigned char* Pw) {
+    if (!active) return;
+    constexpr int NC = NW * 16 * S;                         // output samples per row of this wave's tile
+    constexpr int PB = NC * 2 + 16;                         // patch row pitch, bytes
+    constexpr int NCH = (NC + 31) / 32;                     // 64-byte chunks per row
+    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
+    const int T_out = p.ldy;
+    const int shift_soff = p.COUT * T_out * 2;             // bytes
+    // the row-major pass's operands: requested FIRST where they fit the registers (MW * NCH <= 10 pieces of scale and shift
+    // each: their round trip then runs under the conversion and the LDS writes - one workgroup per CU, four consumer waves,
+    // nothing else hides it: up.3 691 -> 626 us), else row tile by row tile inside the pass (three channel tiles at once
+    // spilled: up.2 264 -> 350 us)
+    constexpr bool HOIST = MW * NCH <= 10;
+    const int rsub = lane >> 2, piece = lane & 3;
+    const int ncv = max(0, min(NW * 16, p.T - tcol0)) * S;  // valid output samples of a row of this tile
+    f32x8 l1[HOIST ? MW : 1][NCH], l2[HOIST ? MW : 1][NCH];
+    int off[HOIST ? MW : 1][NCH], nv[HOIST ? MW : 1][NCH];
+    auto request = [&](int m, int slot) {
+        const int cot = (mg * MW + m) * 16 + rsub;
+        const bool cok = cot < p.COUT;
+        const int rowb = ((cok ? cot : 0) * T_out + tcol0 * S) * 2;
+        #pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 32 + piece * 8;
+            nv[slot][c] = (cok && col < NC) ? max(0, min(8, ncv - col)) : 0;
+            off[slot][c] = nv[slot][c] > 0 ? rowb + col * 2 : OOB_OFF;
+            if (EPI == EPI_AFF) {
+                l1[slot][c] = act_load8(R.ss, off[slot][c], 0);
+                l2[slot][c] = act_load8(R.ss, off[slot][c], shift_soff);
+            }
+        }
+    };
+    if constexpr (HOIST) {
+        #pragma unroll
+        for (int m = 0; m < MW; ++m) request(m, m);
+    }
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const float bias = K.bias(p, 0, m, (mg * MW + m) * 16 + (lane & 15));
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const f32x4 zz = acc[1][n][m] + bias;
+            const f32x4 zf = zz + acc[0][n][m];
+            const f32x4 zl = zz + acc[2][n][m];
+            auto phase_value = [&](int k) -> float {
+                const int jj = k / S, ph = k % S;
+                const float a = ph == 0 ? zf[jj] : ph == S - 1 ? zl[jj] : zz[jj];
+                return fmaxf(a, a * slope);
+            };
+            unsigned char* dst = Pw + (m * 16 + (lane & 15)) * PB + ((n * 16 + (lane >> 4) * 4) * S) * 2;
+            #pragma unroll
+            for (int q = 0; q < S; ++q) {                   // 4 S samples = S pieces of 8 bytes
+                u32x2v w;
+                w.x = f32_to_bf16_bits(phase_value(4 * q)) | (f32_to_bf16_bits(phase_value(4 * q + 1)) << 16);
+                w.y = f32_to_bf16_bits(phase_value(4 * q + 2)) | (f32_to_bf16_bits(phase_value(4 * q + 3)) << 16);
+                *reinterpret_cast<u32x2v*>(dst + q * 8) = w;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const unsigned char* src = Pw + (m * 16 + rsub) * PB + piece * 16;
+        float a1 = 0.f, a2 = 0.f;
+        const int sl = HOIST ? m : 0;
+        if constexpr (!HOIST) request(m, 0);
+        #pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 32 + piece * 8;
+            f32x8 v = bf8_unpack(*reinterpret_cast<const u32x4*>(src + (col < NC ? c * 64 : 0)));
+            const int nvs = min(8, (nv[sl][c] + 3) & ~3);    // (ragged rows: the straddling group of 4 is stored whole)
+            act_store8(R.y, off[sl][c], v, nvs);             // dropped when y is absent
+            if (EPI == EPI_AFF) {
+                f32x8 u;
+                u.lo = l1[sl][c].lo * v.lo + l2[sl][c].lo; u.hi = l1[sl][c].hi * v.hi + l2[sl][c].hi;
+                u = keep8_exact(u, nv[sl][c]);
+                act_store8(R.y2, off[sl][c], u, nvs);
+                a1 += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
+                a2 += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
+                      ((u.hi.x * u.hi.x + u.hi.y * u.hi.y) + (u.hi.z * u.hi.z + u.hi.w * u.hi.w));
+            }
+        }
+        if (EPI == EPI_AFF) {
+            // the caller folds s1 / s2 over the lane >> 4 groups and takes channel lane & 15 from lanes 0..15: hand the row
+            // sums over in that layout (row r lives in lanes 4 r .. 4 r + 3 here)
+            a1 += __shfl_xor(a1, 1); a2 += __shfl_xor(a2, 1);
+            a1 += __shfl_xor(a1, 2); a2 += __shfl_xor(a2, 2);
+            const float r1 = __shfl(a1, 4 * (lane & 15)), r2 = __shfl(a2, 4 * (lane & 15));
+            if (lane < 16) { s1[m] += r1; s2[m] += r2; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// instances that take the staged polyphase epilogue (the patch of a wave: MW * 16 rows of 4 S NW * 8 + 16 bytes)
+template <int MW, int NW, int MODE, int EPI, int S>
+constexpr bool hx_poly_staged() { return MODE == MODE_POLY && EPI == EPI_AFF && hx_poly_patch_bytes<MW, NW, S>() <= 16 * 1024; }
 // the pair epilogue needs an even number of time tiles per wave; its operands are staged while they fit
 template <int MW, int NW, int MODE> constexpr bool hx_pairs_epi() { return MODE == MODE_DIRECT && NW % 2 == 0; }
 #else
 template <int MW, int NW, int MODE> constexpr bool hx_pairs_epi() { return false; }
+template <int MW, int NW, int MODE, int EPI, int S> constexpr bool hx_poly_staged() { return false; }
+template <int MW, int NW, int S> constexpr int hx_poly_patch_bytes() { return 0; }
 #endif
 
 // variants that stage their epilogue operands (scale, shift, residual) in LDS ahead of the epilogue with
@@ -1328,7 +1440,11 @@ void conv_hx_kernel(const ConvParams p0) {
                     if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))); }
                     if constexpr (POLY) {
 #ifdef FASTSVC_ACT_BF16
-                        hx_epilogue_poly8<MW, NW, EPI, S, TAILK>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
+                        if constexpr (hx_poly_staged<MW, NW, MODE, EPI, S>())
+                            hx_epilogue_poly_staged<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K,
+                                                                    tiles + 2 * bufsz + cw * hx_poly_patch_bytes<MW, NW, S>());
+                        else
+                            hx_epilogue_poly8<MW, NW, EPI, S, TAILK>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
 #else
                         ws_epilogue_poly<MW, NW, EPI, S, TAILK ? 2 : 0>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
 #endif
@@ -1460,7 +1576,7 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
         return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 1>(grid, smem, stream, p);
     } else if constexpr (MODE == MODE_POLY) {
 #define FASTSVC_HXP(sv) \
-        if (p.s == sv) return aff ? hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_AFF, sv>(grid, smem, stream, p) \
+        if (p.s == sv) return aff ? hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_AFF, sv>(grid, smem + (hx_poly_staged<MW, NW, MODE_POLY, EPI_AFF, sv>() ? 4 * hx_poly_patch_bytes<MW, NW, sv>() : 0), stream, p) \
                                   : hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_PLAIN, sv>(grid, smem, stream, p);
         FASTSVC_HXP(2) FASTSVC_HXP(4) FASTSVC_HXP(5)
 #undef FASTSVC_HXP
