@@ -728,7 +728,7 @@ __device__ __forceinline__ void hx_epilogue_poly_staged(const ConvParams& p, con
 }
 // instances that take the staged polyphase epilogue (the patch of a wave: MW * 16 rows of 4 S NW * 8 + 16 bytes)
 template <int MW, int NW, int MODE, int EPI, int S>
-constexpr bool hx_poly_staged() { return MODE == MODE_POLY && EPI == EPI_AFF && hx_poly_patch_bytes<MW, NW, S>() <= 16 * 1024; }
+constexpr bool hx_poly_staged() { return MODE == MODE_POLY && (EPI == EPI_AFF || EPI == EPI_PLAIN) && hx_poly_patch_bytes<MW, NW, S>() <= 16 * 1024; }
 // the pair epilogue needs an even number of time tiles per wave; its operands are staged while they fit
 template <int MW, int NW, int MODE> constexpr bool hx_pairs_epi() { return MODE == MODE_DIRECT && NW % 2 == 0; }
 #else
@@ -1577,7 +1577,7 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
     } else if constexpr (MODE == MODE_POLY) {
 #define FASTSVC_HXP(sv) \
         if (p.s == sv) return aff ? hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_AFF, sv>(grid, smem + (hx_poly_staged<MW, NW, MODE_POLY, EPI_AFF, sv>() ? 4 * hx_poly_patch_bytes<MW, NW, sv>() : 0), stream, p) \
-                                  : hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_PLAIN, sv>(grid, smem, stream, p);
+                                  : hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_PLAIN, sv>(grid, smem + (hx_poly_staged<MW, NW, MODE_POLY, EPI_PLAIN, sv>() ? 4 * hx_poly_patch_bytes<MW, NW, sv>() : 0), stream, p);
         FASTSVC_HXP(2) FASTSVC_HXP(4) FASTSVC_HXP(5)
 #undef FASTSVC_HXP
         return hipErrorInvalidValue;
