@@ -128,10 +128,32 @@ def test_hip_loss_recipe_batch_weighted_gradient_and_reproducibility(dev):
         x = x0.clone().requires_grad_(True)
         sc, mag = crit(x, y)
         (2.0 * sc + 0.5 * mag).backward()
-        outs.append((float(sc), float(mag), x.grad.clone()))
+        outs.append((float(sc.detach()), float(mag.detach()), x.grad.clone()))
     (sc, mag, gx), (rsc, rmag, rgx), (sc2, mag2, gx2) = outs
     assert abs(sc - rsc) <= 1e-5 * rsc and abs(mag - rmag) <= 1e-5 * rmag, (sc, rsc, mag, rmag)
     assert gx.shape == x0.shape
     err = (gx - rgx).abs()
     assert float(err.max()) <= 5e-3 * float(rgx.abs().max()) and float(err.mean()) <= 2e-4 * float(rgx.abs().max())
     assert sc == sc2 and mag == mag2 and torch.equal(gx, gx2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 1100, [2048, 8], [512, 3], [2048, 8]), (5, 777, [64, 16], [16, 5], [48, 16]),
+                                  (3, 130, [256], [256], [200]), (2, 4097, [1024, 128], [1, 127], [1024, 100])], ids=str)
+def test_hip_loss_edge_geometries_vs_oracle(dev, case):
+    """Shortest admissible signals (fft_size / 2 < T by a few samples), a hop of one sample, hops that do not divide the
+    frame, an odd number of frames (the second frame of the last pair is absent), one frame per utterance, windows shorter
+    than the frame: losses and both gradients against the float64 oracle."""
+    B, T, ffts, hops, wins = case
+    rng = np.random.default_rng(B * 100 + T)
+    y = (rng.standard_normal((B, T)) * 0.3).astype(np.float32)
+    x = (y * 0.7 + rng.standard_normal((B, T)) * 0.1).astype(np.float32)
+    crit = A.MultiResolutionSTFTLoss(fft_sizes=ffts, hop_sizes=hops, win_lengths=wins).to(dev)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    sc, mag = crit(xt, torch.from_numpy(y).to(dev))
+    (1.5 * sc + 0.25 * mag).backward()
+    osc, omag = O.mr_stft_loss(x, y, ffts, hops, wins)
+    og = O.mr_stft_loss_grad(x, y, ffts, hops, wins, 1.5, 0.25)
+    assert abs(float(sc.detach()) - osc) <= 2e-5 * osc and abs(float(mag.detach()) - omag) <= 2e-5 * omag, (float(sc.detach()), osc, float(mag.detach()), omag)
+    err = np.abs(xt.grad.cpu().numpy() - og)
+    assert err.max() <= 5e-3 * np.abs(og).max() and err.mean() <= 2e-4 * np.abs(og).max(), (err.max(), err.mean(), np.abs(og).max())
