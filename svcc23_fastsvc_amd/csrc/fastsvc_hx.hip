@@ -726,6 +726,65 @@ __device__ __forceinline__ void hx_epilogue_poly_staged(const ConvParams& p, con
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// The decimating pair's two outputs (c1 and the 1x1 residual r) the same way: ws_epilogue_dec2 stores 8-byte pieces, sixteen
+// rows x four pieces per instruction and tensor - the pairs ran at 8-10 % matrix-pipe occupancy, 5 k of 6 k cycles per unit outside
+// the matrix work.  Both finished tiles go to the wave's LDS patch and leave row-major: NW * 32 contiguous bytes per row.
+template <int MW, int NW> constexpr int hx_dec2_patch_bytes() { return 2 * MW * 16 * (NW * 32 + 16); }
+template <int MW, int NW, class KT>
+__device__ __forceinline__ void hx_epilogue_dec2_staged(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[2][NW][MW], int sig, int mg,
+                                                        int tcol0, bool active, int lane, const KT& K, unsigned char* Pw) {
+    if (!active) return;
+    constexpr int PB = NW * 32 + 16;                        // patch row pitch, bytes
+    constexpr int TB = MW * 16 * PB;                        // one tensor's tile
+    constexpr int NP = NW * 2;                              // 16-byte pieces per row
+    constexpr int ITEMS = MW * 16 * NP;
+    #pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int cot = (mg * MW + m) * 16 + (lane & 15);
+        const float bias = K.bias(p, sig, m, cot), bias2 = K.bias2(p, sig, m, cot);
+        const float iv = K.inv(m), iv2 = K.inv2(m);
+        #pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            unsigned char* dst = Pw + (m * 16 + (lane & 15)) * PB + (n * 16 + (lane >> 4) * 4) * 2;
+            const f32x4 a = KT::finish(acc[0][n][m], iv, bias), b = KT::finish(acc[1][n][m], iv2, bias2);
+            u32x2v wa, wb;
+            wa.x = f32_to_bf16_bits(a.x) | (f32_to_bf16_bits(a.y) << 16); wa.y = f32_to_bf16_bits(a.z) | (f32_to_bf16_bits(a.w) << 16);
+            wb.x = f32_to_bf16_bits(b.x) | (f32_to_bf16_bits(b.y) << 16); wb.y = f32_to_bf16_bits(b.z) | (f32_to_bf16_bits(b.w) << 16);
+            *reinterpret_cast<u32x2v*>(dst) = wa;
+            *reinterpret_cast<u32x2v*>(dst + TB) = wb;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    #pragma unroll
+    for (int k = 0; k < (ITEMS + 63) / 64; ++k) {
+        const int idx = lane + 64 * k;
+        const int row = idx / NP, piece = idx - row * NP;
+        const int cot = mg * MW * 16 + row;
+        const int col = tcol0 + piece * 8;
+        const int nv = (idx < ITEMS && cot < p.COUT) ? max(0, min(8, p.T - col)) : 0;
+        const int nvs = min(8, (nv + 3) & ~3);              // (ragged rows: the straddling group of 4 is stored whole)
+        const int off = nv > 0 ? (cot * p.ldy + col) * 2 : OOB_OFF;
+        const unsigned char* src = Pw + (idx < ITEMS ? row * PB + piece * 16 : 0);
+        const u32x4 wa = *reinterpret_cast<const u32x4*>(src), wb = *reinterpret_cast<const u32x4*>(src + TB);
+        if (__builtin_amdgcn_ballot_w64(nvs == 4) == 0) {   // wave-uniform: no half piece (nearly always)
+            __builtin_amdgcn_raw_buffer_store_b128(wa, R.y, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(wb, R.y2, off, 0, 0);
+        } else {
+            u32x2v a0, a1, b0, b1;
+            a0.x = wa.x; a0.y = wa.y; a1.x = wa.z; a1.y = wa.w; b0.x = wb.x; b0.y = wb.y; b1.x = wb.z; b1.y = wb.w;
+            __builtin_amdgcn_raw_buffer_store_b64(a0, R.y, nvs >= 4 ? off : OOB_OFF, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(a1, R.y, nvs >= 8 ? off + 8 : OOB_OFF, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(b0, R.y2, nvs >= 4 ? off : OOB_OFF, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(b1, R.y2, nvs >= 8 ? off + 8 : OOB_OFF, 0, 0);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int MW, int NW, int MODE> constexpr bool hx_dec2_staged() { return MODE == MODE_DEC2 && hx_dec2_patch_bytes<MW, NW>() <= 16 * 1024; }
 // instances that take the staged polyphase epilogue (the patch of a wave: MW * 16 rows of 4 S NW * 8 + 16 bytes)
 template <int MW, int NW, int MODE, int EPI, int S>
 constexpr bool hx_poly_staged() { return MODE == MODE_POLY && (EPI == EPI_AFF || EPI == EPI_PLAIN) && hx_poly_patch_bytes<MW, NW, S>() <= 16 * 1024; }
@@ -735,6 +794,8 @@ template <int MW, int NW, int MODE> constexpr bool hx_pairs_epi() { return MODE 
 template <int MW, int NW, int MODE> constexpr bool hx_pairs_epi() { return false; }
 template <int MW, int NW, int MODE, int EPI, int S> constexpr bool hx_poly_staged() { return false; }
 template <int MW, int NW, int S> constexpr int hx_poly_patch_bytes() { return 0; }
+template <int MW, int NW, int MODE> constexpr bool hx_dec2_staged() { return false; }
+template <int MW, int NW> constexpr int hx_dec2_patch_bytes() { return 0; }
 #endif
 
 // variants that stage their epilogue operands (scale, shift, residual) in LDS ahead of the epilogue with
@@ -1450,7 +1511,15 @@ void conv_hx_kernel(const ConvParams p0) {
 #endif
                     }
                     else if constexpr (DEC2)
+                    {
+#ifdef FASTSVC_ACT_BF16
+                        if constexpr (hx_dec2_staged<MW, NW, MODE>())
+                            hx_epilogue_dec2_staged<MW, NW>(p, R, acc2, sig, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K,
+                                                            tiles + 2 * bufsz + cw * hx_dec2_patch_bytes<MW, NW>());
+                        else
+#endif
                         ws_epilogue_dec2<MW, NW>(p, R, acc2, sig, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
+                    }
                     else {
 #ifdef FASTSVC_ACT_BF16
                         if constexpr (PAIRS) {
@@ -1572,8 +1641,9 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
         return hipErrorInvalidValue;
     } else if constexpr (MODE == MODE_DEC2) {
         // S = 2: compact input (p.s == 1, rows a multiple of 4 long, 16-byte aligned) - vector window loads
-        if (p.s == 1 && (p.ldx & 3) == 0) return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 2>(grid, smem, stream, p);
-        return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 1>(grid, smem, stream, p);
+        const size_t patch = hx_dec2_staged<MW, NW, MODE_DEC2>() ? 4 * (size_t)hx_dec2_patch_bytes<MW, NW>() : 0;   // (bfloat16 storage)
+        if (p.s == 1 && (p.ldx & 3) == 0) return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 2>(grid, smem + patch, stream, p);
+        return hx_launch_kind<MW, NW, WM, WN, MODE_DEC2, EPI_PLAIN, 1>(grid, smem + patch, stream, p);
     } else if constexpr (MODE == MODE_POLY) {
 #define FASTSVC_HXP(sv) \
         if (p.s == sv) return aff ? hx_launch_kind<MW, NW, WM, WN, MODE_POLY, EPI_AFF, sv>(grid, smem + (hx_poly_staged<MW, NW, MODE_POLY, EPI_AFF, sv>() ? 4 * hx_poly_patch_bytes<MW, NW, sv>() : 0), stream, p) \
