@@ -53,13 +53,25 @@ void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     __shared__ float xl[CC][CG_XS];
     __shared__ float wl[RC][cg_ws(NCT)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int co0 = blockIdx.y * CT, b = blockIdx.z;
+    // Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2) in launch order: remap so that one XCD
+    // gets a CONTIGUOUS run of (time tile, channel group) items of an utterance - the channel groups of a tile re-read the same
+    // input window and neighbouring tiles share their halos, which then stay in that XCD's L2
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nxy = gridDim.x * gridDim.y, d = blockIdx.x + gridDim.x * blockIdx.y, per = nxy >> 3;
+        if (d < (per << 3)) {
+            const int w = (d & 7) * per + (d >> 3);
+            bx = w / (int)gridDim.y;
+            by = w - bx * (int)gridDim.y;
+        }
+    }
+    const int co0 = by * CT, b = blockIdx.z;
     const int halo = (K / 2) * dil, xw = CG_TT + 2 * halo;
     const float* xb = x + (long)b * Cin * T;
     float* yb = y + (long)b * Cout * T;
     const int n = lane & 15, kk = lane >> 4;
     const int tiles = (T + CG_TT - 1) / CG_TT;
-    const int tile0 = blockIdx.x * tpw, ntile = min(tpw, tiles - tile0);
+    const int tile0 = bx * tpw, ntile = min(tpw, tiles - tile0);
     const int nchunk = (Cin + CC - 1) / CC;
     f32x4 acc[NCT][2];
     #pragma unroll
