@@ -828,10 +828,18 @@ __device__ __forceinline__ void hx_last_reduce(const ConvParams& p, const f32x4 
         f32x4 s = acc[n][0] * kw[0];
         #pragma unroll
         for (int m = 1; m < MW; ++m) s += acc[n][m] * kw[m];
+        // sum over the 16 lanes of a row (= the 16 channels of a tile) by DPP moves - quad swaps, then the mirrored half row
+        // and the mirrored row: every pairing joins disjoint partial sums, all 16 lanes end with the total.  (__shfl_xor is
+        // ds_bpermute here: four DEPENDENT LDS-crossbar round trips per component, the fused conv_last cost more than the
+        // 737 MB store it saves)
         #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            s.x += __shfl_xor(s.x, d); s.y += __shfl_xor(s.y, d);
-            s.z += __shfl_xor(s.z, d); s.w += __shfl_xor(s.w, d);
+        for (int e = 0; e < 4; ++e) {
+            float v = s[e];
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+            s[e] = v;
         }
         const int t = PAIRS ? tcol0 + (n >> 1) * 32 + (lane >> 4) * 8 + (n & 1) * 4 : tcol0 + n * 16 + (lane >> 4) * 4;
         buf_store4(yr, ((lane & 15) == 0 && t < p.T) ? t * 4 : OOB_OFF, s + bias);
