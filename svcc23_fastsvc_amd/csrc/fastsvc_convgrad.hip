@@ -353,6 +353,8 @@ int fastsvc_conv1d_forward(const float* x, const float* w, const float* bias, fl
     if (!x || !w || !y) return FASTSVC_E_INVALID;
     if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || dilation < 1 || K < 1 || (K & 1) == 0) return FASTSVC_E_INVALID;
     if (!cg_args_ok(B, Cin, Cout, T, K, dilation) || (K / 2) * dilation > CG_MAX_HALO || B > 65535) return FASTSVC_E_UNSUPPORTED;
+    // (one utterance's input is addressed through a buffer descriptor with 32-bit byte offsets)
+    if ((long)Cin * T * 4 >= 0x7fffff00L || (long)Cin * Cout * K * 4 >= 0x7fffff00L) return FASTSVC_E_UNSUPPORTED;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (K == 1) launch_fwd<1>(stream, x, w, bias, y, B, Cin, Cout, T, dilation, transposed);
     else launch_fwd<3>(stream, x, w, bias, y, B, Cin, Cout, T, dilation, transposed);
