@@ -56,14 +56,14 @@ void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     // Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2) in launch order: remap so that one XCD
     // gets a CONTIGUOUS run of (time tile, channel group) items of an utterance - the channel groups of a tile re-read the same
     // input window and neighbouring tiles share their halos, which then stay in that XCD's L2
-    int bx = blockIdx.x, by = blockIdx.y;
+    // (items are numbered channel group fastest; the launch-order index d of the first 8 * (n / 8) workgroups is permuted onto
+    // them, the remaining n % 8 keep theirs - one bijection over all n items)
+    int bx, by;
     {
         const int nxy = gridDim.x * gridDim.y, d = blockIdx.x + gridDim.x * blockIdx.y, per = nxy >> 3;
-        if (d < (per << 3)) {
-            const int w = (d & 7) * per + (d >> 3);
-            bx = w / (int)gridDim.y;
-            by = w - bx * (int)gridDim.y;
-        }
+        const int w = d < (per << 3) ? (d & 7) * per + (d >> 3) : d;
+        bx = w / (int)gridDim.y;
+        by = w - bx * (int)gridDim.y;
     }
     const int co0 = by * CT, b = blockIdx.z;
     const int halo = (K / 2) * dil, xw = CG_TT + 2 * halo;

@@ -37,6 +37,8 @@ CASES = [
     (2, 24, 48, 515, 3, 1), (2, 48, 96, 300, 1, 1), (2, 96, 96, 260, 3, 4), (3, 192, 192, 131, 3, 27),
     (2, 192, 384, 75, 3, 1), (2, 144, 192, 50, 3, 1), (2, 24, 1, 1203, 3, 1), (1, 48, 48, 129, 3, 9),
     (2, 96, 48, 400, 3, 3), (1, 7, 5, 33, 3, 2), (5, 20, 70, 128, 1, 1),
+    # (time tiles x channel groups not a multiple of 8, several groups: the XCD-aware workgroup permutation's remainder)
+    (2, 96, 96, 800, 3, 3), (1, 48, 192, 700, 3, 1), (3, 24, 144, 1300, 1, 1), (2, 192, 96, 330, 3, 9),
 ]
 
 
