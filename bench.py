@@ -54,7 +54,7 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 WEIGHT_SEED = 201
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: long enough for the clocks to settle (a cfg2 step is 1.4 ms: 20 steps after 5 warm-up ones read 3-4 %
@@ -76,7 +76,199 @@ def parse():
     ap.add_argument("--no-table", action="store_true",
                     help="ignore the shipped launch-shape table (svcc23_fastsvc_amd/tuned_mi355x.json)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
-    return ap.parse_args()
+    ap.add_argument("--detail", default=os.environ.get("FASTSVC_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
+                    help="where the full record goes (per-kernel table, secondary workloads' rooflines, notes); stdout carries "
+                         "only the compact line")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: exercise the launcher, the gloo rendezvous, the barrier + max-over-ranks timing and the "
+                         "line builder with a sleep as the step (tests/test_bench_line.py)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The ONE stdout line stays small (the driver's parser gave up on round 4's 21 KB line): headline fields, the dominant
+# kernel's roofline, the CPU baseline and one {ms_per_step, e2e_frac} pair per secondary workload.  Everything else -
+# the per-kernel table, the secondary workloads' own rooflines, notes - goes to --detail (bench_detail.json).
+# ---------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6144
+SHORT_DTYPE = {"float32": "f32 (products as split-f16 MFMA x3, f32 accumulate; f32 storage)",
+               "bfloat16": "bf16 (bf16 MFMA products, f32 accumulate; bf16 storage)"}
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "secondary", "detail")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches_per_step",
+                 "alg_bytes_per_launch", "alg_flops_per_launch", "e2e_frac", "most_time_lost")
+
+
+def _sig(x, n=5):
+    """Floats to n significant digits, recursively (the line carries measurements, not 17-digit doubles)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def short_dtype(storage: str, arithmetic: str = "") -> str:
+    if arithmetic in ("f32", "f32 arithmetic, bf16 activation storage"):      # FASTSVC_HX=0: the f32-input MFMA kernels
+        return arithmetic
+    return SHORT_DTYPE[storage]
+
+
+def compact_roofline(roof):
+    if not roof or "error" in roof:
+        return roof
+    out = {k: roof.get(k) for k in ROOFLINE_KEYS if k not in ("e2e_frac", "most_time_lost")}
+    out["e2e_frac"] = (roof.get("e2e") or {}).get("frac")
+    lost = roof.get("most_time_lost") or {}
+    out["most_time_lost"] = {"kernel": lost.get("kernel"), "frac": lost.get("frac"), "ms_per_step": lost.get("ms_per_step")}
+    return out
+
+
+def compact_secondary(sec):
+    if not sec:
+        return None
+    out = {}
+    for k, v in sec.items():
+        if not isinstance(v, dict):
+            continue
+        if "error" in v:
+            out[k] = {"error": str(v["error"])[:160]}
+        elif "cost_model" in v:                                   # the off-table shape: cost model vs autotuned
+            out[k] = {"ms_per_step": v["cost_model"]["ms_per_step"], "autotuned_ms_per_step": v["autotuned"]["ms_per_step"]}
+        else:
+            e2e = ((v.get("roofline") or {}).get("e2e") or {}).get("frac")
+            out[k] = {"ms_per_step": v.get("ms_per_step"), "e2e_frac": e2e}
+            if v.get("n_gpus", 1) != 1:
+                out[k]["n_gpus"] = v["n_gpus"]
+    return out
+
+
+def compact_cpu(cpu):
+    if not cpu:
+        return None
+    out = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind")}
+    out["sample"] = str(cpu.get("sample", ""))[:200]
+    if "samples_per_s_by_threads" in cpu:
+        out["by_threads"] = cpu["samples_per_s_by_threads"]
+    return out
+
+
+def compact_line(full: dict, detail_path=None) -> dict:
+    """The line the driver parses, from the full record: the contract's keys plus `roofline` and `cpu_baseline`."""
+    line = {k: full.get(k) for k in LINE_KEYS if k not in ("roofline", "cpu_baseline", "secondary", "detail")}
+    line["dtype"] = str(full.get("dtype", ""))[:80]
+    cfgd = dict(full.get("config") or {})
+    cfgd["workload"] = str(cfgd.get("workload", ""))[:200]
+    line["config"] = {k: cfgd[k] for k in ("workload", "global_batch", "utterance_samples", "parallelism") if k in cfgd}
+    line["roofline"] = compact_roofline(full.get("roofline"))
+    line["cpu_baseline"] = compact_cpu(full.get("cpu_baseline"))
+    line["secondary"] = compact_secondary(full.get("secondary"))
+    line["detail"] = os.path.basename(detail_path) if detail_path else None
+    return _sig(line)
+
+
+def emit(json_fd: int, full: dict, detail_path):
+    """Write the full record to `detail_path` and the compact line to the saved stdout descriptor."""
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError as e:                                     # a read-only tree must not take the line down
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+            detail_path = None
+    text = json.dumps(compact_line(full, detail_path), separators=(",", ":"))
+    if len(text) > LINE_LIMIT:                                   # never again: drop the optional blocks before the headline
+        slim = compact_line(full, detail_path)
+        slim["secondary"] = {k: {"ms_per_step": v.get("ms_per_step")} for k, v in (slim.get("secondary") or {}).items()}
+        text = json.dumps(slim, separators=(",", ":"))
+    sys.stdout.flush()
+    os.write(json_fd, (text + "\n").encode())
+
+
+def self_launch(args, argv):
+    """`bench.py --gpus N` (N > 1) started as ONE process with no WORLD_SIZE: start the N ranks here, one per visible GPU,
+    the way the contract's torch.distributed.run command would, and pass their single line through."""
+    import socket
+    import subprocess
+    if not args.dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible - refusing to report a "
+                             f"{args.gpus}-GPU figure from fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, json_fd):
+    """--dry-run: every rank sleeps 1 ms per step; gloo barrier + MAX over ranks as in the real run; rank 0 prints the
+    compact line built from a canned roofline (no GPU, no library)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    steps, warmup = args.steps or 5, args.warmup if args.warmup is not None else 1
+    for _ in range(warmup):
+        time.sleep(0.001)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        time.sleep(0.001)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        full = canned_result(world, steps, warmup, elapsed)
+        emit(json_fd, full, args.detail)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def canned_result(world=1, steps=5, warmup=1, elapsed=0.005):
+    """A full record of the shape main() builds (worst-case sizes: long notes, 30 kernels, every secondary block) - for
+    --dry-run and for the line-size test."""
+    note = "n" * 500
+    per_kernel = {f"bf16::conv_hx_kernel<{i},2,1,4,0,4,1,true,false>": {"ms_per_step": 1.234567891234, "launches": 2,
+                  "TFLOPs": 123.456789123, "GBs": 4321.123456789, "roofline_ms": 0.123456789123, "frac": 0.123456789123}
+                  for i in range(30)}
+    roof = {"bound": "hbm", "achieved": 4380.123456789, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": 0.5475154320987,
+            "traffic": 3767000000.0, "traffic_source": note, "kernel": "bf16::conv_hx_kernel<2,2,1,4,0,4,1,true,false>",
+            "kernel_choice": "most time per step", "avg_launch_us": 842.2123456789, "launches_per_step": 2,
+            "alg_bytes_per_launch": 3686400000.0, "alg_flops_per_launch": 1.0e11,
+            "most_time_lost": {"kernel": "bf16::cond_stage1_kernel<x1>", "ms_per_step": 1.54, "roofline_ms": 0.19, "frac": 0.125,
+                               "lost_ms_per_step": 1.35},
+            "e2e": {"frac": 0.3212345678, "note": note, "per_kernel_roofline_ms": 3.73}, "per_kernel": per_kernel}
+    sec = {k: {"workload": note, "ms_per_step": 1.3801234567, "dtype": note, "roofline": {"e2e": {"frac": 0.31234567, "note": note},
+                                                                                         "top_kernels_by_time": per_kernel}}
+           for k in ("cfg3_float32", "cfg2_float32", "cfg2_bfloat16", "cfg1_float32", "cfg1_bfloat16", "cfg4_bfloat16_n1",
+                     "cfg4_float32_n1", "cfg4var_float32_n1", "cfg5_float32", "cfg5_bfloat16")}
+    sec["off_table_shape"] = {"workload": note, "cost_model": {"ms_per_step": 1.1}, "autotuned": {"ms_per_step": 1.0}}
+    return {"metric": "audio samples/sec (24 kHz) FastSVC generator fwd", "value": 64 * 240000 * steps / elapsed * world,
+            "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": SHORT_DTYPE["bfloat16"], "data": "synthetic",
+            "config": {"workload": "dry run (no GPU): " + note, "global_batch": 64 * world, "utterance_samples": 240000,
+                       "parallelism": f"utterance-parallel x{world}"},
+            "roofline": roof, "secondary": sec,
+            "cpu_baseline": {"value": 8.4e5, "unit": "samples/s", "cores": 16, "kind": "port", "sample": note,
+                             "samples_per_s_by_threads": {"1": 3.0e5, "8": 7.0e5, "16": 8.4e5, "32": 8.0e5, "64": 7.0e5},
+                             "cfg2": {"x": note}}}
 
 
 def resolve_workload(gpus: int, workload, storage):
@@ -365,7 +557,7 @@ def run_off_table_shape(cfg, dev, B=5, F=731, steps=50, warmup=10):
     for mode in ("cost_model", "autotuned"):
         plan = A.Plan(cfg, compact_workspace=True)
         blob = plan.pack(S.synth_state_dict(cfg, WEIGHT_SEED)).to(dev)
-        ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+        ws = torch.empty(plan.workspace_bytes(B, plan.padded_frames(F)), dtype=torch.uint8, device=dev)
         n_entries = sum(1 for k in plan.tuned_shapes() if k.split("|")[1] == str(B))
         if mode == "autotuned":
             plan.forward(blob, *args_dev, workspace=ws, autotune=True)
@@ -488,7 +680,11 @@ def training_kernel_rooflines(dev, B, T, n=20):
     return out
 
 
-def run_cfg5(args, dist, world, rank, dev):
+class _Skip(Exception):
+    pass
+
+
+def run_cfg5(args, dist, world, rank, dev, extras=True):
     """BASELINE config 5: the recipe's training step (train_fastsvc.py:157-240) per GPU on a batch of 32 crops of
     16000 samples (fastsvc.yaml:71-72), both sub-networks training, gradients averaged over the ranks (RCCL).
     Generator forward = HIP kernels (twice per step: the trainer's second, no-grad forward feeds the
@@ -522,6 +718,8 @@ def run_cfg5(args, dist, world, rank, dev):
     # discriminator and losses included), `hip_share_of_step` says how much of the step the HIP launches are
     roof = None
     try:
+        if not extras:
+            raise _Skip()
         with torch.no_grad():
             roof = roofline(gen.plan, gen.packed_weights(dev), [ppg, sine, lft, emb], ms, n_prof=2)
         roof["hip_forwards_per_step"] = 2
@@ -529,14 +727,16 @@ def run_cfg5(args, dist, world, rank, dev):
         roof["e2e"]["frac"] = 2.0 * roof["e2e"]["per_kernel_roofline_ms"] / ms
         roof["e2e"]["note"] += ("  cfg5: frac = 2 x the forward's per-kernel roofline / the measured TRAINING step - the backward, "
                                 "discriminator and losses are PyTorch-ROCm operators and count as time without roofline.")
+    except _Skip:
+        roof = None
     except Exception as e:
         roof = {"error": repr(e)}
     try:
-        train_kernels = training_kernel_rooflines(dev, B, T)
+        train_kernels = training_kernel_rooflines(dev, B, T) if extras else None
     except Exception as e:
         train_kernels = {"error": repr(e)}
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and extras:
         cpu = cpu_train_step_baseline(args.cpu_seconds)
     n_g = sum(p.numel() for p in gen.parameters())
     n_d = sum(p.numel() for p in disc.parameters())
@@ -544,7 +744,8 @@ def run_cfg5(args, dist, world, rank, dev):
         "metric": "audio samples/sec (24 kHz) FastSVC training step", "value": world * B * T * args.steps / elapsed,
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"generator forward: {gen.plan.arithmetic}; " + ("generator backward: float32 HIP convolution / FiLM-norm nodes (f32 master weights, optimizer state, "
+        "dtype": short_dtype(args.storage, gen.plan.arithmetic),
+        "dtype_note": f"generator forward: {gen.plan.arithmetic}; " + ("generator backward: float32 HIP convolution / FiLM-norm nodes (f32 master weights, optimizer state, "
                  "InstanceNorm statistics), remaining ops under bf16 autocast; discriminator, STFT and adversarial losses f32 (MIOpen's bf16 "
                  "backward-data of the discriminator's first conv faults intermittently on this ROCm: training.py)" if bf16 else
                  "generator backward: float32 HIP convolution / FiLM-norm nodes (f32-operand MFMA); STFT loss f32 HIP; discriminator f32 PyTorch-ROCm"),
@@ -562,8 +763,20 @@ def run_cfg5(args, dist, world, rank, dev):
     }
 
 
-def main():
-    args = parse()
+def run_cfg5_secondary(storage, dev, steps=10, warmup=6):
+    """BASELINE config 5's train step inside the default line: 10 timed steps at the recipe batch on this GPU."""
+    ns = argparse.Namespace(storage=storage, steps=steps, warmup=warmup, no_cpu_baseline=True, cpu_seconds=0.0)
+    full = run_cfg5(ns, None, 1, 0, dev, extras=False)
+    torch.cuda.empty_cache()
+    return {"workload": full["config"]["workload"], "ms_per_step": full["ms_per_step"], "value": full["value"],
+            "unit": full["unit"], "steps": steps, "warmup": warmup, "dtype": full["dtype"]}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, argv)                               # never returns
     default_workload = args.workload is None
     args.workload, args.storage = resolve_workload(args.gpus, args.workload, args.storage)
     big = args.workload in ("cfg3", "cfg4", "cfg4var")
@@ -582,8 +795,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, json_fd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     dist = None
@@ -599,8 +814,7 @@ def main():
     if args.workload == "cfg5":
         line = run_cfg5(args, dist, world, rank, dev)
         if rank == 0:
-            sys.stdout.flush()
-            os.write(json_fd, (json.dumps(line) + "\n").encode())
+            emit(json_fd, line, args.detail)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -749,7 +963,9 @@ def main():
                     ("cfg4_bfloat16_n1", lambda: run_cfg4_single_gpu(cfg, dev, storage="bfloat16")),
                     ("cfg4_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev)),
                     ("cfg4var_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev, name="cfg4var")),
-                    ("off_table_shape", lambda: run_off_table_shape(cfg, dev))]
+                    ("off_table_shape", lambda: run_off_table_shape(cfg, dev)),
+                    ("cfg5_float32", lambda: run_cfg5_secondary("float32", dev)),
+                    ("cfg5_bfloat16", lambda: run_cfg5_secondary("bfloat16", dev))]
             for key, fn in runs:
                 try:
                     secondary[key] = fn()
@@ -769,7 +985,7 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": plan.arithmetic,
+            "dtype": short_dtype(args.storage, plan.arithmetic), "dtype_note": plan.arithmetic,
             "data": "synthetic",
             "config": {"workload": (f"{args.workload}: {wl['desc']}, sharded over {world} GPU(s) in batches of <= {B}, "
                                     if strong else f"{args.workload}: {wl['desc']} per GPU, ") +
@@ -786,8 +1002,7 @@ def main():
             "secondary": secondary,
             "cpu_baseline": cpu,
         }
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        emit(json_fd, line, args.detail)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
