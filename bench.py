@@ -68,6 +68,9 @@ def parse(argv=None):
     ap.add_argument("--storage", default=None, choices=["float32", "bfloat16"],
                     help="workspace tensor storage: bfloat16 = BASELINE config 3's dtype (default for the forward "
                          "workloads: what `value` is quoted on); float32 = the 1e-3 parity path (default for cfg5)")
+    ap.add_argument("--discriminator", default="melgan", choices=["melgan", "hifigan"],
+                    help="cfg5: melgan = the recipe yaml's MelGAN multi-scale discriminator (4.35 M parameters); hifigan = the HiFiGAN "
+                         "multi-period + multi-scale discriminator BASELINE config 5 names (fastsvc.py:631-1143 defaults, 70.7 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 float32 / bfloat16 block")
     ap.add_argument("--autotune", action="store_true",
@@ -258,7 +261,7 @@ def canned_result(world=1, steps=5, warmup=1, elapsed=0.005):
     sec = {k: {"workload": note, "ms_per_step": 1.3801234567, "dtype": note, "roofline": {"e2e": {"frac": 0.31234567, "note": note},
                                                                                          "top_kernels_by_time": per_kernel}}
            for k in ("cfg3_float32", "cfg2_float32", "cfg2_bfloat16", "cfg1_float32", "cfg1_bfloat16", "cfg4_bfloat16_n1",
-                     "cfg4_float32_n1", "cfg4var_float32_n1", "cfg5_float32", "cfg5_bfloat16")}
+                     "cfg4_float32_n1", "cfg4var_float32_n1", "cfg5_float32", "cfg5_bfloat16", "cfg5_hifigan_float32")}
     sec["off_table_shape"] = {"workload": note, "cost_model": {"ms_per_step": 1.1}, "autotuned": {"ms_per_step": 1.0}}
     return {"metric": "audio samples/sec (24 kHz) FastSVC generator fwd", "value": 64 * 240000 * steps / elapsed * world,
             "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -700,7 +703,10 @@ def run_cfg5(args, dist, world, rank, dev, extras=True):
     gen.load_state_dict({k: torch.from_numpy(v) for k, v in S.synth_state_dict(cfg, WEIGHT_SEED).items()})
     gen.activation_storage = args.storage
     gen = gen.to(dev).train()
-    disc = TRN.MelGANMultiScaleDiscriminator(**TRN.RECIPE["discriminator_params"]).to(dev).train()
+    hifi = getattr(args, "discriminator", "melgan") == "hifigan"
+    disc = (TRN.HiFiGANMultiScaleMultiPeriodDiscriminator() if hifi else
+            TRN.MelGANMultiScaleDiscriminator(**TRN.RECIPE["discriminator_params"])).to(dev).train()
+    dname = "HiFiGAN multi-period + multi-scale discriminator (reference defaults)" if hifi else "MelGAN multi-scale discriminator (recipe yaml)"
     bf16 = args.storage == "bfloat16"
     trainer = TRN.TrainStep(gen, disc, dict(discriminator_train_start_steps=0, autocast_dtype="bfloat16" if bf16 else None), steps=1)
     ppg, sine, lft, emb = S.device_batch(cfg, B, F, 5000 + rank, dev)
@@ -750,7 +756,7 @@ def run_cfg5(args, dist, world, rank, dev, extras=True):
                  "backward-data of the discriminator's first conv faults intermittently on this ROCm: training.py)" if bf16 else
                  "generator backward: float32 HIP convolution / FiLM-norm nodes (f32-operand MFMA); STFT loss f32 HIP; discriminator f32 PyTorch-ROCm"),
         "data": "synthetic",
-        "config": {"workload": f"cfg5: full train step (generator fwd + bwd, MelGAN multi-scale discriminator, MR-STFT x6 + adversarial "
+        "config": {"workload": f"cfg5: full train step (generator fwd + bwd, {dname}, MR-STFT x6 + adversarial "
                                f"losses, RAdam), batch {B} x {T} samples per GPU, data-parallel x{world} with a flat-bucket gradient all-reduce"
                                + (", bfloat16 (BASELINE config 5's dtype)" if bf16 else ", float32 (--storage bfloat16: config 5's dtype)"),
                    "global_batch": world * B, "utterance_samples": T, "parallelism": f"data-parallel x{world}",
@@ -763,9 +769,9 @@ def run_cfg5(args, dist, world, rank, dev, extras=True):
     }
 
 
-def run_cfg5_secondary(storage, dev, steps=10, warmup=6):
+def run_cfg5_secondary(storage, dev, steps=10, warmup=6, discriminator="melgan"):
     """BASELINE config 5's train step inside the default line: 10 timed steps at the recipe batch on this GPU."""
-    ns = argparse.Namespace(storage=storage, steps=steps, warmup=warmup, no_cpu_baseline=True, cpu_seconds=0.0)
+    ns = argparse.Namespace(storage=storage, steps=steps, warmup=warmup, no_cpu_baseline=True, cpu_seconds=0.0, discriminator=discriminator)
     full = run_cfg5(ns, None, 1, 0, dev, extras=False)
     torch.cuda.empty_cache()
     return {"workload": full["config"]["workload"], "ms_per_step": full["ms_per_step"], "value": full["value"],
@@ -965,7 +971,8 @@ def main(argv=None):
                     ("cfg4var_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev, name="cfg4var")),
                     ("off_table_shape", lambda: run_off_table_shape(cfg, dev)),
                     ("cfg5_float32", lambda: run_cfg5_secondary("float32", dev)),
-                    ("cfg5_bfloat16", lambda: run_cfg5_secondary("bfloat16", dev))]
+                    ("cfg5_bfloat16", lambda: run_cfg5_secondary("bfloat16", dev)),
+                    ("cfg5_hifigan_float32", lambda: run_cfg5_secondary("float32", dev, steps=5, warmup=4, discriminator="hifigan"))]
             for key, fn in runs:
                 try:
                     secondary[key] = fn()

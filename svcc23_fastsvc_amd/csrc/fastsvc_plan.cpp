@@ -1691,9 +1691,40 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
         const int NTb = cond_stage0_tile_columns(0);
         q.small = small_env >= 0 ? small_env : (((T + NTb - 1) / NTb) * B < slots_all ? 1 : 0);
     }
-    const int NT = cond_stage0_tile_columns(q.small);
-    const long ntx = (T + NT - 1) / NT;
-    if (tpw_env > 0) q.tpw = tpw_env;
+    // The layer pipeline (cond_stage0_pipe_kernel; q.small = 2, tpw = chunks per workgroup) where a workgroup gets a long
+    // run of chunks - its fill costs 5 + 8 / N steps -: one or two rounds of the 256 resident workgroups (one per CU).
+    // FASTSVC_COND_PIPE = 0: never, 2: always (tests, A/B); a launch-table entry "cond.0|B|T[|b]" with algorithm 4
+    // (phase kernel) / 5 (pipeline) decides for one batch shape.
+    // bfloat16 storage only by default: the float32-storage instance (split-binary16 products, two LDS pieces) returns run-to-run
+    // DIFFERENT values in a handful of tiles per 10^6 (tools/cond_pipe_determinism.py) - until that is understood
+    // float32 storage keeps the phase kernel, which is exact; FASTSVC_COND_PIPE = 2 still forces the pipeline for investigation.
+    static const int pipe_env = std::getenv("FASTSVC_COND_PIPE") ? std::atoi(std::getenv("FASTSVC_COND_PIPE")) : 1;
+    int pipe_mode = (pipe_env == 1 && P.storage != 1) ? 0 : pipe_env;
+    {
+        char key[96];
+        std::snprintf(key, sizeof(key), P.storage == 1 ? "cond.0|%d|%ld|b" : "cond.0|%d|%ld", B, (long)T);
+        std::lock_guard<std::mutex> lock(P.tune_mu);
+        auto it = P.tuned.find(key);
+        if (it != P.tuned.end() && it->second.algo == 4) pipe_mode = 0;
+        if (it != P.tuned.end() && it->second.algo == 5 && (P.storage == 1 || pipe_env == 2)) pipe_mode = 2;
+    }
+    if (pipe_mode && small_env < 0) {
+        const int NTp = cond_stage0_tile_columns(P.storage == 1 ? 3 : 2);
+        const long nchunks = (T + NTp - 1) / NTp;
+        long kc = 0;
+        for (int r = 2; r >= 1 && !kc; --r) {
+            const long per_utt = std::max<long>(1, (256L * r) / B);
+            const long k = (nchunks + per_utt - 1) / per_utt;
+            if (k >= (r == 2 ? 48 : 24) || (pipe_mode == 2 && r == 1)) kc = k;
+        }
+        // (the pipeline addresses both signals' hd rows of an utterance through ONE 32-bit-offset descriptor)
+        const bool hd_fits = ((long)B * q.hd_b + (long)d.C * q.hd_ld) * (P.storage == 1 ? 2L : 4L) < (1L << 31);
+        if (kc && hd_fits) { q.small = 2; q.tpw = (int)std::min<long>(tpw_env > 0 ? tpw_env : kc, 0xffff); }
+    }
+    const int NT = q.small == 2 ? 0 : cond_stage0_tile_columns(q.small);
+    const long ntx = q.small == 2 ? 0 : (T + NT - 1) / NT;
+    if (q.small == 2) {}
+    else if (tpw_env > 0) q.tpw = tpw_env;
     else {
         const long slots = P.storage == 1 ? 512 : 256, total = ntx * B;     // workgroups resident at a time (LDS: two per CU in bfloat16 storage, one in float32)
         const long rounds = std::max<long>(1, (total + slots * 32 - 1) / (slots * 32));
@@ -1719,7 +1750,8 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
         const double ae = P.storage == 1 ? 2.0 : 4.0;
         const double bytes = (2.0 * 4.0 + 2.0 * C * ae + 2.0 * C * ae / d1.scale) * cols +
                              4.0 * (double)(2 * (d.c2[0].w_floats + d.c3[0].w_floats + d.film[0].w_floats) + d.heads.w_floats);
-        hipError_t e = prof->begin(stream, "cond.0", P.storage == 1 ? "cond_stage0<x1>" : "cond_stage0<x3>", flops, bytes);
+        hipError_t e = prof->begin(stream, "cond.0", q.small == 2 ? (P.storage == 1 ? "cond_stage0_pipe<x1>" : "cond_stage0_pipe<x3>")
+                                                                 : (P.storage == 1 ? "cond_stage0<x1>" : "cond_stage0<x3>"), flops, bytes);
         if (e != hipSuccess) return e;
         e = launch();
         if (e != hipSuccess) return e;

@@ -382,6 +382,35 @@ def fill_module_from_hash(module, seed: int) -> None:
 
 
 # ---------------------------------------------------------------------------
+# HiFiGAN discriminator fixture configuration (tests/golden/hifigan_disc.npz): reduced widths - the default widths hold
+# 70.7 M parameters - chosen so that every structural feature is exercised: three scales with pooling, grouped strided
+# k = 41 convolutions whose group count grows to its cap, five periods with reflect padding (the length below is a multiple
+# of none of them), hidden widths that reach their caps (the period stack's output conv reads the capped width).
+# ---------------------------------------------------------------------------
+HIFIGAN_FIXTURE_PARAMS = dict(
+    scales=3,
+    scale_downsample_pooling="AvgPool1d",
+    scale_downsample_pooling_params=dict(kernel_size=4, stride=2, padding=2),
+    scale_discriminator_params=dict(in_channels=1, out_channels=1, kernel_sizes=[15, 41, 5, 3], channels=16,
+                                    max_downsample_channels=64, max_groups=16, bias=True, downsample_scales=[2, 2, 4, 4, 1],
+                                    nonlinear_activation="LeakyReLU", nonlinear_activation_params=dict(negative_slope=0.1)),
+    follow_official_norm=True,
+    periods=[2, 3, 5, 7, 11],
+    period_discriminator_params=dict(in_channels=1, out_channels=1, kernel_sizes=[5, 3], channels=4,
+                                     downsample_scales=[3, 3, 3, 3, 1], max_downsample_channels=16, bias=True,
+                                     nonlinear_activation="LeakyReLU", nonlinear_activation_params=dict(negative_slope=0.1),
+                                     use_weight_norm=True, use_spectral_norm=False),
+)
+HIFIGAN_FIXTURE_INPUT = (2, 1, 4001)       # (B, 1, T)
+
+
+def key_hashes(keys) -> np.ndarray:
+    """int64 CRC32 of every state-dict key, in order: module-tree equality as integer data."""
+    import zlib
+    return np.array([zlib.crc32(k.encode()) for k in keys], dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------
 # Multi-resolution STFT loss test signals (tests/golden/stft_loss.npz: the expected values come from the reference)
 # ---------------------------------------------------------------------------
 def stft_loss_cases(recipe_params: Dict) -> List[Tuple[str, np.ndarray, np.ndarray, Dict]]:

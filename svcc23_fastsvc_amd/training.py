@@ -17,10 +17,15 @@ the two adversarial losses, `RAdam` (``harana/optimizers/radam.py:14-99``; one f
 ``torch._foreach``), and `TrainStep` with a flat-bucket RCCL gradient all-reduce for data-parallel training (the
 reference trains on ONE GPU; BASELINE config 5 asks for 8).
 
-Honest scope: the generator FORWARD runs on the HIP kernels; its backward is PyTorch-ROCm autograd over the
-restated dataflow (``autograd.py``), the discriminator and the STFT loss are PyTorch-ROCm operators (stock
-convolutions / rocFFT).  Hand-written backward kernels are not built.  Everything here is pinned
-against the LIVE reference by ``tests/golden/train_step.npz`` (``tests/golden/make_golden.py train``).
+Honest scope: the generator FORWARD runs on the fused HIP path; its BACKWARD is an autograd graph over the restated
+dataflow (``autograd.py``) whose heavy nodes are hand-written HIP kernels (``conv_grad.py``: convolution forward /
+backward-data / backward-weight, FiLM + InstanceNorm + LeakyReLU, the all-layer weight-norm) and whose
+remaining elementwise glue is PyTorch-ROCm; the multi-resolution STFT loss is HIP forward and backward
+(``stft_loss.py``) on the GPU (the torch composition below serves the CPU tests); the discriminators, the adversarial
+losses and RAdam are PyTorch-ROCm operators.  Discriminators restated here: the yaml's `MelGANMultiScaleDiscriminator`
+and the HiFiGAN multi-period / multi-scale family BASELINE config 5 names (``fastsvc.py:631-1143``).  Everything is
+pinned against the LIVE reference by ``tests/golden/train_step.npz``, ``train_recipe.npz`` and ``hifigan_disc.npz``
+(``tests/golden/make_golden.py train | train_recipe | hifigan``).
 """
 from __future__ import annotations
 
@@ -171,6 +176,200 @@ class MelGANMultiScaleDiscriminator(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# HiFiGAN multi-period / multi-scale discriminators (fastsvc.py:631-1143): what BASELINE config 5 names.  Same module
+# trees / state-dict keys as the reference classes, so its checkpoints load; `D(x)` -> list of final outputs, one per
+# sub-discriminator (scales first, then periods), `return_fmaps=True` adds the flat list of hidden feature maps.
+# ------------------------------------------------------------------------------------------------------------
+def _activation(name: str, params: Optional[dict]) -> nn.Module:
+    return getattr(nn, name)(**(params or {}))
+
+
+class HiFiGANPeriodDiscriminator(nn.Module):
+    """(B, C, T) is reflect-padded to a multiple of `period`, folded to (B, C, T / period, period) and run through
+    Conv2d layers with (k, 1) kernels - every column of the fold is a 1-D signal of stride `period` (fastsvc.py:631-760).
+    The output conv has kernel ``kernel_sizes[1] - 1`` with padding ``(kernel_sizes[1] - 1) // 2`` (so it is one row
+    LONGER than its input for the default 3) - as the reference builds it."""
+
+    def __init__(self, in_channels=1, out_channels=1, period=3, kernel_sizes=(5, 3), channels=32,
+                 downsample_scales=(3, 3, 3, 3, 1), max_downsample_channels=1024, bias=True,
+                 nonlinear_activation="LeakyReLU", nonlinear_activation_params=None, use_weight_norm=True,
+                 use_spectral_norm=False):
+        super().__init__()
+        k0, k1 = int(kernel_sizes[0]), int(kernel_sizes[1])
+        if len(kernel_sizes) != 2 or k0 % 2 == 0 or k1 % 2 == 0:
+            raise ValueError("kernel_sizes must be two odd numbers")
+        if use_weight_norm and use_spectral_norm:
+            raise ValueError("Either use use_weight_norm or use_spectral_norm.")
+        act = nonlinear_activation_params if nonlinear_activation_params is not None else {"negative_slope": 0.1}
+        self.period = int(period)
+        self.convs = nn.ModuleList()
+        c_in, c_out = in_channels, channels
+        for sc in downsample_scales:
+            self.convs.append(nn.Sequential(nn.Conv2d(c_in, c_out, (k0, 1), (int(sc), 1), padding=((k0 - 1) // 2, 0), bias=bias),
+                                            _activation(nonlinear_activation, act)))
+            c_in, c_out = c_out, min(c_out * 4, max_downsample_channels)
+        # (c_out has already been advanced once more: the reference's output conv reads `out_chs`, not `in_chs` - equal
+        # whenever the last hidden width sits at the cap, which the constructor requires of a loadable configuration)
+        self.output_conv = nn.Conv2d(c_out, out_channels, (k1 - 1, 1), 1, padding=((k1 - 1) // 2, 0), bias=bias)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                if use_weight_norm:
+                    nn.utils.weight_norm(m)
+                elif use_spectral_norm:
+                    nn.utils.spectral_norm(m)
+
+    def forward(self, x, return_fmaps: bool = False):
+        b, c, t = x.shape
+        if t % self.period:
+            pad = self.period - t % self.period
+            x = F.pad(x, (0, pad), "reflect")
+            t += pad
+        x = x.view(b, c, t // self.period, self.period)
+        fmaps = []
+        for f in self.convs:
+            x = f(x)
+            fmaps.append(x)
+        out = torch.flatten(self.output_conv(x), 1, -1)
+        return (out, fmaps) if return_fmaps else out
+
+
+class HiFiGANMultiPeriodDiscriminator(nn.Module):
+    def __init__(self, periods=(2, 3, 5, 7, 11), discriminator_params=None):
+        super().__init__()
+        params = dict(discriminator_params or {})
+        params.pop("period", None)
+        self.discriminators = nn.ModuleList(HiFiGANPeriodDiscriminator(period=int(p), **params) for p in periods)
+
+    def forward(self, x, return_fmaps: bool = False):
+        outs, fmaps = [], []
+        for d in self.discriminators:
+            if return_fmaps:
+                o, fm = d(x, True)
+                fmaps.extend(fm)
+            else:
+                o = d(x)
+            outs.append(o)
+        return (outs, fmaps) if return_fmaps else outs
+
+
+class HiFiGANScaleDiscriminator(nn.Module):
+    """Conv1d stack: k = 15 input conv, grouped strided k = 41 convs (groups 4, 16, ... <= max_groups; channels doubling up
+    to the cap), a k = 5 conv and the k = 3 output conv (fastsvc.py:835-975).
+
+    Reference quirk kept on purpose (SURVEY.md §8 e): its `apply_weight_norm` / `apply_spectral_norm` test
+    ``isinstance(m, nn.Conv2d)`` on this Conv1d-only stack (fastsvc.py:957-975), so NEITHER norm is ever applied and the
+    state dict holds plain `weight` / `bias` - whatever `use_weight_norm`, `use_spectral_norm` or the multi-scale
+    wrapper's `follow_official_norm` say.  `reference_norm_quirk=False` applies the norm the flags ask for instead."""
+
+    def __init__(self, in_channels=1, out_channels=1, kernel_sizes=(15, 41, 5, 3), channels=128,
+                 max_downsample_channels=1024, max_groups=16, bias=True, downsample_scales=(2, 2, 4, 4, 1),
+                 nonlinear_activation="LeakyReLU", nonlinear_activation_params=None, use_weight_norm=True,
+                 use_spectral_norm=False, reference_norm_quirk: bool = True):
+        super().__init__()
+        ks = [int(k) for k in kernel_sizes]
+        if len(ks) != 4 or any(k % 2 == 0 for k in ks):
+            raise ValueError("kernel_sizes must be four odd numbers")
+        if use_weight_norm and use_spectral_norm:
+            raise ValueError("Either use use_weight_norm or use_spectral_norm.")
+        act = nonlinear_activation_params if nonlinear_activation_params is not None else {"negative_slope": 0.1}
+        self.layers = nn.ModuleList()
+        self.layers.append(nn.Sequential(nn.Conv1d(in_channels, channels, ks[0], bias=bias, padding=(ks[0] - 1) // 2),
+                                         _activation(nonlinear_activation, act)))
+        c_in, c_out, groups = channels, channels, 4
+        for sc in downsample_scales:
+            self.layers.append(nn.Sequential(nn.Conv1d(c_in, c_out, kernel_size=ks[1], stride=int(sc), padding=(ks[1] - 1) // 2,
+                                                       groups=groups, bias=bias), _activation(nonlinear_activation, act)))
+            c_in = c_out
+            c_out = min(c_in * 2, max_downsample_channels)
+            groups = min(groups * 4, max_groups)
+        c_out = min(c_in * 2, max_downsample_channels)
+        self.layers.append(nn.Sequential(nn.Conv1d(c_in, c_out, kernel_size=ks[2], stride=1, padding=(ks[2] - 1) // 2, bias=bias),
+                                         _activation(nonlinear_activation, act)))
+        self.last_layer = nn.Conv1d(c_out, out_channels, kernel_size=ks[3], stride=1, padding=(ks[3] - 1) // 2, bias=bias)
+        if not reference_norm_quirk:
+            for m in self.modules():
+                if isinstance(m, nn.Conv1d):
+                    if use_weight_norm:
+                        nn.utils.weight_norm(m)
+                    elif use_spectral_norm:
+                        nn.utils.spectral_norm(m)
+
+    def forward(self, x, return_fmaps: bool = False):
+        fmaps = []
+        for f in self.layers:
+            x = f(x)
+            fmaps.append(x)
+        out = self.last_layer(x)
+        return (out, fmaps) if return_fmaps else out
+
+
+class HiFiGANMultiScaleDiscriminator(nn.Module):
+    """Scale k sees the input pooled k times (AvgPool1d kernel 4, stride 2, padding 2: torch's default count_include_pad)."""
+
+    def __init__(self, scales=3, downsample_pooling="AvgPool1d", downsample_pooling_params=None, discriminator_params=None,
+                 follow_official_norm=False, reference_norm_quirk: bool = True):
+        super().__init__()
+        self.discriminators = nn.ModuleList()
+        for i in range(int(scales)):
+            params = dict(discriminator_params or {})
+            if follow_official_norm:
+                params["use_weight_norm"], params["use_spectral_norm"] = (i != 0), (i == 0)
+            self.discriminators.append(HiFiGANScaleDiscriminator(reference_norm_quirk=reference_norm_quirk, **params))
+        pp = downsample_pooling_params if downsample_pooling_params is not None else dict(kernel_size=4, stride=2, padding=2)
+        self.pooling = getattr(nn, downsample_pooling)(**pp)
+
+    def forward(self, x, return_fmaps: bool = False):
+        outs, fmaps = [], []
+        for d in self.discriminators:
+            if return_fmaps:
+                o, fm = d(x, True)
+                fmaps.extend(fm)
+            else:
+                o = d(x)
+            outs.append(o)
+            x = self.pooling(x)
+        return (outs, fmaps) if return_fmaps else outs
+
+
+class HiFiGANMultiScaleMultiPeriodDiscriminator(nn.Module):
+    """`msd` + `mpd` (fastsvc.py:1056-1143): outputs of the scales, then of the periods."""
+
+    def __init__(self, scales=3, scale_downsample_pooling="AvgPool1d", scale_downsample_pooling_params=None,
+                 scale_discriminator_params=None, follow_official_norm=True, periods=(2, 3, 5, 7, 11),
+                 period_discriminator_params=None, reference_norm_quirk: bool = True):
+        super().__init__()
+        self.msd = HiFiGANMultiScaleDiscriminator(scales=scales, downsample_pooling=scale_downsample_pooling,
+                                                  downsample_pooling_params=scale_downsample_pooling_params,
+                                                  discriminator_params=scale_discriminator_params,
+                                                  follow_official_norm=follow_official_norm,
+                                                  reference_norm_quirk=reference_norm_quirk)
+        self.mpd = HiFiGANMultiPeriodDiscriminator(periods=periods, discriminator_params=period_discriminator_params)
+
+    def forward(self, x, return_fmaps: bool = False):
+        if return_fmaps:
+            so, sf = self.msd(x, True)
+            po, pf = self.mpd(x, True)
+            return so + po, sf + pf
+        return self.msd(x) + self.mpd(x)
+
+
+def discriminator_is_per_sample_stateless(d: nn.Module) -> bool:
+    """True when `D(cat([a, b]))` equals `cat([D(a), D(b)])` and a forward mutates nothing: no BatchNorm (cross-sample
+    statistics) and no spectral norm (a power iteration per training forward) anywhere in the module."""
+    for m in d.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            return False
+        for hook in getattr(m, "_forward_pre_hooks", {}).values():
+            if type(hook).__name__ == "SpectralNorm":
+                return False
+        if hasattr(m, "parametrizations"):
+            for plist in m.parametrizations.values():
+                if any(type(q).__name__ == "_SpectralNorm" for q in plist):
+                    return False
+    return True
+
+
+# ------------------------------------------------------------------------------------------------------------
 # adversarial losses, MSE flavour (adversarial_loss.py:16-127); `outs`: list per discriminator of per-layer lists
 # ------------------------------------------------------------------------------------------------------------
 def _final(outs):
@@ -318,6 +517,11 @@ class TrainStep:
         # fault, depending on which solver MIOpen's find step picked (caught with MIOPEN_ENABLE_LOGGING_CMD=1)
         ac = cfg.get("autocast_dtype")
         self.autocast_dtype = getattr(torch, ac) if isinstance(ac, str) else ac
+        # fake + real through the discriminator as ONE batch, and its parameters frozen for the generator's adversarial term:
+        # only for discriminators whose forward is stateless per sample (weight-norm convolutions, LeakyReLU, pooling - the
+        # MelGAN and HiFiGAN families as the reference builds them); a BatchNorm or spectral-norm discriminator gets the
+        # reference's two calls in its order (train_fastsvc.py:207-211)
+        self._stateless_d = discriminator_is_per_sample_stateless(discriminator)
 
     def _autocast(self, discriminator: bool = False):
         dev = next(self.generator.parameters()).device
@@ -345,7 +549,7 @@ class TrainStep:
                 # backward work (its weight gradients) and as many launches; frozen for this one call, same updates
                 # (HIP-graph replay of the discriminator's own update, torch.cuda.make_graphed_callables, was measured
                 # too: 53.6 ms against 52.0 ms launch by launch - not kept)
-                d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+                d_params = [p for p in self.discriminator.parameters() if p.requires_grad] if self._stateless_d else []
                 for p in d_params:
                     p.requires_grad_(False)
                 try:
@@ -367,7 +571,7 @@ class TrainStep:
             if train_d and hasattr(self.generator, "prefetch_packed_weights"):
                 self.generator.prefetch_packed_weights()     # parameters -> host while the GPU runs the real batch below
         if train_d:
-            if cfg.get("batch_discriminator_inputs", True):
+            if cfg.get("batch_discriminator_inputs", True) and self._stateless_d:
                 # fake and real batch through the discriminator as ONE batch of 2B: it has no cross-sample operator (weight-norm
                 # convolutions, LeakyReLU, average pooling), so the outputs are those of two calls - and the step, which is bound
                 # by the host's launch path once the generator's kernels are hand-written, issues half as many discriminator
@@ -378,7 +582,7 @@ class TrainStep:
                 with self._autocast(discriminator=True):
                     finals = _final(self.discriminator(torch.cat([y_.detach(), y], dim=0)))
                     real, fake = discriminator_adversarial_loss([o[:nb] for o in finals], [o[nb:] for o in finals])
-            else:
+            elif self._stateless_d:
                 # (the real batch first: it does not depend on the generator, and the host re-packs the updated generator
                 # weights while the GPU is busy with it - same losses as `D(y_), D(y)` in the reference's order)
                 with self._autocast(discriminator=True):
@@ -386,6 +590,13 @@ class TrainStep:
                 with torch.no_grad():
                     y_ = self.generator(*x)              # second forward, with the updated generator
                 with self._autocast(discriminator=True):
+                    real, fake = discriminator_adversarial_loss(self.discriminator(y_.detach()), p_real)
+            else:
+                # a discriminator with state (spectral norm's power iteration, BatchNorm): the reference's calls, in its order
+                with torch.no_grad():
+                    y_ = self.generator(*x)
+                with self._autocast(discriminator=True):
+                    p_real = self.discriminator(y)
                     real, fake = discriminator_adversarial_loss(self.discriminator(y_.detach()), p_real)
             dis_loss = real.float() + fake.float()
             logd["real_loss"], logd["fake_loss"], logd["discriminator_loss"] = real.detach(), fake.detach(), dis_loss.detach()

@@ -29,6 +29,9 @@ Fixtures written:
                         resolutions, the class defaults (window shorter than the frame, hop not dividing it) and a batch
                         with a silent and a very quiet prediction (bins at the 1e-7 floor): sc, mag and autograd's
                         d sc / dx, d mag / dx
+  hifigan_disc.npz      the HiFiGAN multi-scale + multi-period discriminator (fastsvc.py:631-1143; BASELINE config 5): key CRCs and
+                        shapes of the default-width module tree, outputs / feature-map means / adversarial losses of a
+                        reduced-width instance on hash inputs, one Trainer._train_step against it
   decode_chain.npz      decode_fastsvc.py:160-189 per utterance for three utterances of different
                         length: F0Statistics.estimate / .convert (features.py:41-108, std forced to 1),
                         then ``inference()`` with the converted F0 (noise_amp=0)
@@ -374,6 +377,99 @@ def train_recipe(M):
     print("train_recipe.npz:", len(out), "arrays", {k: float(v) for k, v in out.items() if k.startswith("loss/")})
 
 
+def hifigan(M):
+    """hifigan_disc.npz: the HiFiGAN multi-scale + multi-period discriminator BASELINE config 5 names (fastsvc.py:631-1143).
+    (1) default-width module tree: CRC32 of every state-dict key, every shape (70.7 M parameters - incl. the reference's
+    quirk that its scale discriminators carry NO weight / spectral norm); (2) reduced widths (synth.HIFIGAN_FIXTURE_PARAMS),
+    parameters from the integer-hash generator: the eight outputs and every hidden feature map's mean |.| on a hash input,
+    the adversarial losses, d gen_adv / d input; (3) one `Trainer._train_step` (train_fastsvc.py:157-240) of the tiny-width
+    generator against this discriminator, both sub-networks training: losses, per-parameter step norms and 4-element slices."""
+    import copy
+    import types
+    from harana.losses import MultiResolutionSTFTLoss, GeneratorAdversarialLoss, DiscriminatorAdversarialLoss
+    from harana.optimizers import RAdam
+    import yaml
+    with open(os.path.join(ROOT_REF, "egs/svcc23/fastsvc1/conf/fastsvc.yaml")) as f:
+        recipe = yaml.safe_load(f)
+    out = {}
+    Dfull = M.HiFiGANMultiScaleMultiPeriodDiscriminator()
+    sdf = Dfull.state_dict()
+    out["full/key_crc"] = S.key_hashes(sdf.keys())
+    out["full/shapes"] = np.array([list(v.shape) + [0] * (4 - v.dim()) for v in sdf.values()], dtype=np.int64)
+    out["full/numel"] = np.int64(sum(p.numel() for p in Dfull.parameters()))
+    del Dfull, sdf
+    seed_d, seed_x = 501, 502
+    D = M.HiFiGANMultiScaleMultiPeriodDiscriminator(**copy.deepcopy(S.HIFIGAN_FIXTURE_PARAMS))
+    S.fill_module_from_hash(D, seed_d)
+    D.train()
+    out["small/key_crc"] = S.key_hashes(D.state_dict().keys())
+    B, _, T = S.HIFIGAN_FIXTURE_INPUT
+    x = torch.from_numpy((0.3 * S.hash_normalish(seed_x, S.stream_id("hifigan.x"), B * T)).reshape(B, 1, T).astype(np.float32))
+    x_hat = torch.from_numpy((0.3 * S.hash_normalish(seed_x, S.stream_id("hifigan.x_hat"), B * T)).reshape(B, 1, T).astype(np.float32))
+    x_hat.requires_grad_(True)
+    outs, fmaps = D(x, return_fmaps=True)
+    outs_hat = D(x_hat)
+    for i, o in enumerate(outs):
+        out[f"small/real.{i}"] = o.detach().numpy()
+        out[f"small/fake.{i}"] = outs_hat[i].detach().numpy()
+    out["small/fmap_mean_abs"] = np.array([float(f.detach().abs().mean()) for f in fmaps], dtype=np.float64)
+    out["small/fmap_numel"] = np.array([f.numel() for f in fmaps], dtype=np.int64)
+    adv = GeneratorAdversarialLoss()(outs_hat)
+    adv.backward()
+    out["small/gen_adv"] = np.float64(adv)
+    out["small/d_gen_adv_d_x"] = x_hat.grad.numpy().copy()
+    real, fake = DiscriminatorAdversarialLoss()(outs_hat, outs)
+    out["small/dis_real"], out["small/dis_fake"] = np.float64(real), np.float64(fake)
+    # (3) one full train step, tiny generator + this discriminator
+    from oracle.refimport import _placeholder
+    for name in ("tensorboardX", "soundfile"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                _placeholder(name)
+    if not hasattr(sys.modules["tensorboardX"], "SummaryWriter"):
+        sys.modules["tensorboardX"].SummaryWriter = lambda *a, **k: None
+    from harana.bin import train_fastsvc as TR
+    cfg = S.TINY_CONFIG
+    seed_w, seed_b, seed_t, seed_d2 = 511, 512, 513, 514
+    Bt, F = 2, 25
+    Tt = F * cfg.hop
+    g, _ = build_reference(M, cfg, seed_w)
+    g.train()
+    D2 = M.HiFiGANMultiScaleMultiPeriodDiscriminator(**copy.deepcopy(S.HIFIGAN_FIXTURE_PARAMS))
+    S.fill_module_from_hash(D2, seed_d2)
+    D2.train()
+    conf = dict(recipe)
+    conf.update(discriminator_train_start_steps=0, use_stft_loss=True, lambda_aux=1.0, outdir="/tmp",
+                train_max_steps=10 ** 9, log_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, save_interval_steps=10 ** 9)
+    crit = {"gen_adv": GeneratorAdversarialLoss(), "dis_adv": DiscriminatorAdversarialLoss(),
+            "stft": MultiResolutionSTFTLoss(**recipe["stft_loss_params"])}
+    opt = {"generator": RAdam(g.parameters(), **recipe["generator_optimizer_params"]),
+           "discriminator": RAdam(D2.parameters(), **recipe["discriminator_optimizer_params"])}
+    sch = {k: torch.optim.lr_scheduler.StepLR(opt[k], **recipe[k + "_scheduler_params"]) for k in opt}
+    tr = TR.Trainer(steps=1, epochs=0, data_loader={}, sampler={"train": None}, model={"generator": g, "discriminator": D2},
+                    criterion=crit, optimizer=opt, scheduler=sch, config=conf, device=torch.device("cpu"))
+    tr.tqdm = types.SimpleNamespace(update=lambda n: None)
+    tr._check_train_finish = lambda: None
+    b = S.synth_batch(cfg, Bt, F, seed_b)
+    target = torch.from_numpy((0.3 * S.hash_normalish(seed_t, S.stream_id("train.target"), Bt * Tt)).reshape(Bt, 1, Tt).astype(np.float32))
+    xs = tuple(torch.from_numpy(a) for a in (b.ppg, b.sine, b.lft, b.spk_emb))
+    before = {"g": {k: v.detach().clone() for k, v in g.state_dict().items()},
+              "d": {k: v.detach().clone() for k, v in D2.state_dict().items()}}
+    tr.total_train_loss.clear()
+    tr._train_step((xs, target))
+    for k, v in tr.total_train_loss.items():
+        out[f"step/loss/{k.split('/')[-1]}"] = np.float64(v)
+    for tag, module in (("g", g), ("d", D2)):
+        for k, v in module.state_dict().items():
+            out[f"step/{tag}/step_norm/{k}"] = np.float64((v.detach() - before[tag][k]).double().norm())
+            out[f"step/{tag}/head/{k}"] = v.detach().flatten()[:4].numpy().copy()
+    out["meta"] = np.array([seed_d, seed_x, seed_w, seed_b, seed_t, seed_d2, Bt, F], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "hifigan_disc.npz"), **out)
+    print("hifigan_disc.npz:", len(out), "arrays", {k: float(v) for k, v in out.items() if k.startswith("step/loss/")})
+
+
 def fold(M):
     cfg = S.TINY_CONFIG
     g, sd = build_reference(M, cfg, 101)
@@ -412,10 +508,10 @@ def stft_loss(M):
 
 if __name__ == "__main__":
     M = import_reference()
-    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain", "grads", "train", "stft_loss"]
+    todo = sys.argv[1:] or ["tiny", "full", "inference", "fold", "decode_chain", "grads", "train", "stft_loss", "hifigan"]
     for name in todo:
         {"tiny": tiny, "full": full, "inference": inference, "fold": fold, "decode_chain": decode_chain, "grads": grads,
-         "train": train, "train_recipe": train_recipe, "stft_loss": stft_loss}[name](M)
+         "train": train, "train_recipe": train_recipe, "stft_loss": stft_loss, "hifigan": hifigan}[name](M)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -10,6 +10,6 @@ common="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-hono
 /opt/rocm/bin/hipcc $common "$@" -x hip -c $cs/fastsvc_cond.hip -o /tmp/cond_var_f32.o &
 /opt/rocm/bin/hipcc $common "$@" -DFASTSVC_ACT_BF16=1 -x hip -c $cs/fastsvc_cond.hip -o /tmp/cond_var_bf16.o &
 wait
-objs=$(ls $b/*.o | grep -v "/cond_")
+objs=$(ls $b/*.o | grep -v "/cond_" | grep -v "_tl_")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/cond_var_f32.o /tmp/cond_var_bf16.o -o $out
 echo $out
