@@ -1695,18 +1695,15 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
     // run of chunks - its fill costs 5 + 8 / N steps -: one or two rounds of the 256 resident workgroups (one per CU).
     // FASTSVC_COND_PIPE = 0: never, 2: always (tests, A/B); a launch-table entry "cond.0|B|T[|b]" with algorithm 4
     // (phase kernel) / 5 (pipeline) decides for one batch shape.
-    // bfloat16 storage only by default: the float32-storage instance (split-binary16 products, two LDS pieces) returns run-to-run
-    // DIFFERENT values in a handful of tiles per 10^6 (tools/cond_pipe_determinism.py) - until that is understood
-    // float32 storage keeps the phase kernel, which is exact; FASTSVC_COND_PIPE = 2 still forces the pipeline for investigation.
     static const int pipe_env = std::getenv("FASTSVC_COND_PIPE") ? std::atoi(std::getenv("FASTSVC_COND_PIPE")) : 1;
-    int pipe_mode = (pipe_env == 1 && P.storage != 1) ? 0 : pipe_env;
+    int pipe_mode = pipe_env;
     {
         char key[96];
         std::snprintf(key, sizeof(key), P.storage == 1 ? "cond.0|%d|%ld|b" : "cond.0|%d|%ld", B, (long)T);
         std::lock_guard<std::mutex> lock(P.tune_mu);
         auto it = P.tuned.find(key);
         if (it != P.tuned.end() && it->second.algo == 4) pipe_mode = 0;
-        if (it != P.tuned.end() && it->second.algo == 5 && (P.storage == 1 || pipe_env == 2)) pipe_mode = 2;
+        if (it != P.tuned.end() && it->second.algo == 5) pipe_mode = 2;
     }
     if (pipe_mode && small_env < 0) {
         const int NTp = cond_stage0_tile_columns(P.storage == 1 ? 3 : 2);
