@@ -623,7 +623,14 @@ struct P0Geom {
     static constexpr int CONST_FLOATS = 2 * 32 * 4 + 2 * 32 + 2 * 3 * 2 * 32 + 2 * 64;
     static constexpr int LAG = 8 / N;                  // chunks of the heads' stream in front of the workgroup's first column
     static constexpr int DUMMY = 64 * 32;              // 32 bytes per lane (shared by the waves: nobody reads them): where the guard-row copies of unmirrored lanes go
-    static constexpr size_t LDS = CONST_FLOATS * 4 + 8 * (size_t)PLANE + 2 * (size_t)STG + DUMMY;
+    // the raw signals in LDS: a ring of four blocks of XB chunks per signal, a block requested XB steps before it is
+    // committed (one step ahead the c1 / c3 waves sat through a memory latency per step: ~1.7 us, the whole pipeline's pace)
+    static constexpr int XB = 8;                       // chunks per block
+    static constexpr int BLK = XB * NT;                // floats per block
+    static constexpr int XR = 4 * BLK;                 // floats per signal ring (a power of two)
+    static constexpr int XPL = BLK / 64;               // floats per lane and block
+    static constexpr size_t LDS = CONST_FLOATS * 4 + 8 * (size_t)PLANE + 2 * (size_t)STG + DUMMY + 2 * (size_t)XR * 4;
+    static_assert((XR & (XR - 1)) == 0, "ring index by masking");
     static_assert(8 % N == 0 && N % 2 == 0, "the layers' total lag (8 tiles) is a whole number of chunks; the heads take tiles in pairs");
 };
 
@@ -765,6 +772,7 @@ void cond_stage0_pipe_kernel(const CondStage0Params p) {
     unsigned char* planes = reinterpret_cast<unsigned char*>(k5inv + 64);         // [c1, c2, h][signal] and the u pair: 8 planes
     unsigned char* stg = planes + 8 * PLANE;                                      // 2 staging buffers
     unsigned char* dummy = stg + 2 * GEO::STG + (threadIdx.x & 63) * 32;
+    float* xring = reinterpret_cast<float*>(stg + 2 * GEO::STG + GEO::DUMMY);     // [signal][XR]: x(t) at (t - tx0) & (XR - 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z;
@@ -777,6 +785,7 @@ void cond_stage0_pipe_kernel(const CondStage0Params p) {
     const int T1 = min(T0 + nch * NT, Tv);
     const int Ktot = nch + LAG;                            // chunks every layer runs
     const int nsteps = Ktot + 5;                           // layer l is busy at steps l .. l + Ktot - 1; l = 5: the copy wave
+    const int tx0 = T0 - 64 - GEO::BLK;                    // time of ring index 0 (block 0 = the block in front of c1's first chunk)
 
     // ---- operand scales (float32 storage) and tables: exactly cond_stage0_kernel's ----
     float sc[4][2] = {{1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}};
@@ -827,7 +836,7 @@ void cond_stage0_pipe_kernel(const CondStage0Params p) {
     }
     // every plane starts as zeros: the channel padding of the rings is never written again (c1's slot 3, the pair's
     // channels 2C + 8 ..), and what a layer computes from not yet written rows during the fill must be finite
-    for (int o = tid * 16; o < 8 * PLANE + 2 * GEO::STG; o += P0_NTHREADS * 16)
+    for (int o = tid * 16; o < 8 * PLANE + 2 * GEO::STG + GEO::DUMMY + 2 * GEO::XR * 4; o += P0_NTHREADS * 16)
         *reinterpret_cast<u32x4*>(planes + o) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 
@@ -854,20 +863,32 @@ void cond_stage0_pipe_kernel(const CondStage0Params p) {
                     wk[oo][pq][c] = f32x2{kw[0], kw[1]};
                 }
         }
-        float xn[3];
-        auto xfetch = [&](int k0) {
-            const int t = T0 - 64 + k0 * NT + col;
+        // this wave keeps its signal's ring filled: block j (ring indices j BLK ..) is requested when block j - 1 is committed,
+        // XB steps before its own commit; blocks 0 .. 2 before the first step
+        constexpr int XB = GEO::XB, BLK = GEO::BLK, XR = GEO::XR, XPL = GEO::XPL;
+        float* xs = xring + sig * XR;
+        float xblk[XPL];
+        auto xrequest = [&](int j) {
             #pragma unroll
-            for (int d = 0; d < 3; ++d) xn[d] = buf_load1(xr, ((unsigned)(t + d - 1) < (unsigned)Tv && !(dbg & 1)) ? (t + d - 1) * 4 : OOB_OFF, 0);
+            for (int r = 0; r < XPL; ++r) {
+                const int t = tx0 + j * BLK + r * 64 + lane;
+                xblk[r] = buf_load1(xr, ((unsigned)t < (unsigned)Tv && !(dbg & 1)) ? t * 4 : OOB_OFF, 0);
+            }
         };
-        xfetch(0);
+        auto xcommit = [&](int j) {
+            #pragma unroll
+            for (int r = 0; r < XPL; ++r) xs[(j * BLK + r * 64 + lane) & (XR - 1)] = xblk[r];
+        };
+        for (int j = 0; j < 3; ++j) { xrequest(j); xcommit(j); }
+        xrequest(3);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");       // (the wave's own reads below follow its writes in order)
         p0_steps(nsteps, [&](auto jc, int s) {
             constexpr int J = decltype(jc)::value;
             if (s < Ktot && !(dbg & 8)) {
                 constexpr int POS = J;
                 const int tc0 = T0 - 64 + s * NT;
-                float xa = xn[0], xb = xn[1], xc = xn[2];
-                xfetch(s + 1);                                 // (past the last chunk: beyond the utterance or unused)
+                const int u = BLK + s * NT + col;              // ring index of this lane's column
+                float xa = xs[(u - 1) & (XR - 1)], xb = xs[u & (XR - 1)], xc = xs[(u + 1) & (XR - 1)];
                 xa = fmaxf(xa, xa * LRELU_SLOPE); xb = fmaxf(xb, xb * LRELU_SLOPE); xc = fmaxf(xc, xc * LRELU_SLOPE);
                 const f32x2 xa2 = {xa, xa}, xb2 = {xb, xb}, xc2 = {xc, xc};
                 const bool edge = tc0 < 0 || tc0 + NT > Tv;
@@ -895,6 +916,14 @@ void cond_stage0_pipe_kernel(const CondStage0Params p) {
                     if (POS == 0) { unsigned char* g2 = col < 8 ? dst + RING * CS_ROW : dummy; cs_put8(g2, g2 + (col < 8 ? lo_off : 16), pk); }
                     if (POS == 2) { unsigned char* g2 = col >= NT - 8 ? dst - RING * CS_ROW : dummy; cs_put8(g2, g2 + (col >= NT - 8 ? lo_off : 16), pk); }
                 }
+            }
+            // block turn-over every XB steps: commit block m + 2 (requested XB steps ago; first needed by the last chunk of
+            // this block of steps), request block m + 3 - into the slot of block m - 1, whose last reader (c3, two steps
+            // and two tiles behind) left it a block of steps ago
+            if (s > 0 && (s & (XB - 1)) == 0) {
+                const int m = s / XB;
+                xcommit(m + 2);
+                xrequest(m + 3);
             }
         });
     } else if (wave < 8) {
@@ -927,16 +956,10 @@ void cond_stage0_pipe_kernel(const CondStage0Params p) {
         }
         const unsigned char* in_plane = planes + ((L - 1) * 2 + sig) * PLANE;
         unsigned char* out_base = planes + (L == 3 ? 6 * PLANE : (L * 2 + sig) * PLANE);
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + sig * p.x_sig + (long)b * p.x_b, Tv);
-        float xnext[N], xv[N];
+        const float* xs = xring + sig * GEO::XR;
+        float xv[N];
         #pragma unroll
-        for (int i = 0; i < N; ++i) { xnext[i] = 0.f; xv[i] = 0.f; }
-        auto xfetch = [&](int k) {                         // the raw signal at c3's columns (rank-1 residual), one step ahead
-            const int t = T0 - 64 + 16 * (k * N - 2) + l15;
-            #pragma unroll
-            for (int i = 0; i < N; ++i) xnext[i] = buf_load1(xr, ((unsigned)(t + 16 * i) < (unsigned)Tv && !(dbg & 1)) ? (t + 16 * i) * 4 : OOB_OFF, 0);
-        };
-        if (L == 2) xfetch(0);
+        for (int i = 0; i < N; ++i) xv[i] = 0.f;
         p0_steps(nsteps, [&](auto jc, int s) {
             constexpr int J = decltype(jc)::value;
             const int k = s - L;
@@ -946,8 +969,7 @@ void cond_stage0_pipe_kernel(const CondStage0Params p) {
                 if (L == 1) p0_layer_chunk<N, P1, 0>(in_plane, out_base, W, rd, wr, kbv, kivv, r1wv, xv, tstart, Tv, lane, dummy);
                 else if (L == 2) {
                     #pragma unroll
-                    for (int i = 0; i < N; ++i) xv[i] = xnext[i];
-                    xfetch(k + 1);
+                    for (int i = 0; i < N; ++i) xv[i] = xs[(GEO::BLK + 16 * (k * N - 2) + 16 * i + l15) & (GEO::XR - 1)];   // the raw signal at c3's columns
                     p0_layer_chunk<N, P2, 1>(in_plane, out_base, W, rd, wr, kbv, kivv, r1wv, xv, tstart, Tv, lane, dummy);
                 } else p0_layer_chunk<N, P3, 2>(in_plane, out_base, W, rd, wr, kbv, kivv, r1wv, xv, tstart, Tv, lane, dummy);
             }
