@@ -948,3 +948,74 @@ def test_long_near_constant_rows_under_instance_norm(dev, excitation):
     rng = float(ref.abs().max())
     err = float((y - ref).abs().max())
     assert np.isfinite(err) and err <= 3e-4 * max(1.0, rng), (excitation, err, rng)
+
+
+@pytest.mark.parametrize("storage", ["float32", "bfloat16"])
+def test_stage0_layer_pipeline_vs_oracle_phase_kernel_and_itself(dev, storage):
+    """Conditioning stage 0 as a LAYER PIPELINE (cond_stage0_pipe_kernel, csrc/fastsvc_cond.hip: a wave owns a layer, chunks
+    of an utterance stream through LDS rings; what long batches run) - forced through the launch table (algorithm 5 under
+    "cond.0|B|T") on a batch small enough for the oracle: ss.0 / down_hd.1 against the oracle's taps
+    (fastsvc.py:164-193,220-232; Squeeze2d upsample.py:53-74), full and ragged on a poisoned workspace; then at 8 x 600
+    frames BIT-IDENTICAL to the phase kernel (algorithm 4: same products in the same order) and to itself over repeated
+    runs (the float32-storage instance once returned run-to-run different tiles: a VALU -> MFMA C-operand hazard)."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 61)
+    wf = S.fold_weight_norm(sd)
+
+    def plan_for(B, F, algo):
+        pl = A.Plan(cfg, storage=storage, compact_workspace=True)
+        T = F * cfg.hop
+        pl.load_tuned({f"cond.0|{B}|{T}": [1, 1, 1, 1, algo], f"cond.0|{B}|{T}|b": [1, 1, 1, 1, algo]})
+        return pl
+
+    B, F = 3, 52
+    b = S.synth_batch(cfg, B, F, 62)
+    plan = plan_for(B, F, 5)
+    blob = plan.pack(sd).to(dev)
+    tol_t, tol_y = (TIGHT, TIGHT) if storage == "float32" else (4e-2, 0.25)
+    ref, taps = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb, return_taps=True)
+    ws = torch.full((plan.workspace_bytes(B, F),), 0xFF, dtype=torch.uint8, device=dev)
+    recs = []
+    y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), workspace=ws, profile=recs)
+    assert [r["kernel"] for r in recs if r["layer"] == "cond.0"][0].startswith("cond_stage0_pipe")
+    ss = plan.tap("ss.0", B, F, ws).float().cpu()
+    want = torch.cat([taps["scale.0"], taps["shift.0"]], dim=1)
+    assert float((ss - want).abs().max()) <= tol_t * max(1.0, float(want.abs().max()))
+    hd = plan.tap("down_hd.1", B, F, ws).float().cpu()
+    for sig, sl in (("lft", slice(0, B)), ("sine", slice(B, 2 * B))):
+        wh = taps[f"down_{sig}.0"][..., ::5]
+        assert float((hd[sl] - wh).abs().max()) <= tol_t * max(1.0, float(wh.abs().max())), sig
+    e = (y.cpu() - ref).abs()
+    assert float(e.max()) <= tol_y
+    lens = [52, 31, 4]
+    ppg, sine, lft = b.ppg.copy(), b.sine.copy(), b.lft.copy()
+    for i, n in enumerate(lens):
+        ppg[i, :, n:] = np.nan; sine[i, :, n * 160:] = np.nan; lft[i, :, n * 160:] = np.nan
+    ws.fill_(0xFF)
+    yr = plan.forward(blob, *_to(dev, ppg, sine, lft, b.spk_emb), lengths=lens, workspace=ws).cpu()
+    for i, n in enumerate(lens):
+        r1 = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg[i:i + 1, :, :n], b.sine[i:i + 1, :, :n * 160],
+                             b.lft[i:i + 1, :, :n * 160], b.spk_emb[i:i + 1])
+        assert float((yr[i:i + 1, :, :n * 160] - r1).abs().max()) <= tol_y, i
+        assert n == F or float(yr[i, :, n * 160:].abs().max()) == 0.0
+    # a batch long enough for many chunks per workgroup: pipeline == phase kernel == pipeline again, bit for bit
+    B2, F2 = 8, 600
+    ins = list(S.device_batch(cfg, B2, F2, 4321, dev))
+    pipe, phase = plan_for(B2, F2, 5), plan_for(B2, F2, 4)
+    wp = torch.full((pipe.workspace_bytes(B2, F2),), 0xFF, dtype=torch.uint8, device=dev)
+    wq = torch.full((phase.workspace_bytes(B2, F2),), 0xFF, dtype=torch.uint8, device=dev)
+    yq = phase.forward(blob, *ins, workspace=wq)
+    first = None
+    for _ in range(4):
+        wp.fill_(0xFF)
+        yp = pipe.forward(blob, *ins, workspace=wp)
+        torch.cuda.synchronize()
+        cur = [pipe.tap(t, B2, F2, wp).clone() for t in ("ss.0", "down_hd.1")] + [yp.clone()]
+        if first is None:
+            first = cur
+            for t, got in zip(("ss.0", "down_hd.1"), cur):
+                assert torch.equal(got, phase.tap(t, B2, F2, wq)), t
+            assert torch.equal(yp, yq)
+        else:
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(cur, first))
