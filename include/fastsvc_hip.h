@@ -261,6 +261,29 @@ int fastsvc_stft_loss_backward(const float* x, const float* y, int32_t B, int32_
                                const int32_t* hop_sizes, const int32_t* win_lengths, const float* const* windows,
                                const float* grad_loss, float* grad_x, void* scratch, void* stream);
 
+/* ---- the grouped strided convolutions of the recipe's discriminator, forward and backward ----
+ * Replaces, for the downsampling layers of MelGANDiscriminator (harana/models/fastsvc.py:386-520: Conv1d(c, min(4c, 512),
+ * kernel_size = 41, stride = 4, padding = 20, groups = c / 4) + LeakyReLU; yaml egs/svcc23/fastsvc1/conf/fastsvc.yaml:34-52), what
+ * the trainer's discriminator calls and their autograd run (harana/bin/train_fastsvc.py:172-175,207-224):
+ *   fastsvc_gconv1d_forward          y = lrelu_slope(bias + grouped_conv(x, w))        x (B, Cin, T), w (Cout, Cin / groups, K),
+ *                                    y (B, Cout, Tout), Tout = (T + 2 pad - K) / stride + 1; slope = 1: no activation
+ *   fastsvc_gconv1d_backward_data    dx = grouped_conv_transpose(dy * lrelu'(y_act), w)  (y_act = the forward's output, or NULL)
+ *   fastsvc_gconv1d_backward_weight  dw[o, i, k] = sum_{b, t} dy'[b, o, t] x[b, g(o) Ig + i, stride t + k - pad], dbias[o] = sum dy'
+ *                                    (dbias may be NULL); scratch: fastsvc_gconv1d_backward_weight_scratch_bytes(B, Cout, T)
+ *                                    device bytes (per-slab partial sums added in a fixed order: bit-reproducible)
+ * Device float32, contiguous.  Supported (fastsvc_gconv1d_supported != 0): Cin / groups = 4, Cout / groups in {8, 16}, K = 41,
+ * stride = 4, pad = 20; anything else FASTSVC_E_UNSUPPORTED (the caller keeps its own convolution).  Asynchronous on `stream`. */
+int fastsvc_gconv1d_supported(int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad);
+int fastsvc_gconv1d_forward(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin, int32_t Cout,
+                            int32_t groups, int32_t T, int32_t K, int32_t stride, int32_t pad, float slope, void* stream);
+int fastsvc_gconv1d_backward_data(const float* dy, const float* y_act, const float* w, float* dx, int32_t B, int32_t Cin,
+                                  int32_t Cout, int32_t groups, int32_t T, int32_t K, int32_t stride, int32_t pad, float slope,
+                                  void* stream);
+size_t fastsvc_gconv1d_backward_weight_scratch_bytes(int32_t B, int32_t Cout, int32_t T);
+int fastsvc_gconv1d_backward_weight(const float* x, const float* dy, const float* y_act, float* dw, float* dbias, void* scratch,
+                                    int32_t B, int32_t Cin, int32_t Cout, int32_t groups, int32_t T, int32_t K, int32_t stride,
+                                    int32_t pad, float slope, void* stream);
+
 /* ---- the convolutions of the generator's backward pass (float32 matrix-core kernels) ----
  * What autograd runs for every Conv1d / Conv2d(1 x k) of the generator when the reference trainer calls
  * gen_loss.backward() (harana/bin/train_fastsvc.py:183; the layers: harana/layers/residual_block.py:27-48,

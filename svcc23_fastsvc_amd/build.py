@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip.so")
 # the stamped diagnostic build (--timeline) is a separate file: loaded only when FASTSVC_HIP_LIB names it
 TIMELINE_LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip_timeline.so")
-SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_cond.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip", "fastsvc_loudness.hip", "fastsvc_stftloss.hip", "fastsvc_convgrad.hip", "fastsvc_filmnorm.hip"]
+SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_cond.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip", "fastsvc_loudness.hip", "fastsvc_stftloss.hip", "fastsvc_convgrad.hip", "fastsvc_filmnorm.hip", "fastsvc_gconv.hip"]
 HEADERS = [os.path.join(CSRC, "fastsvc_kernels.h"), os.path.join(ROOT, "include", "fastsvc_hip.h")]
 ARCH = "gfx950"
 
@@ -54,6 +54,7 @@ UNITS = [
     ("fastsvc_convgrad.hip", [], "convgrad.o"),
     ("fastsvc_filmnorm.hip", [], "filmnorm.o"),
     ("fastsvc_stage.hip", [], "stage.o"),
+    ("fastsvc_gconv.hip", [], "gconv.o"),
 ]
 
 

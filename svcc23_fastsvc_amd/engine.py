@@ -40,6 +40,8 @@ ABI_SYMBOLS = (
     "fastsvc_stft_loss_scratch_bytes", "fastsvc_stft_loss_forward", "fastsvc_stft_loss_backward",
     "fastsvc_conv1d_forward", "fastsvc_conv1d_backward_weight", "fastsvc_conv1d_backward_weight_scratch_bytes",
     "fastsvc_film_norm_forward", "fastsvc_film_norm_backward", "fastsvc_weight_norm_forward", "fastsvc_weight_norm_backward",
+    "fastsvc_gconv1d_supported", "fastsvc_gconv1d_forward", "fastsvc_gconv1d_backward_data",
+    "fastsvc_gconv1d_backward_weight_scratch_bytes", "fastsvc_gconv1d_backward_weight",
 )
 
 
@@ -119,6 +121,16 @@ def load_library():
     lib.fastsvc_conv1d_backward_weight_scratch_bytes.restype = sz
     lib.fastsvc_conv1d_backward_weight.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.fastsvc_conv1d_backward_weight.restype = ctypes.c_int
+    lib.fastsvc_gconv1d_supported.argtypes = [i32] * 6
+    lib.fastsvc_gconv1d_supported.restype = ctypes.c_int
+    lib.fastsvc_gconv1d_forward.argtypes = [vp, vp, vp, vp] + [i32] * 8 + [ctypes.c_float, vp]
+    lib.fastsvc_gconv1d_forward.restype = ctypes.c_int
+    lib.fastsvc_gconv1d_backward_data.argtypes = [vp, vp, vp, vp] + [i32] * 8 + [ctypes.c_float, vp]
+    lib.fastsvc_gconv1d_backward_data.restype = ctypes.c_int
+    lib.fastsvc_gconv1d_backward_weight_scratch_bytes.argtypes = [i32, i32, i32]
+    lib.fastsvc_gconv1d_backward_weight_scratch_bytes.restype = sz
+    lib.fastsvc_gconv1d_backward_weight.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 8 + [ctypes.c_float, vp]
+    lib.fastsvc_gconv1d_backward_weight.restype = ctypes.c_int
     lib.fastsvc_film_norm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, ctypes.c_float, ctypes.c_float, vp]
     lib.fastsvc_film_norm_forward.restype = ctypes.c_int
     lib.fastsvc_film_norm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, ctypes.c_float, vp]

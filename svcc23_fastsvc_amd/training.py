@@ -38,6 +38,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .gconv import ConvAct, GroupedConv1d
+
 RECIPE = {
     # egs/svcc23/fastsvc1/conf/fastsvc.yaml
     "stft_loss_params": dict(fft_sizes=[2048, 1024, 512, 256, 128, 64], hop_sizes=[512, 256, 128, 64, 32, 16],
@@ -112,8 +114,10 @@ def _melgan_scale(in_channels: int, out_channels: int, kernel_sizes: Sequence[in
     c = channels
     for s in downsample_scales:
         c_out = min(c * s, max_channels)
-        layers.append(nn.Sequential(nn.Conv1d(c, c_out, kernel_size=10 * s + 1, stride=s, padding=5 * s, groups=c // 4),
-                                    nn.LeakyReLU(slope)))
+        # (GroupedConv1d / ConvAct: nn.Conv1d + LeakyReLU under the reference's keys, one HIP launch forward and three backward
+        # on the GPU for the recipe's shape - k = 41, stride 4, four input channels per group; gconv.py)
+        layers.append(ConvAct(GroupedConv1d(c, c_out, kernel_size=10 * s + 1, stride=s, padding=5 * s, groups=c // 4),
+                              nn.LeakyReLU(slope)))
         c = c_out
     c_out = min(c * 2, max_channels)
     layers.append(nn.Sequential(nn.Conv1d(c, c_out, k0, padding=(k0 - 1) // 2), nn.LeakyReLU(slope)))
