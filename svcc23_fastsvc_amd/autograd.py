@@ -151,9 +151,12 @@ class GeneratorFunction(torch.autograd.Function):
         emb = saved[3] if ctx.has_emb else None
         params = saved[4:] if ctx.has_emb else saved[3:]
         needs = ctx.needs_input_grad            # (module, names, x, s, l, spk_emb, *params)
-        # bfloat16 activation storage (BASELINE config 5's dtype): the restatement runs under bf16 autocast - bf16
-        # convolutions / linears with float32 accumulation, float32 InstanceNorm - i.e. the precision the forward computed
-        # in; gradients come back in the float32 of the master parameters
+        # bfloat16 activation storage: the FORWARD ran with bfloat16 tensors and bf16 MFMA products; the backward is a FLOAT32
+        # recompute of the same dataflow - the HIP convolution / FiLM-norm nodes take and return float32 (conv_grad.py casts),
+        # only the remaining F.linear / elementwise ops see the bf16 autocast below - so gradients are taken at a float32
+        # re-evaluation of a forward that was rounded to bfloat16: the mismatch is the forward's own bf16 error (1e-2 of the
+        # output's rms, test_workloads_gpu.py) carried into the loss gradient; tests/test_training.py holds the bfloat16 step to
+        # the float32 step within that.  Gradients come back in the float32 of the master parameters.
         amp = (torch.autocast(device_type="cuda", dtype=torch.bfloat16)
                if getattr(ctx.module, "activation_storage", "float32") == "bfloat16" and x.is_cuda else contextlib.nullcontext())
         with torch.enable_grad(), amp:

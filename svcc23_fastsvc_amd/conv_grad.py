@@ -16,6 +16,7 @@ import ctypes
 from typing import Optional
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from .engine import FastSVCError, load_library
 
@@ -64,6 +65,7 @@ class _Conv1dFn(torch.autograd.Function):
         return _launch_forward(x, w, b, w.shape[0], dilation, False)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.to(torch.float32).contiguous()
@@ -86,6 +88,13 @@ class _Conv1dFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def conv1d_supported(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) -> bool:
+    """What csrc/fastsvc_convgrad.hip takes: k = 1 or 3, halo (k // 2) * dilation <= 27, every tensor below 2 GiB."""
+    k = int(weight.shape[-1])
+    big = max(x.numel(), x.shape[0] * weight.shape[0] * x.shape[2]) * 4 >= (1 << 31)
+    return k in (1, 3) and (k // 2) * int(dilation) <= 27 and not big
+
+
 def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1) -> torch.Tensor:
     """``F.conv1d(x, weight, bias, padding=(k // 2) * dilation, dilation=dilation)`` for k = 1 or 3, differentiable with
     respect to x, weight and bias through the HIP kernels."""
@@ -93,6 +102,11 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         raise FastSVCError("conv1d (HIP) needs GPU tensors; there is no CPU fallback")
     if x.dim() != 3 or weight.dim() != 3 or weight.shape[1] != x.shape[1]:
         raise ValueError(f"conv1d: x {tuple(x.shape)} / weight {tuple(weight.shape)} do not fit")
+    if not conv1d_supported(x, weight, dilation):
+        # shapes the kernels decline (FASTSVC_E_UNSUPPORTED: other tap counts, halos past 27, tensors of 2 GiB and more): the
+        # stock operator on the same GPU tensors - still no CPU route
+        import torch.nn.functional as F
+        return F.conv1d(x, weight, bias, padding=(weight.shape[-1] // 2) * int(dilation), dilation=int(dilation))
     return _Conv1dFn.apply(x, weight, bias, int(dilation))
 
 
@@ -117,6 +131,7 @@ class _FilmNormFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         x, scale, shift, bias, mean, rstd = ctx.saved_tensors
         dout = dout.to(torch.float32).contiguous()
@@ -179,6 +194,7 @@ class _WeightNormFn(torch.autograd.Function):
         return tuple(ws)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, *dws):
         n, rows, cols = ctx.n, ctx.rows, ctx.cols
         saved = ctx.saved_tensors

@@ -1733,7 +1733,13 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
     static const int dbg_env = std::getenv("FASTSVC_COND_DBG") ? std::atoi(std::getenv("FASTSVC_COND_DBG")) : 0;
     q.tpw |= dbg_env << 16;
     static unsigned long long* trace_buf = nullptr;
+#ifdef FASTSVC_COND_TRACE
     static const bool trace_env = std::getenv("FASTSVC_COND_TRACE") != nullptr;
+#else
+    // (only a library whose kernels were built with -DFASTSVC_COND_TRACE writes stamps through amax_hd: in the product build the
+    // kernel's atomicMax into that 4 KB buffer would run out of bounds for B >= 3)
+    static const bool trace_env = false;
+#endif
     if (trace_env && prof) {
         if (!trace_buf) (void)hipMalloc(&trace_buf, 8 * 64 * 8);
         (void)hipMemsetAsync(trace_buf, 0, 8 * 64 * 8, stream);

@@ -14,6 +14,8 @@ from typing import Sequence, Tuple
 import torch
 from torch import nn
 
+from torch.autograd.function import once_differentiable
+
 from .engine import FastSVCError, load_library
 
 
@@ -53,6 +55,7 @@ class _STFTLossFn(torch.autograd.Function):
         return loss[0], loss[1]
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_sc, g_mag):
         x, y = ctx.saved_tensors
         res, scratch = ctx.res, ctx.scratch
