@@ -1613,14 +1613,382 @@ static hipError_t cond_stage1_instance(const CondStage1Params& p, hipStream_t st
     return hipGetLastError();
 }
 
+#ifdef FASTSVC_ACT_BF16
+// =====================================================================================================================
+// Stage 1 (C = 48, C_in = 24) as a LAYER PIPELINE - bfloat16 storage only (the float32 instance's hi + lo planes do not fit
+// three-chunk rings).  Same scheme as cond_stage0_pipe_kernel; what differs:
+//   * 12 waves: 0-1 stage-in of a signal's compact input (raw -> a 6-chunk ring for the 1x1 residual conv, LeakyReLU'd -> the
+//     3-chunk ring c1 reads; loads requested two steps ahead) AND its c1; 2-3 c2; 4-5 c3 (starts from the 1x1 residual conv of
+//     the raw tile: the phase kernel's order of summation); 6-7 film.conv; 8-10 two 16-channel tiles of the heads each; 11 copy-out.
+//   * a layer wave holds ALL THREE 16-channel output tiles of its layer (18-21 weight fragments resident - the phase kernel
+//     streams 31 per wave and tile from L2) and feeds them from ONE activation fragment: a third of the fragment reads.
+//   * the 48-channel tensors c1 / c2 / h live in planes of 96-BYTE rows (64-byte rows pad 48 channels to 64: 19 planes would
+//     not fit): bank = (24 row + 4 slot) mod 64 is conflict-free for ds_read_b128 at any row offset without a swizzle; the
+//     second K chunk of a row reads 32 bytes into the next row - finite values under zero weight rows.
+//   * chunks of 32 columns (N = 2); the heads' stream lags 5 tiles = 5 chunks incl. alignment behind the stage-in.
+constexpr int Q1_NWAVES = 12, Q1_NTHREADS = Q1_NWAVES * 64;
+struct Q1Geom {
+    static constexpr int N = 2, NT = 32, RING = 96, GUARD = 8, PROWS = RING + 2 * GUARD;
+    static constexpr int P64 = PROWS * 64, P96 = PROWS * 96;
+    static constexpr int XRT = 12;                         // tiles of the raw-input ring (the 1x1 conv reads 3 steps + 3 tiles behind)
+    static constexpr int XRAW = XRT * 16 * 64;
+    static constexpr int SP = NT * 2 + 16;                 // staging pitch
+    static constexpr int STG = 2 * C1_C * SP;
+    static constexpr int LAG = 5;                          // chunks of the heads' stream in front of the first output column
+    static constexpr int TAB = 128;
+    static constexpr int CONST_FLOATS = TAB + 3 * TAB + 128;
+    // planes in this order: xact[2] (P64), u[3] (P64), xraw[2], c1[2] c2[2] h[2] (P96), 64 bytes of zeros, staging x 2, dummy
+    static constexpr int O_XACT = 0, O_U = O_XACT + 2 * P64, O_XRAW = O_U + 3 * P64, O_C1 = O_XRAW + 2 * XRAW, O_C2 = O_C1 + 2 * P96,
+                         O_H = O_C2 + 2 * P96, O_STG = O_H + 2 * P96 + 64, O_DUMMY = O_STG + 2 * STG, O_END = O_DUMMY + 64 * 32;
+    static constexpr size_t LDS = CONST_FLOATS * 4 + (size_t)O_END;
+};
+
+// one chunk (2 tiles) of a stage-1 layer: all three 16-channel output tiles per activation fragment, swapped operands
+//   KIND 0: lrelu -> a 96-byte-row plane (c1, c2);  1: c3 = raw, accumulator starts from the 1x1 residual conv of the raw input tile;
+//        2: lrelu -> the 96-channel planes [lft ; sine] of the heads (64-byte rows, swizzled)
+//   NC: K chunks of the input; IN96: input plane has 96-byte rows (else one swizzled 64-byte-row plane)
+template <int POS, int NC, bool IN96, int KIND>
+__device__ __forceinline__ void q1_layer_chunk(const unsigned char* in_plane, unsigned char* out_base, const CsW* W /* [NC][3][3] */,
+                                               const CsW* W1 /* [3], KIND 1 */, const unsigned char* xraw_tile0, const unsigned char* xraw_tile1,
+                                               const int (&rd)[3], const int (&wr)[3], const f32x4 (&kbv)[3], int tstart, int Tv, int lane,
+                                               unsigned char* dummy) {
+    using GEO = Q1Geom;
+    constexpr int N = GEO::N, NTL3 = 3 * N;
+    constexpr int TS_IN = 16 * (IN96 ? 96 : 64), TS_OUT = 16 * (KIND == 2 ? 64 : 96), GOFF = GEO::RING * (KIND == 2 ? 64 : 96);
+    const int l15 = lane & 15, g = lane >> 4;
+    f32x4 acc[N][3];
+    #pragma unroll
+    for (int i = 0; i < N; ++i)
+        #pragma unroll
+        for (int m = 0; m < 3; ++m) acc[i][m] = kbv[m];
+    if constexpr (KIND == 1) {
+        #pragma unroll
+        for (int i = 0; i < N; ++i) {
+            CsFrag xr;
+            xr.p[0] = *reinterpret_cast<const cs8*>((i ? xraw_tile1 : xraw_tile0) + cs_off(l15, g));
+            #pragma unroll
+            for (int m = 0; m < 3; ++m) acc[i][m] = cs_prod<true>(W1[m], xr, acc[i][m]);
+        }
+    }
+    #pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+        CsFrag a[N][3];
+        #pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int PIN = (POS * N + i - 1 + NTL3) % NTL3;
+            #pragma unroll
+            for (int tap = 0; tap < 3; ++tap) a[i][tap].p[0] = *reinterpret_cast<const cs8*>(in_plane + rd[tap] + ch * 64 + PIN * TS_IN);
+        }
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            #pragma unroll
+            for (int i = 0; i < N; ++i)
+                #pragma unroll
+                for (int m = 0; m < 3; ++m) acc[i][m] = cs_prod<true>(W[(ch * 3 + tap) * 3 + m], a[i][tap], acc[i][m]);
+    }
+    #pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int P = POS * N + i;
+        const int tt = tstart + 16 * i;
+        const bool edge = tt < 0 || tt + 16 > Tv;
+        unsigned keep = 0xffffffffu;
+        if (edge) keep = (unsigned)(tt + l15) < (unsigned)Tv ? 0xffffffffu : 0u;
+        #pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            f32x4 v = acc[i][m];
+            if constexpr (KIND != 1) v = cs_lrelu4(v);
+            unsigned char* dst = out_base + wr[m] + P * TS_OUT;
+            const CsPk4 pk = cs_pack4(v, keep);
+            cs_put4(dst, dst, pk);
+            if (P == 0) { unsigned char* g2 = l15 < 8 ? dst + GOFF : dummy; cs_put4(g2, g2, pk); }
+            if (P == NTL3 - 1) { unsigned char* g2 = l15 >= 8 ? dst - GOFF : dummy; cs_put4(g2, g2, pk); }
+        }
+    }
+}
+
+__global__ __launch_bounds__(Q1_NTHREADS, 1)
+void cond_stage1_pipe_kernel(const CondStage1Params p) {
+    using GEO = Q1Geom;
+    constexpr int N = GEO::N, NT = GEO::NT, RING = GEO::RING, GUARD = GEO::GUARD, LAG = GEO::LAG, TAB = GEO::TAB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* k1b = reinterpret_cast<float*>(smem);           // [signal][64] c1 bias
+    float* klb = k1b + TAB;                                // [3][signal][64]: c2, c3 (+ the 1x1 conv's bias), film.conv
+    float* k5b = klb + 3 * TAB;                            // [128] heads
+    unsigned char* L = smem + GEO::CONST_FLOATS * 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z;
+    const int Tv = p.lens ? p.lens[b] * p.len_mul : p.T;
+    const int Kc = p.tpw & 0xffff;
+    const int T0 = blockIdx.x * Kc * NT;
+    if (T0 >= Tv) return;
+    const int nch = min(Kc, (Tv - T0 + NT - 1) / NT);
+    const int T1 = min(T0 + nch * NT, Tv);
+    const int Ktot = nch + LAG;
+    const int nsteps = Ktot + 6;
+    const int torg = T0 - 16 * LAG;                        // time of the stage-in's first column (tile Q)
+    for (int i = tid; i < TAB; i += Q1_NTHREADS) {
+        const int s = i >> 6, c = i & 63;
+        const bool ok = c < C1_C;
+        k1b[i] = ok ? p.b1[s][c] : 0.f;
+        klb[0 * TAB + i] = ok ? p.bias[0][s][c] : 0.f;
+        klb[1 * TAB + i] = ok ? p.br[s][c] + p.bias[1][s][c] : 0.f;
+        klb[2 * TAB + i] = ok ? p.bias[2][s][c] : 0.f;
+        k5b[i] = i < 2 * C1_C ? p.b5[i] : 0.f;
+    }
+    for (int o = tid * 16; o < GEO::O_END; o += Q1_NTHREADS * 16) *reinterpret_cast<u32x4*>(L + o) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    const int l15 = lane & 15, g = lane >> 4;
+    unsigned char* dummy = L + GEO::O_DUMMY + lane * 32;
+
+    if (wave < 2) {
+        // ================= stage-in of this signal's input + c1 = lrelu(conv3(lrelu(x)) + b1) =================
+        const int sig = wave;
+        const __amdgpu_buffer_rsrc_t xr = act_rsrc(reinterpret_cast<const float*>(p.x), sig * p.x_sig + (long)b * p.x_b, (long)C1_CIN * p.ldx);
+        const bool has_item = lane < 24;
+        const int it_q = lane / 3, it_o = lane - it_q * 3;     // rows 4 q .. 4 q + 3 of the chunk, octet o
+        unsigned char* xact = L + GEO::O_XACT + sig * GEO::P64;
+        unsigned char* xraw = L + GEO::O_XRAW + sig * GEO::XRAW;
+        cs_u2 px[3][8];                                        // three chunks in flight: requested two steps before their commit
+        auto request = [&](cs_u2 (&set)[8], int k0) {
+            const int t = torg + k0 * NT + 4 * it_q;
+            const bool tok = has_item && (unsigned)t < (unsigned)Tv && k0 < Ktot;
+            #pragma unroll
+            for (int c = 0; c < 8; ++c)
+                set[c] = __builtin_amdgcn_raw_buffer_load_b64(xr, tok ? ((it_o * 8 + c) * p.ldx + t) * 2 : OOB_OFF, 0, 0);
+        };
+        CsW W[9];
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            #pragma unroll
+            for (int m = 0; m < 3; ++m)
+                W[tap * 3 + m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w1[sig]) + (long)(tap * 3 + m) * CS_FRAG, lane);
+        int rd[3], wr[3];
+        f32x4 kbv[3];
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap) rd[tap] = cs_off(GUARD + (tap - 1) + l15, g);
+        #pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            wr[m] = (GUARD + l15) * 96 + (16 * m + 4 * g) * 2;
+            kbv[m] = *reinterpret_cast<const f32x4*>(k1b + sig * 64 + 16 * m + 4 * g);
+        }
+        request(px[0], 0);
+        request(px[1], 1);
+        int xrt = 0;                                           // tile of the raw ring the next chunk goes to
+        p0_steps(nsteps, [&](auto jc, int s) {
+            constexpr int J = decltype(jc)::value;
+            if (s < Ktot) {
+                // ---- stage-in of chunk s: raw -> the 12-tile ring, LeakyReLU'd -> position J of the 3-chunk ring ----
+                request(px[(J + 2) % 3], s + 2);
+                if (has_item) {
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned short e[8];
+                        #pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const unsigned w = j < 2 ? px[J][c].x : px[J][c].y;
+                            e[c] = (unsigned short)((j & 1) ? (w >> 16) : (w & 0xffffu));
+                        }
+                        const u32x4 raw = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                                           (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+                        f32x4 lo4, hi4;
+                        #pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            lo4[c] = __builtin_bit_cast(float, (unsigned)e[c] << 16);
+                            hi4[c] = __builtin_bit_cast(float, (unsigned)e[4 + c] << 16);
+                        }
+                        const CsPk8 act = cs_pack8(cs_lrelu4(lo4), cs_lrelu4(hi4), 0xffffffffu);
+                        const int rr = 4 * it_q + j;
+                        *reinterpret_cast<u32x4*>(xraw + cs_off(xrt * 16 + rr, it_o)) = raw;
+                        unsigned char* dst = xact + cs_off(GUARD + J * NT + rr, it_o);
+                        cs_put8(dst, dst, act);
+                        if (J == 0) { unsigned char* g2 = rr < 8 ? dst + RING * 64 : dummy; cs_put8(g2, g2, act); }
+                        if (J == 2) { unsigned char* g2 = rr >= NT - 8 ? dst - RING * 64 : dummy; cs_put8(g2, g2, act); }
+                    }
+                }
+                xrt = xrt + N >= GEO::XRT ? 0 : xrt + N;
+            }
+            const int k = s - 1;
+            if (k >= 0 && k < Ktot)
+                q1_layer_chunk<(J + 2) % 3, 1, false, 0>(xact, L + GEO::O_C1 + sig * GEO::P96, W, nullptr, nullptr, nullptr, rd, wr, kbv,
+                                                         torg + 16 * (k * N - 1), Tv, lane, dummy);
+        });
+    } else if (wave < 8) {
+        // ================= c2 / c3 / film.conv of one signal =================
+        const int Lr = 2 + ((wave - 2) >> 1), sig = wave & 1;   // layer 2 c2, 3 c3, 4 film.conv
+        const int li = Lr - 2;
+        CsW W[18], W1[3];
+        #pragma unroll
+        for (int q = 0; q < 6; ++q)
+            #pragma unroll
+            for (int m = 0; m < 3; ++m)
+                W[q * 3 + m] = cs_wload(reinterpret_cast<const unsigned char*>(p.w[li][sig]) + (long)(q * 3 + m) * CS_FRAG, lane);
+        #pragma unroll
+        for (int m = 0; m < 3; ++m)
+            W1[m] = Lr == 3 ? cs_wload(reinterpret_cast<const unsigned char*>(p.w1[sig]) + (long)(3 * 3 + m) * CS_FRAG, lane) : W[m];
+        const int dil = Lr == 2 ? 2 : Lr == 3 ? 4 : 1;
+        int rd[3], wr[3];
+        f32x4 kbv[3];
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap) rd[tap] = (GUARD + (tap - 1) * dil + l15) * 96 + g * 16;
+        #pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int co0 = 16 * m + 4 * g;
+            kbv[m] = *reinterpret_cast<const f32x4*>(klb + li * TAB + sig * 64 + co0);
+            if (Lr == 4) {
+                const int cc0 = sig * C1_C + co0;
+                wr[m] = (cc0 >> 5) * GEO::P64 + cs_off(GUARD + l15, (cc0 & 31) >> 3) + (cc0 & 7) * 2;
+            } else wr[m] = (GUARD + l15) * 96 + co0 * 2;
+        }
+        const unsigned char* in_plane = L + (Lr == 2 ? GEO::O_C1 : Lr == 3 ? GEO::O_C2 : GEO::O_H) + sig * GEO::P96;
+        unsigned char* out_base = L + (Lr == 2 ? GEO::O_C2 + sig * GEO::P96 : Lr == 3 ? GEO::O_H + sig * GEO::P96 : GEO::O_U);
+        const unsigned char* xraw = L + GEO::O_XRAW + sig * GEO::XRAW;
+        int xrt = GEO::XRT - 3;                                // c3's chunk 0 starts 3 tiles in front of the raw ring's tile 0
+        p0_steps(nsteps, [&](auto jc, int s) {
+            constexpr int J = decltype(jc)::value;
+            const int k = s - Lr;
+            if (k >= 0 && k < Ktot) {
+                const int tstart = torg + 16 * (k * N - Lr);
+                if (Lr == 2) q1_layer_chunk<(J + 1) % 3, 2, true, 0>(in_plane, out_base, W, W1, nullptr, nullptr, rd, wr, kbv, tstart, Tv, lane, dummy);
+                else if (Lr == 3) {
+                    const int t1 = xrt + 1 >= GEO::XRT ? 0 : xrt + 1;
+                    q1_layer_chunk<J, 2, true, 1>(in_plane, out_base, W, W1, xraw + xrt * 1024, xraw + t1 * 1024, rd, wr, kbv, tstart, Tv, lane, dummy);
+                    xrt = t1 + 1 >= GEO::XRT ? 0 : t1 + 1;
+                } else q1_layer_chunk<(J + 2) % 3, 2, true, 2>(in_plane, out_base, W, W1, nullptr, nullptr, rd, wr, kbv, tstart, Tv, lane, dummy);
+            }
+        });
+    } else if (wave < 11) {
+        // ================= heads: two of the six 16-channel output tiles per wave, both from one fragment =================
+        const int hw = wave - 8;
+        CsW W5[2][9];
+        #pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+            const int tile = 2 * hw + mm, gq = tile / 3, m5t = tile - gq * 3;
+            #pragma unroll
+            for (int q = 0; q < 9; ++q)
+                W5[mm][q] = cs_wload(reinterpret_cast<const unsigned char*>(p.w5) + (long)(gq * 27 + q * 3 + m5t) * CS_FRAG, lane);
+        }
+        int rd[3];
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap) rd[tap] = cs_off(GUARD + (tap - 1) + l15, g);
+        const float bias0 = k5b[(2 * hw) * 16 + l15], bias1 = k5b[(2 * hw + 1) * 16 + l15];
+        const unsigned char* upl = L + GEO::O_U;
+        const int srow = ((2 * hw) * 16 + l15) * GEO::SP + 4 * g * 2;
+        p0_steps(nsteps, [&](auto jc, int s) {
+            constexpr int J = decltype(jc)::value;
+            const int k = s - 5;
+            if (k >= LAG && k < Ktot) {
+                constexpr int POS = (J + 1) % 3;               // (J - 5) mod 3
+                unsigned char* sb = L + GEO::O_STG + (s & 1) * GEO::STG + srow;
+                f32x4 acc[N][2];
+                #pragma unroll
+                for (int i = 0; i < N; ++i) { acc[i][0] = f32x4{bias0, bias0, bias0, bias0}; acc[i][1] = f32x4{bias1, bias1, bias1, bias1}; }
+                #pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    CsFrag a[N][3];
+                    #pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const int PIN = (POS * N + i - 1 + 3 * N) % (3 * N);
+                        #pragma unroll
+                        for (int tap = 0; tap < 3; ++tap) a[i][tap].p[0] = *reinterpret_cast<const cs8*>(upl + ch * GEO::P64 + rd[tap] + PIN * 1024);
+                    }
+                    #pragma unroll
+                    for (int tap = 0; tap < 3; ++tap)
+                        #pragma unroll
+                        for (int i = 0; i < N; ++i)
+                            #pragma unroll
+                            for (int mm = 0; mm < 2; ++mm) acc[i][mm] = cs_prod<false>(W5[mm][ch * 3 + tap], a[i][tap], acc[i][mm]);
+                }
+                #pragma unroll
+                for (int i = 0; i < N; ++i)
+                    #pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+                        *reinterpret_cast<cs_u2*>(sb + mm * 16 * GEO::SP + i * 32) = __builtin_bit_cast(cs_u2, __builtin_convertvector(acc[i][mm], cs4));
+            }
+        });
+    } else {
+        // ================= copy-out: staged [scale ; shift] rows -> ss, h[::s'] -> hd =================
+        const __amdgpu_buffer_rsrc_t ssr = act_rsrc(reinterpret_cast<const float*>(p.ss), (long)b * p.ss_b, (long)2 * C1_C * p.ld);
+        const int hds = p.hd ? p.hd_s : 1;
+        const int hdTv = (int)udiv_small((unsigned)Tv, hds);
+        const __amdgpu_buffer_rsrc_t hdr = act_rsrc(reinterpret_cast<const float*>(p.hd ? p.hd : p.ss), p.hd ? (long)b * p.hd_b : 0,
+                                                    p.hd ? p.hd_sig + (long)C1_C * p.hd_ld : 0);
+        const int ck = lane & 3, cr = lane >> 2;               // 4 pieces of 16 bytes per staged row, 16 rows per pass
+        const int jj = lane & 7, q = lane >> 3;                // hd: lane = (decimated column, 12 channels of one signal)
+        const int hs = q >> 2, hc0 = (q & 3) * 12;
+        p0_steps(nsteps, [&](auto jc, int s) {
+            constexpr int J = decltype(jc)::value;
+            {
+                const int kk = s - 6 - LAG;
+                if (kk >= 0 && kk < nch) {
+                    const unsigned char* sb = L + GEO::O_STG + ((s - 1) & 1) * GEO::STG + cr * GEO::SP + ck * 16;
+                    const int t = T0 + kk * NT + ck * 8;
+                    const int o = t < Tv ? (cr * p.ld + t) * 2 : OOB_OFF;
+                    #pragma unroll
+                    for (int i = 0; i < 2 * C1_C / 16; ++i) {
+                        const u32x4 w = *reinterpret_cast<const u32x4*>(sb + i * 16 * GEO::SP);
+                        __builtin_amdgcn_raw_buffer_store_b128(w, ssr, o, i * 16 * p.ld * 2, 0);
+                    }
+                }
+            }
+            {
+                const int k3 = s - 4;                           // the h chunk c3 finished in the step before
+                if (p.hd && k3 >= 0 && k3 < Ktot) {
+                    constexpr int POS = (J + 2) % 3;           // (J - 4) mod 3
+                    const int th0 = torg + 16 * (k3 * N - 3);
+                    const int ta = max(th0, T0), tb = min(th0 + NT, T1);
+                    const int j_lo = (int)udiv_small((unsigned)(ta + hds - 1), hds);
+                    const int j_hi = min((int)udiv_small((unsigned)(max(tb, ta) + hds - 1), hds), hdTv);
+                    const int hrow0 = (int)(hs * p.hd_sig) + hc0 * p.hd_ld;
+                    for (int j = j_lo + jj; j < j_hi; j += 8) {
+                        const int row = GUARD + POS * NT + (j * hds - th0);
+                        const unsigned char* src = L + GEO::O_H + hs * GEO::P96 + row * 96 + hc0 * 2;
+                        cs_u2 hv[3];
+                        #pragma unroll
+                        for (int e = 0; e < 3; ++e) hv[e] = *reinterpret_cast<const cs_u2*>(src + 8 * e);
+                        #pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const unsigned w = u < 2 ? hv[e].x : hv[e].y;
+                                const unsigned short v = (unsigned short)((u & 1) ? (w >> 16) : (w & 0xffffu));
+                                __builtin_amdgcn_raw_buffer_store_b16(v, hdr, (hrow0 + j) * 2, (4 * e + u) * p.hd_ld * 2, 0);
+                            }
+                    }
+                }
+            }
+        });
+    }
+}
+
+static hipError_t cond_stage1_pipe_instance(const CondStage1Params& p, hipStream_t stream) {
+    using GEO = Q1Geom;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_stage1_pipe_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS);
+    if (attr != hipSuccess) return attr;
+    if (p.hd && (p.hd_sig + (long)C1_C * p.hd_ld) * 2L >= (1L << 31)) return hipErrorInvalidValue;
+    if (((long)C1_CIN * p.ldx) * 2L >= (1L << 31)) return hipErrorInvalidValue;
+    const int nchunks = (p.T + GEO::NT - 1) / GEO::NT;
+    const int kc = p.tpw & 0xffff;
+    dim3 grid((nchunks + kc - 1) / kc, 1, p.B);
+    hipLaunchKernelGGL(cond_stage1_pipe_kernel, grid, dim3(Q1_NTHREADS), GEO::LDS, stream, p);
+    return hipGetLastError();
+}
+#endif
+
 hipError_t launch_cond_stage1(const CondStage1Params& p, hipStream_t stream) {
     if (p.C != C1_C || p.Cin != C1_CIN || (p.T % 8) != 0 || (p.ld % 8) != 0 || (p.ldx % 4) != 0 || (p.tpw & 0xffff) < 1 ||
         (p.hd && p.hd_s < 2)) return hipErrorInvalidValue;
+#ifdef FASTSVC_ACT_BF16
+    if (p.small == 2) return cond_stage1_pipe_instance(p, stream);
+#else
+    if (p.small == 2) return hipErrorInvalidValue;         // (bfloat16 storage only: Q1Geom)
+#endif
     return p.small ? cond_stage1_instance<4>(p, stream) : cond_stage1_instance<8>(p, stream);
 }
 
 #ifndef FASTSVC_ACT_BF16
-int cond_stage1_tile_columns(int small) { return small ? C1Geom<4>::NT : C1Geom<8>::NT; }
+int cond_stage1_tile_columns(int small) { return small == 2 ? 32 : small ? C1Geom<4>::NT : C1Geom<8>::NT; }
 #endif
 
 #ifdef FASTSVC_ACT_BF16

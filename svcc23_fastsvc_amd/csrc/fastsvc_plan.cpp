@@ -1816,9 +1816,34 @@ hipError_t run_cond_stage1(const fastsvc_plan& P, const float* blob, const float
         const int NTb = cond_stage1_tile_columns(0);
         q.small = small_env >= 0 ? small_env : (((T1 + NTb - 1) / NTb) * B < slots_all ? 1 : 0);
     }
-    const int NT = cond_stage1_tile_columns(q.small);
-    const long ntx = (T1 + NT - 1) / NT;
-    if (tpw_env > 0) q.tpw = tpw_env;
+    // the layer pipeline (cond_stage1_pipe_kernel, bfloat16 storage only; q.small = 2, tpw = 32-column chunks per workgroup):
+    // its fill is 11 steps, so only for long runs; "cond.1|B|T1|b" in the launch table forces either (algorithm 4 / 5)
+    static const int pipe_env = std::getenv("FASTSVC_COND_PIPE") ? std::atoi(std::getenv("FASTSVC_COND_PIPE")) : 1;
+    int pipe_mode = P.storage == 1 ? pipe_env : 0;
+    if (P.storage == 1) {
+        char key[96];
+        std::snprintf(key, sizeof(key), "cond.1|%d|%ld|b", B, (long)T1);
+        std::lock_guard<std::mutex> lock(P.tune_mu);
+        auto it = P.tuned.find(key);
+        if (it != P.tuned.end() && it->second.algo == 4) pipe_mode = 0;
+        if (it != P.tuned.end() && it->second.algo == 5) pipe_mode = 2;
+    }
+    if (pipe_mode && small_env < 0) {
+        const int NTp = cond_stage1_tile_columns(2);
+        const long nchunks = (T1 + NTp - 1) / NTp;
+        long kc = 0;
+        for (int r = 2; r >= 1 && !kc; --r) {
+            const long per_utt = std::max<long>(1, (256L * r) / B);
+            const long k = (nchunks + per_utt - 1) / per_utt;
+            if (k >= (r == 2 ? 80 : 16) || (pipe_mode == 2 && r == 1)) kc = k;     // (8 x 600 frames, 19 chunks each: 58 vs 94 us)
+        }
+        const bool fits = ((long)B * q.hd_b + (long)d.C * q.hd_ld) * 2L < (1L << 31) && (long)d.Cin * T1 * 2L < (1L << 31);
+        if (kc && fits) { q.small = 2; q.tpw = (int)std::min<long>(tpw_env > 0 ? tpw_env : kc, 0xffff); }
+    }
+    const int NT = q.small == 2 ? 0 : cond_stage1_tile_columns(q.small);
+    const long ntx = q.small == 2 ? 0 : (T1 + NT - 1) / NT;
+    if (q.small == 2) {}
+    else if (tpw_env > 0) q.tpw = tpw_env;
     else {
         const long slots = P.storage == 1 ? 512 : 256, total = ntx * B;
         const long rounds = std::max<long>(1, (total + slots * 32 - 1) / (slots * 32));
@@ -1834,7 +1859,7 @@ hipError_t run_cond_stage1(const fastsvc_plan& P, const float* blob, const float
         const double ae = P.storage == 1 ? 2.0 : 4.0;
         const double bytes = (2.0 * Ci * ae + 2.0 * C * ae + 2.0 * C * ae / d2.scale) * cols +
                              4.0 * (double)(2 * (d.rc1[0].w_floats + d.c2[0].w_floats + d.c3[0].w_floats + d.film[0].w_floats) + d.heads.w_floats);
-        hipError_t e = prof->begin(stream, "cond.1", P.storage == 1 ? "cond_stage1<x1>" : "cond_stage1<x3>", flops, bytes);
+        hipError_t e = prof->begin(stream, "cond.1", q.small == 2 ? "cond_stage1_pipe<x1>" : P.storage == 1 ? "cond_stage1<x1>" : "cond_stage1<x3>", flops, bytes);
         if (e != hipSuccess) return e;
         e = launch();
         if (e != hipSuccess) return e;

@@ -19,7 +19,8 @@ if os.environ.get("SMALL_ONLY"):
 def plan_for(storage, B, F, algo):
     pl = A.Plan(cfg, storage=storage, compact_workspace=True)
     T = F * cfg.hop
-    pl.load_tuned({f"cond.0|{B}|{T}": [1, 1, 1, 1, algo], f"cond.0|{B}|{T}|b": [1, 1, 1, 1, algo]})
+    pl.load_tuned({f"cond.0|{B}|{T}": [1, 1, 1, 1, algo], f"cond.0|{B}|{T}|b": [1, 1, 1, 1, algo],
+                   f"cond.1|{B}|{T // 5}|b": [1, 1, 1, 1, algo]})
     return pl
 
 
@@ -46,10 +47,10 @@ for storage in storages:
             yq = phase.forward(blob, *ins, workspace=wq, lengths=lengths)
             torch.cuda.synchronize()
             out = []
-            for tap in ("ss.0", "down_hd.1"):
+            for tap in ("ss.0", "down_hd.1", "ss.1", "down_hd.2"):
                 a, b = pipe.tap(tap, B, F, wp).float(), phase.tap(tap, B, F, wq).float()
                 if lengths is not None:
-                    dec = 1 if tap == "ss.0" else 5
+                    dec = {"ss.0": 1, "down_hd.1": 5, "ss.1": 5, "down_hd.2": 20}[tap]
                     for i, n in enumerate(lengths):          # only the valid columns of every utterance are defined
                         nv = n * cfg.hop // dec
                         for half in range(a.shape[0] // B):
@@ -65,9 +66,10 @@ for storage in storages:
             print(f"{storage} B={B} F={F} lengths={lengths}: " + "  ".join(out) +
                   f"  y max|d| {float(dy.max()):.3e} mean|d| {float(dy.mean()):.2e} finite {bool(torch.isfinite(yp).all())}", flush=True)
         tp, tq = prof(pipe, blob, ins, wp), prof(phase, blob, ins, wq)
-        kp = [(k, v) for k, v in tp.items() if k[0] == "cond.0"][0]
-        kq = [(k, v) for k, v in tq.items() if k[0] == "cond.0"][0]
-        print(f"   cond.0: pipeline {kp[0][1]} {kp[1]:.1f} us   phase {kq[0][1]} {kq[1]:.1f} us   "
-              f"(forward: {sum(tp.values()):.1f} vs {sum(tq.values()):.1f} us)", flush=True)
+        for lay in ("cond.0", "cond.1"):
+            kp = [(k, v) for k, v in tp.items() if k[0] == lay][0]
+            kq = [(k, v) for k, v in tq.items() if k[0] == lay][0]
+            print(f"   {lay}: pipeline {kp[0][1]} {kp[1]:.1f} us   phase {kq[0][1]} {kq[1]:.1f} us   "
+                  f"(forward: {sum(tp.values()):.1f} vs {sum(tq.values()):.1f} us)", flush=True)
         del wp, wq, ins
         torch.cuda.empty_cache()

@@ -12,7 +12,7 @@ cfg = S.FULL_CONFIG
 dev = torch.device("cuda:0")
 pl = A.Plan(cfg, storage=storage, compact_workspace=True)
 T = F * cfg.hop
-pl.load_tuned({f"cond.0|{B}|{T}": [1, 1, 1, 1, 5], f"cond.0|{B}|{T}|b": [1, 1, 1, 1, 5]})
+pl.load_tuned({f"cond.0|{B}|{T}": [1, 1, 1, 1, 5], f"cond.0|{B}|{T}|b": [1, 1, 1, 1, 5], f"cond.1|{B}|{T // 5}|b": [1, 1, 1, 1, 5]})
 blob = pl.pack(S.synth_state_dict(cfg, 201)).to(dev)
 ins = list(S.device_batch(cfg, B, F, 900 + B, dev))
 ws = torch.empty(pl.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
@@ -22,7 +22,7 @@ for it in range(int(os.environ.get("RUNS", "12"))):
     ws.fill_(0xFF)
     pl.forward(blob, *ins, workspace=ws)
     torch.cuda.synchronize()
-    cur = {t: pl.tap(t, B, F, ws).float().clone() for t in ("ss.0", "down_hd.1")}
+    cur = {t: pl.tap(t, B, F, ws).float().clone() for t in ("ss.0", "down_hd.1", "ss.1", "down_hd.2")}
     if ref is None:
         ref = cur
         continue
