@@ -951,8 +951,8 @@ def test_long_near_constant_rows_under_instance_norm(dev, excitation):
 
 
 @pytest.mark.parametrize("storage", ["float32", "bfloat16"])
-def test_stage0_layer_pipeline_vs_oracle_phase_kernel_and_itself(dev, storage):
-    """Conditioning stage 0 as a LAYER PIPELINE (cond_stage0_pipe_kernel, csrc/fastsvc_cond.hip: a wave owns a layer, chunks
+def test_layer_pipelines_vs_oracle_phase_kernel_and_themselves(dev, storage):
+    """Conditioning stage 0 - and, in bfloat16 storage, stage 1 (cond_stage1_pipe_kernel) - as a LAYER PIPELINE (cond_stage0_pipe_kernel, csrc/fastsvc_cond.hip: a wave owns a layer, chunks
     of an utterance stream through LDS rings; what long batches run) - forced through the launch table (algorithm 5 under
     "cond.0|B|T") on a batch small enough for the oracle: ss.0 / down_hd.1 against the oracle's taps
     (fastsvc.py:164-193,220-232; Squeeze2d upsample.py:53-74), full and ragged on a poisoned workspace; then at 8 x 600
@@ -966,7 +966,8 @@ def test_stage0_layer_pipeline_vs_oracle_phase_kernel_and_itself(dev, storage):
     def plan_for(B, F, algo):
         pl = A.Plan(cfg, storage=storage, compact_workspace=True)
         T = F * cfg.hop
-        pl.load_tuned({f"cond.0|{B}|{T}": [1, 1, 1, 1, algo], f"cond.0|{B}|{T}|b": [1, 1, 1, 1, algo]})
+        pl.load_tuned({f"cond.0|{B}|{T}": [1, 1, 1, 1, algo], f"cond.0|{B}|{T}|b": [1, 1, 1, 1, algo],
+                       f"cond.1|{B}|{T // 5}|b": [1, 1, 1, 1, algo]})      # stage 1's pipeline: bfloat16 storage only
         return pl
 
     B, F = 3, 52
@@ -979,13 +980,15 @@ def test_stage0_layer_pipeline_vs_oracle_phase_kernel_and_itself(dev, storage):
     recs = []
     y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), workspace=ws, profile=recs)
     assert [r["kernel"] for r in recs if r["layer"] == "cond.0"][0].startswith("cond_stage0_pipe")
-    ss = plan.tap("ss.0", B, F, ws).float().cpu()
-    want = torch.cat([taps["scale.0"], taps["shift.0"]], dim=1)
-    assert float((ss - want).abs().max()) <= tol_t * max(1.0, float(want.abs().max()))
-    hd = plan.tap("down_hd.1", B, F, ws).float().cpu()
-    for sig, sl in (("lft", slice(0, B)), ("sine", slice(B, 2 * B))):
-        wh = taps[f"down_{sig}.0"][..., ::5]
-        assert float((hd[sl] - wh).abs().max()) <= tol_t * max(1.0, float(wh.abs().max())), sig
+    assert [r["kernel"] for r in recs if r["layer"] == "cond.1"][0].startswith("cond_stage1_pipe") == (storage == "bfloat16")
+    for k, dec in ((0, 5), (1, 4)):
+        ss = plan.tap(f"ss.{k}", B, F, ws).float().cpu()
+        want = torch.cat([taps[f"scale.{k}"], taps[f"shift.{k}"]], dim=1)
+        assert float((ss - want).abs().max()) <= tol_t * max(1.0, float(want.abs().max())), k
+        hd = plan.tap(f"down_hd.{k + 1}", B, F, ws).float().cpu()
+        for sig, sl in (("lft", slice(0, B)), ("sine", slice(B, 2 * B))):
+            wh = taps[f"down_{sig}.{k}"][..., ::dec]
+            assert float((hd[sl] - wh).abs().max()) <= tol_t * max(1.0, float(wh.abs().max())), (k, sig)
     e = (y.cpu() - ref).abs()
     assert float(e.max()) <= tol_y
     lens = [52, 31, 4]
@@ -1011,10 +1014,11 @@ def test_stage0_layer_pipeline_vs_oracle_phase_kernel_and_itself(dev, storage):
         wp.fill_(0xFF)
         yp = pipe.forward(blob, *ins, workspace=wp)
         torch.cuda.synchronize()
-        cur = [pipe.tap(t, B2, F2, wp).clone() for t in ("ss.0", "down_hd.1")] + [yp.clone()]
+        names = ("ss.0", "down_hd.1", "ss.1", "down_hd.2")
+        cur = [pipe.tap(t, B2, F2, wp).clone() for t in names] + [yp.clone()]
         if first is None:
             first = cur
-            for t, got in zip(("ss.0", "down_hd.1"), cur):
+            for t, got in zip(names, cur):
                 assert torch.equal(got, phase.tap(t, B2, F2, wq)), t
             assert torch.equal(yp, yq)
         else:
