@@ -57,9 +57,9 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
         js[key] = (js.get(key, 0.0) * n0 + hbm * fetch[k][1]) / (n0 + fetch[k][1])
         merged[key] = n0 + fetch[k][1]
     # whole-stage conditioning launches (csrc/fastsvc_cond.hip)
-    m = re.search(r"cond_stage(\d)_kernel<", k)
+    m = re.search(r"cond_stage(\d)(_pipe)?_kernel", k)
     if m:
-        js["cond_stage%s<%s>" % (m.group(1), "x1" if "bf16::" in k else "x3")] = hbm
+        js["cond_stage%s%s<%s>" % (m.group(1), m.group(2) or "", "x1" if "bf16::" in k else "x3")] = hbm
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
     if m:
         js["conv_mfma<%s,%s,%s,%s>" % m.groups()] = hbm
