@@ -1709,10 +1709,10 @@ hipError_t run_cond_stage0(const fastsvc_plan& P, const float* blob, const float
         const int NTp = cond_stage0_tile_columns(P.storage == 1 ? 3 : 2);
         const long nchunks = (T + NTp - 1) / NTp;
         long kc = 0;
-        for (int r = 2; r >= 1 && !kc; --r) {
-            const long per_utt = std::max<long>(1, (256L * r) / B);
+        {   // ONE round of the 256 resident workgroups (two rounds of half the run measured 1-3 % slower: tools/cond_pipe_tpw.sh)
+            const long per_utt = std::max<long>(1, 256L / B);
             const long k = (nchunks + per_utt - 1) / per_utt;
-            if (k >= (r == 2 ? 48 : 24) || (pipe_mode == 2 && r == 1)) kc = k;
+            if (k >= 24 || pipe_mode == 2) kc = k;
         }
         // (the pipeline addresses both signals' hd rows of an utterance through ONE 32-bit-offset descriptor)
         const bool hd_fits = ((long)B * q.hd_b + (long)d.C * q.hd_ld) * (P.storage == 1 ? 2L : 4L) < (1L << 31);
@@ -1832,10 +1832,10 @@ hipError_t run_cond_stage1(const fastsvc_plan& P, const float* blob, const float
         const int NTp = cond_stage1_tile_columns(2);
         const long nchunks = (T1 + NTp - 1) / NTp;
         long kc = 0;
-        for (int r = 2; r >= 1 && !kc; --r) {
-            const long per_utt = std::max<long>(1, (256L * r) / B);
+        {
+            const long per_utt = std::max<long>(1, 256L / B);
             const long k = (nchunks + per_utt - 1) / per_utt;
-            if (k >= (r == 2 ? 80 : 16) || (pipe_mode == 2 && r == 1)) kc = k;     // (8 x 600 frames, 19 chunks each: 58 vs 94 us)
+            if (k >= 16 || pipe_mode == 2) kc = k;          // (8 x 600 frames, 19 chunks each: 58 vs 94 us for the phase kernel)
         }
         const bool fits = ((long)B * q.hd_b + (long)d.C * q.hd_ld) * 2L < (1L << 31) && (long)d.Cin * T1 * 2L < (1L << 31);
         if (kc && fits) { q.small = 2; q.tpw = (int)std::min<long>(tpw_env > 0 ? tpw_env : kc, 0xffff); }
