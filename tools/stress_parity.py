@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Randomised parity sweep on the GPU (developer tool): random (B, F), ragged or not, with / without
 speaker embedding, table / cost-model / forced-Winograd launch choices, vs the CPU oracle.
-STRESS_STORAGE=bfloat16 sweeps the bfloat16-storage path (mean / max tolerances of the bf16 tests)."""
+STRESS_STORAGE=bfloat16 sweeps the bfloat16-storage path (mean-abs error relative to the rms: 3e-2; utterances of
+1-2 frames, whose InstanceNorm statistics are over 4-8 samples in stage 0, sit at 3.3-3.7e-2 and get 5e-2).
+FASTSVC_COND_PIPE=2 forces the layer pipelines of conditioning stages 0 / 1 at every size."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -51,7 +53,7 @@ for it in range(n):
             if BF16: e = float((y[i:i+1, :, :m*160] - ref).abs().mean()) / max(1e-6, float(ref.pow(2).mean().sqrt()))
             err = max(err, e)
             assert float(y[i, :, m*160:].abs().max()) == 0.0 if m < F else True
-    if err > (3e-2 if BF16 else 1e-4) and os.environ.get("STRESS_DEBUG"):
+    if err > (5e-2 if BF16 else 1e-4) and os.environ.get("STRESS_DEBUG"):
         def one(pl, **kw):
             yy = pl.forward(blob, *ins, emb, lengths=lens, **kw).cpu()
             if lens is None:
@@ -69,6 +71,7 @@ for it in range(n):
             print(f"   allocator block poisoned with {v}:", round(one(p2), 6))
         torch.cuda.synchronize()
     worst = max(worst, err)
-    flag = "" if err <= (3e-2 if BF16 else 1e-4) else "   <-- ABOVE TOLERANCE"
+    tol = (5e-2 if min(lens or [F]) <= 2 else 3e-2) if BF16 else 1e-4
+    flag = "" if err <= tol else "   <-- ABOVE TOLERANCE"
     print(f"B={B} F={F} spk={spk} lens={lens} table={table} compact={compact}: rel err {err:.2e}{flag}", flush=True)
 print(f"worst {worst:.3e}")
