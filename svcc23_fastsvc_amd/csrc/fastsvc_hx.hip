@@ -153,9 +153,11 @@ __device__ __forceinline__ HxFrag hx_neg(HxFrag a) {
 // OPT_LAST (MODE_CHAIN's first conv): transposed result tiles (hx_prod SWAP), and time tile NW-1 is computed only
 // when `do_last` (wave-uniform; the extra tile of the last wave along time) - a scalar branch around that
 // tile's MFMAs only (two whole copies of the unit under an if/else made hipcc spill).
-template <int MW, int NW, bool RELOAD, bool OPT_LAST = false>
+// NS / SOFF / ADV: the ring holds NS fragments per unit of which this conv's start at slot SOFF; the last conv of the
+// unit advances the ring (a launch with a second operand runs two convs per unit, ConvParams::x2).
+template <int MW, int NW, bool RELOAD, bool OPT_LAST = false, int NS = 3 * MW * HX_NP, int SOFF = 0, bool ADV = true>
 __device__ __forceinline__ void hx_unit_direct(f32x4 (&acc)[NW][MW], const unsigned char* tile, const int (&aoff)[3],
-                                               int lo_off, HxWeightStream<3 * MW * HX_NP>& ws, bool do_last = true) {
+                                               int lo_off, HxWeightStream<NS>& ws, bool do_last = true) {
     constexpr int NSTEP = 3 * NW;
     HxFrag a[2];
     a[0] = hx_read(tile, aoff[0], lo_off);
@@ -166,14 +168,14 @@ __device__ __forceinline__ void hx_unit_direct(f32x4 (&acc)[NW][MW], const unsig
             a[(s + 1) & 1] = hx_read(tile, aoff[(s + 1) / NW] + ((s + 1) % NW) * 16 * HX_ROW, lo_off);
             __builtin_amdgcn_sched_barrier(0);                 // reads stay ahead of the MFMAs
         }
-        if (!OPT_LAST || n + 1 < NW || do_last) hx_step<MW, OPT_LAST>(acc[n], a[s & 1], &ws.wr[tap * MW * HX_NP]);
+        if (!OPT_LAST || n + 1 < NW || do_last) hx_step<MW, OPT_LAST>(acc[n], a[s & 1], &ws.wr[SOFF + tap * MW * HX_NP]);
         if (RELOAD && n + 1 == NW) {                            // last use of this tap's fragments
             #pragma unroll
-            for (int q = 0; q < MW * HX_NP; ++q) ws.request(tap * MW * HX_NP + q);
+            for (int q = 0; q < MW * HX_NP; ++q) ws.request(SOFF + tap * MW * HX_NP + q);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (RELOAD) ws.advance();
+    if (RELOAD && ADV) ws.advance();
 }
 
 // DIRECT unit whose weight fragments are read from LDS (`wl`: this unit's [tap][m][piece] KB-sized fragments,
@@ -806,8 +808,14 @@ constexpr bool hx_estage() {
     return MODE == MODE_DIRECT && (EPI == EPI_AFF || EPI == EPI_RES) && (hx_pairs_epi<MW, NW, MODE>() ? MW * NW <= 12 : MW * NW <= 6);
 }
 
+// instances that request the NEXT tile's epilogue operands one tile ahead into a second slot set (EST2, see the
+// consumer loop): one K chunk per tile (the caller checks WSTATIC) and slot sets small enough to double
 template <int MW, int NW, int MODE, int EPI>
+constexpr bool hx_est2() { return hx_estage<MW, NW, MODE, EPI>() && MW * NW <= 4; }
+
+template <int MW, int NW, int MODE, int EPI, int S = 1>
 constexpr int hx_min_waves() {
+
     // 128 VGPRs = two 8-wave workgroups per CU (one computes while the other stores: the C = 24 layers are
     // bound by their store phase) where the producers' two register sets (2 x 32), the unit-deep weight ring
     // (12 * MW) and the accumulators fit; else 256
@@ -854,12 +862,19 @@ __device__ __forceinline__ void hx_last_reduce(const ConvParams& p, const f32x4 
 // stores the straddling float4 whole (between the row end and the pitch lies nobody's data).  Its own instances:
 // folded into the others it cost the 128-register variants their spill-free allocation.
 template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S, bool WSTATIC, bool TAILK = false>
-__global__ __launch_bounds__(512, (hx_min_waves<MW, NW, MODE, EPI>()))
+__global__ __launch_bounds__(512, (hx_min_waves<MW, NW, MODE, EPI, S>()))
 void conv_hx_kernel(const ConvParams p0) {
     constexpr bool UPH = MODE == MODE_UPHEAD;                          // conv_first -> {stretched residual conv, stretched up conv + FiLM affine}
     constexpr bool POLY = MODE == MODE_POLY, DEC2 = MODE == MODE_DEC2, CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1 || UPH;
     constexpr bool IN1 = MODE == MODE_CHAIN1;                          // the staging waves compute the stage's first conv
     constexpr bool WLB = MODE == MODE_CHAIN && S == 2;                 // the second conv's weights live in LDS (one channel group)
+    // MODE_DIRECT with S > 1: a SECOND operand (ConvParams::x2) - the raw tensor x2 stretched S times along time through
+    // its own k=3, d=1 conv - is accumulated with the main conv: units alternate (main chunk, x2 chunk), the main ones
+    // in window buffer 0, the x2 ones in buffer 1, one weight unit each.  (Measured against ONE unit per chunk that stages
+    // both windows and runs six tap steps - one barrier less per tile: C = 24, bfloat16, 64 x 240000: 1233-1343 us
+    // against 954 - the second window's LDS and the twelve resident fragments cost the second workgroup of the CU;
+    // C = 48: 555 against 585 us.)
+    constexpr bool XR = MODE == MODE_DIRECT && S > 1;
     constexpr int NT = 16 * NW * WN;                                   // (input-rate) columns per workgroup tile
     // MODE_CHAIN: the first conv also produces the second one's halo (<= 4 columns per side): its tile starts 4
     // columns early and is one 16-column MFMA tile longer (computed by the last wave along time)
@@ -903,7 +918,7 @@ void conv_hx_kernel(const ConvParams p0) {
     const int tile0 = blockIdx.x * p.tpw;
     const int ntiles = min(p.tpw, ntx - tile0);
     if (ntiles <= 0) return;
-    const int nunits = ntiles * nch;
+    const int nunits = ntiles * (XR ? 2 * nch : nch);
 #ifdef FASTSVC_TIMELINE
     // diagnostic build (tools/timeline.py): lane 0 of every wave stamps s_memtime at its phase boundaries
     const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -924,7 +939,7 @@ void conv_hx_kernel(const ConvParams p0) {
     // Two workgroups share a CU in the 128-VGPR variants.  Dispatched together they would run their phases
     // in lockstep (both load, both multiply, both store): the second one of a CU (workgroup ids 256 apart
     // in dispatch order) starts about half a unit late, so one stores while the other multiplies.
-    if constexpr (hx_min_waves<MW, NW, MODE, EPI>() >= 4) {
+    if constexpr (hx_min_waves<MW, NW, MODE, EPI, S>() >= 4) {
         const int wg_id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         if ((wg_id >> 8) & 1) {
             for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles per step
@@ -942,6 +957,7 @@ void conv_hx_kernel(const ConvParams p0) {
     // stream in flight: the amax row is one more dependent global load, and in front of everything else it cost
     // every launch its latency (+2-3.5 us per kernel, measured).
     float sx = 1.f;                                    // the staging waves multiply what they stage by sx
+    float sx2 = 1.f;                                   // XR: ... and the second operand by sx2
     float s_mid_scale = 1.f;                           // MODE_CHAIN: scale of the intermediate tile
     const int ninv = 16 * MW * p.ngroups;
     const float* invtab = (HX_NP == 2 && p.whx_inv) ? p.whx_inv + (long)sig * p.whx_inv_sig : nullptr;
@@ -969,6 +985,13 @@ void conv_hx_kernel(const ConvParams p0) {
                     }
                 }
                 sx = hx_scale_for(bound);
+            }
+            if constexpr (XR) {
+                if (p.amax_x2) {
+                    float bd = amax_read(p.amax_x2, b);
+                    if (p.bnd_x2) bd = bd * p.bnd_x2[0] + p.bnd_x2[1];
+                    sx2 = hx_scale_for(bd);
+                }
             }
         }
 #endif
@@ -1088,8 +1111,9 @@ void conv_hx_kernel(const ConvParams p0) {
         // unconditional loads of unit `un`: 8 channels x 4 time steps per item; whatever lies outside the
         // tensor or the utterance reads as 0 through the descriptor (offset pushed out of range)
         auto pload = [&](int un, f32x4 (&px)[ITEMS][8], unsigned& tokmask) {
-            const int tl = un / nch;
-            const int ch = un - tl * nch;
+            const int uk = XR ? un >> 1 : un;          // (XR: the main units are the even ones)
+            const int tl = uk / nch;
+            const int ch = uk - tl * nch;
             const int t_start = (tile0 + tl) * NT - HB - halo_al;
             const int soff = ch * HX_KC * p.ldx * 4;
             const int rows_left = p.CIN - ch * HX_KC;
@@ -1139,7 +1163,7 @@ void conv_hx_kernel(const ConvParams p0) {
         // prologue transform (one FMA: InstanceNorm-apply + speaker bias; LeakyReLU), split, transpose, LDS write
         auto pcommit = [&](int un, const f32x4 (&px)[ITEMS][8], unsigned tokmask, unsigned char* tile) {
             if (FASTSVC_DBG_ON(p, DBG_NO_COMMIT)) return;
-            const int ch = un % nch;
+            const int ch = (XR ? un >> 1 : un) % nch;
             if constexpr (IN1) {
                 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) {
@@ -1200,6 +1224,91 @@ void conv_hx_kernel(const ConvParams p0) {
             }
         };
 
+        // ---- XR, second operand: Stretch_S(x2), raw.  Item = (octet of 8 channels, group of XJ input columns): XJ * 8
+        // element loads, every column written S times = XROWS consecutive rows of the second window (row r <-> output
+        // column t_start + r, the same alignment as the main window; the x2 conv's taps are rows -1 / 0 / +1).  64 groups
+        // per tile cover window + halo for every shape (64 * XROWS - XROWS + 1 >= 253 rows); rows that fall outside the
+        // window go to the spare row behind it, columns outside the utterance read 0 = the conv's zero padding.
+        constexpr int XJ = (XR && S == 2) ? 2 : 1, XROWS = XJ * (XR ? S : 1);
+        const __amdgpu_buffer_rsrc_t x2r = XR ? act_rsrc(p.x2, (long)b * p.x2_b, (long)p.CIN * p.ldx2) : xr;
+        const int x2T = !XR ? 0 : p0.lens ? p0.lens[b] * p0.x2len_mul : p.x2_T;
+        const int xoct = ptid & 3, xg = ptid >> 2;
+        auto ploadX = [&](int un, float (&px)[XJ][8]) {
+            if constexpr (XR) {
+                const int uk = un >> 1;                // (the odd units)
+                const int tl = uk / nch;
+                const int ch = uk - tl * nch;
+                const int t_start = (tile0 + tl) * NT - halo_al;
+                const int g0 = (t_start + 8 * XROWS) / XROWS - 8;                 // floor(t_start / XROWS), t_start >= -28
+                const int soff = ch * HX_KC * p.ldx2 * 4;
+                const int rows_left = p.CIN - ch * HX_KC;
+                #pragma unroll
+                for (int jj = 0; jj < XJ; ++jj) {
+                    const int j = (g0 + xg) * XJ + jj;
+                    const bool ok = (unsigned)j < (unsigned)x2T && un < nunits;
+                    #pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int r = xoct * 8 + c;
+                        px[jj][c] = act_load1(x2r, (ok && r < rows_left) ? (r * p.ldx2 + j) * 4 : OOB_OFF, soff);
+                    }
+                }
+            }
+        };
+        auto pcommitX = [&](int un, const float (&px)[XJ][8], unsigned char* tile) {
+            if constexpr (XR) {
+                const int tl = (un >> 1) / nch;
+                const int t_start = (tile0 + tl) * NT - halo_al;
+                const int g0 = (t_start + 8 * XROWS) / XROWS - 8;
+                const int r0 = (g0 + xg) * XROWS - t_start;
+                #pragma unroll
+                for (int jj = 0; jj < XJ; ++jj) {
+                    hx8 h;
+                    #pragma unroll
+                    for (int c = 0; c < 8; ++c) h[c] = (hx_t)(HX_NP == 2 ? px[jj][c] * sx2 : px[jj][c]);
+                    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+                    u32x4w lp = {0u, 0u, 0u, 0u};
+                    if constexpr (HX_NP == 2) {
+                        const u32x4w hp = __builtin_bit_cast(u32x4w, h);
+                        #pragma unroll
+                        for (int k = 0; k < 4; ++k) lp[k] = hx_lo_pair(hp[k], px[jj][2 * k] * sx2, px[jj][2 * k + 1] * sx2);
+                    }
+                    #pragma unroll
+                    for (int ph = 0; ph < S; ++ph) {
+                        const int r = r0 + jj * S + ph;
+                        const int off = hx_lds_off((unsigned)r < (unsigned)W ? r : W, xoct);
+                        *reinterpret_cast<hx8*>(tile + off) = h;
+                        if constexpr (HX_NP == 2) *reinterpret_cast<u32x4w*>(tile + lo_off + off) = lp;
+                    }
+                }
+            }
+        };
+        if constexpr (XR) {
+            f32x4 pa[ITEMS][8];
+            float xb[XJ][8];
+            unsigned oka = 0;
+            pload(0, pa, oka);
+            ploadX(1, xb);
+            stamp(2);
+            setup_shared();
+            pcommit(0, pa, oka, tiles);
+            stamp(3);
+            __syncthreads();                           // unit 0 staged
+            stamp(4);
+            for (int u = 0; u < nunits; u += 2) {       // (an even number of units: every main unit has its x2 unit)
+                pload(u + 2, pa, oka);
+                stamp(9);
+                pcommitX(u + 1, xb, tiles + bufsz);
+                stamp(5);
+                __syncthreads();                       // end of unit u
+                stamp(6);
+                ploadX(u + 3, xb);
+                stamp(9);
+                pcommit(u + 2, pa, oka, tiles);
+                stamp(5);
+                __syncthreads();                       // end of unit u + 1
+                stamp(6);
+            }
+        } else {
         f32x4 pa[ITEMS][8], pb[ITEMS][8];
         unsigned oka = 0, okb = 0;                       // per-item "rows inside the utterance" bits
         // No branch may sit between a load and its use (hipcc then counts vmcnt for the path WITHOUT the
@@ -1242,20 +1351,33 @@ void conv_hx_kernel(const ConvParams p0) {
             if (CHAIN && u + 1 < nunits && ((u + 1) % nch) == nch - 1) __syncthreads();
             stamp(6);
         }
+        }
     } else {
         // ================================ CONSUMER WAVES ================================
         f32x4 acc[(POLY || DEC2 || UPH) ? 1 : NW][MW];
         f32x4 acc3[3][(POLY || UPH) ? NW : 1][MW];    // polyphase: a / z / c accumulator sets
         f32x4 acc2[2][DEC2 ? NW : 1][MW];             // decimating pair: k=3 / 1x1
+        constexpr bool XSPLIT = XR && HX_NP == 2;     // second operand, float32 storage: its own accumulator set (other operand scales)
+        f32x4 accX[XSPLIT ? NW : 1][MW];
         float s1[MW], s2[MW];
         HxWeightStream<NSLOT> wst;
-        const int wunits = UPH ? nch + 2 * p.nch32b : CHAIN ? nch + p.nch32b : nch;    // weight units per tile (CHAIN: first conv's, then the second's)
+        const int wunits = UPH ? nch + 2 * p.nch32b : CHAIN ? nch + p.nch32b : XR ? 2 * nch : nch;    // weight units per tile (CHAIN: first conv's, then the second's; XR: interleaved)
         wst.init(reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
                      (long)(active ? mg : 0) * wunits * NSLOT * HX_FRAG, WLB ? nch : wunits, lane);
         int aoff[3];
         #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
             aoff[tap] = hx_lds_off((halo_al - halo) + tap * halo + wave_n * (NW * 16) + (lane & 15), lane >> 4);
+        int aoffX[3];                                  // XR: taps of the second operand's conv (dilation 1, same window alignment)
+        #pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            aoffX[tap] = XR ? hx_lds_off((halo_al - 1) + tap + wave_n * (NW * 16) + (lane & 15), lane >> 4) : 0;
+        // XR with one K chunk (WSTATIC): the second conv's fragments stay in registers like the first one's
+        HxWeightStream<NSLOT> wstX_static;
+        if constexpr (XR && WSTATIC)
+            wstX_static.init(reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
+                                 ((long)(active ? mg : 0) * wunits + 1) * NSLOT * HX_FRAG, 1, lane);
+        HxWeightStream<NSLOT>& wstX = (XR && WSTATIC) ? wstX_static : wst;
         EpiRsrc R;
         {
             const long ct = (long)p.COUT * p.ldy;
@@ -1277,6 +1399,7 @@ void conv_hx_kernel(const ConvParams p0) {
             k_bias[m] = cok ? p.bias[(long)sig * p.bias_sig + co] : 0.f;
             k_bias2[m] = 0.f; k_r1w[m] = 0.f; k_r1b[m] = 0.f;
             if constexpr (DEC2 || UPH) k_bias2[m] = cok ? p.bias2[(long)sig * p.bias2_sig + co] : 0.f;
+            if constexpr (XR) k_bias[m] += cok ? p.bias2[co] : 0.f;        // both convs' biases join the one accumulator
             if constexpr (EPI == EPI_RANK1) {
                 k_r1w[m] = cok ? p.r1w[(long)sig * p.r1_sig + co] : 0.f;
                 k_r1b[m] = cok ? p.r1b[(long)sig * p.r1_sig + co] : 0.f;
@@ -1296,6 +1419,7 @@ void conv_hx_kernel(const ConvParams p0) {
                     t_inv[m] = cok ? invtab[(CHAIN ? ninv : 0) + cot] : 0.f;
                     if constexpr (DEC2) t_inv2[m] = cok ? invtab[ninv + cot] : 0.f;
                     if constexpr (UPH) t_inv2[m] = cok ? invtab[2 * ninv + cot] : 0.f;
+                    if constexpr (XR) t_inv2[m] = cok ? invtab[ninv + cot] : 0.f;
                 }
             }
         }
@@ -1312,8 +1436,13 @@ void conv_hx_kernel(const ConvParams p0) {
         constexpr int EST_WAVE_FLOATS = EST ? (PAIRS ? MW * (NW / 2) * 256 : MW * NW * EST_ITEM_FLOATS) : 0;   // per operand
         const int est_ops = EPI == EPI_RES ? 1 : p.res ? 3 : 2;
         const float* Ew = reinterpret_cast<const float*>(tiles + 2 * bufsz) + cw * (est_ops * EST_WAVE_FLOATS);
+        // EST2 (one K chunk per tile: WSTATIC): the operands of tile t + 1 are requested BEFORE tile t's products into a
+        // second slot set - requested in front of their own tile's products they had one short matrix loop (200-600
+        // cycles) to cover a memory round trip, i.e. every tile's epilogue started with an exposed HBM latency
+        constexpr bool EST2 = hx_est2<MW, NW, MODE, EPI>() && WSTATIC && !XR;
+        const int est_set = 4 * est_ops * EST_WAVE_FLOATS;         // floats of one slot set (all four waves)
         // bfloat16 pair epilogue: this wave's re-layout patch behind every wave's operand slots
-        float* Xw = const_cast<float*>(reinterpret_cast<const float*>(tiles + 2 * bufsz)) + 4 * est_ops * EST_WAVE_FLOATS +
+        float* Xw = const_cast<float*>(reinterpret_cast<const float*>(tiles + 2 * bufsz)) + (EST2 ? 2 : 1) * est_set +
                     cw * (16 * 36);
         (void)Xw;
         stamp(2);
@@ -1327,6 +1456,19 @@ void conv_hx_kernel(const ConvParams p0) {
                     s_inv[li] = t_inv[m] * isx;
                     if constexpr (DEC2 || UPH) s_inv[16 * MW * WM + li] = t_inv2[m] * isx;
                 }
+            }
+        }
+        // XR, float32 storage: the second conv accumulates in its own set (its operands carry other power-of-two scales);
+        // the set joins the main one before the epilogue, times (inverse scales of x2's conv) / (those of the main conv) -
+        // a power of two, from the exponent fields
+        float xratio[MW];
+        #pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            xratio[m] = 0.f;
+            if constexpr (XR && HX_NP == 2) {
+                auto ex = [](float v) { return (int)((__builtin_bit_cast(unsigned, v) >> 23) & 0xffu); };
+                const int e = ex(t_inv2[m]) - ex(t_inv[m]) + ex(sx) - ex(sx2) + 127;
+                if (t_inv[m] != 0.f) xratio[m] = __builtin_bit_cast(float, (unsigned)min(254, max(1, e)) << 23);
             }
         }
         __syncthreads();                               // unit 0 staged (and s_inv visible)
@@ -1475,8 +1617,83 @@ void conv_hx_kernel(const ConvParams p0) {
                 stamp(8);
                 }
             }
+        } else if constexpr (XR) {
+            for (int tl = 0; tl < ntiles; ++tl) {
+                #pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m) {
+                        acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (XSPLIT) accX[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                const int tcolw = (tile0 + tl) * NT + wave_n * (NW * 16);
+                for (int ch = 0; ch < nch; ++ch) {
+                    if constexpr (EST) {
+                        // the epilogue's scale / shift pieces, two units ahead of it
+                        if (active && ch + 1 == nch) {
+#ifdef FASTSVC_ACT_BF16
+                            if constexpr (PAIRS) hx_epilogue8_stage<MW, NW / 2, EPI>(p, R, Ew, mg, tcolw, lane);
+                            else
+#endif
+                            ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, tcolw, lane);
+                        }
+                    }
+                    if (active) hx_unit_direct<MW, NW, !WSTATIC>(acc, tiles, aoff, lo_off, wst);
+                    stamp(7);
+                    __syncthreads();                   // end of the main unit
+                    stamp(6);
+                    ++u;
+                    if (active) {
+                        if constexpr (XSPLIT) hx_unit_direct<MW, NW, !WSTATIC>(accX, tiles + bufsz, aoffX, lo_off, wstX);
+                        else hx_unit_direct<MW, NW, !WSTATIC>(acc, tiles + bufsz, aoffX, lo_off, wstX);
+                    }
+                    stamp(7);
+                    if (ch + 1 == nch) {
+                        if constexpr (XSPLIT) {
+                            #pragma unroll
+                            for (int n = 0; n < NW; ++n)
+                                #pragma unroll
+                                for (int m = 0; m < MW; ++m) acc[n][m] += accX[n][m] * xratio[m];
+                        }
+                        #pragma unroll
+                        for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
+                        if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC); }
+#ifdef FASTSVC_ACT_BF16
+                        if constexpr (PAIRS) hx_epilogue8<MW, NW / 2, EPI, EST, false>(p, R, acc, s1, s2, sig, mg, tcolw, active, lane, K, Ew, Xw);
+                        else
+#endif
+                        ws_epilogue_kind<MW, NW, EPI, EST, 0, -1>(p, R, acc, s1, s2, sig, mg, tcolw, active, lane, K, Ew);
+                        if (flags & F_STATS) {
+                            #pragma unroll
+                            for (int m = 0; m < MW; ++m) {
+                                float a1 = s1[m], a2 = s2[m];
+                                a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+                                a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                                if (active && lane < 16) {
+                                    const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
+                                    atomicAdd(&sstat[slot + 0], (double)a1);
+                                    atomicAdd(&sstat[slot + 1], (double)a2);
+                                }
+                            }
+                        }
+                    }
+                    stamp(8);
+                    __syncthreads();                   // end of the x2 unit
+                    stamp(6);
+                    ++u;
+                }
+            }
         } else
         for (int tl = 0; tl < ntiles; ++tl) {
+            auto est_stage = [&](const float* slots, int tile) {
+                if constexpr (EST) {
+#ifdef FASTSVC_ACT_BF16
+                    if constexpr (PAIRS) hx_epilogue8_stage<MW, NW / 2, EPI>(p, R, slots, mg, tile * NT + wave_n * (NW * 16), lane);
+                    else
+#endif
+                    ws_epilogue_stage<MW, NW, EPI>(p, R, slots, mg, tile * NT + wave_n * (NW * 16), lane);
+                }
+            };
             #pragma unroll
             for (int n = 0; n < NW; ++n)
                 #pragma unroll
@@ -1485,16 +1702,16 @@ void conv_hx_kernel(const ConvParams p0) {
                     else if constexpr (DEC2) { acc2[0][n][m] = acc2[1][n][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                     else acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+            const float* EwT = EST2 ? Ew + (tl & 1) * est_set : Ew;       // this tile's slot set
             for (int ch = 0; ch < nch; ++ch, ++u) {
-                if constexpr (EST) {
-                    // one unit earlier when the tile has several K chunks: more time to land
-                    if (active && ch == max(nch - 2, 0) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
-#ifdef FASTSVC_ACT_BF16
-                        if constexpr (PAIRS) hx_epilogue8_stage<MW, NW / 2, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
-                        else
-#endif
-                        ws_epilogue_stage<MW, NW, EPI>(p, R, Ew, mg, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
+                if constexpr (EST2) {
+                    if (active && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
+                        if (tl == 0) est_stage(Ew, tile0);
+                        if (tl + 1 < ntiles) est_stage(Ew + ((tl + 1) & 1) * est_set, tile0 + tl + 1);
                     }
+                } else if constexpr (EST) {
+                    // one unit earlier when the tile has several K chunks: more time to land
+                    if (active && ch == max(nch - 2, 0) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) est_stage(Ew, tile0 + tl);
                 }
                 if (active && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))) {
                     if constexpr (POLY) hx_unit_poly<MW, NW, !WSTATIC>(acc3, tiles + (u & 1) * bufsz, aoff, lo_off, wst);
@@ -1506,6 +1723,16 @@ void conv_hx_kernel(const ConvParams p0) {
                     #pragma unroll
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
                     // the staged pieces are older than the NSLOT ring re-requests of this unit
+                    if constexpr (EST2) {
+                        // everything but the NEXT tile's pieces (the youngest requests of this wave) has landed
+                        if (active) {
+                            constexpr int PER_OP = PAIRS ? MW * (NW / 2) : MW * NW * EST_DMA_PER_ITEM;
+                            if (tl + 1 >= ntiles) ws_epilogue_stage_wait<0>(false);
+                            else if (EPI == EPI_RES) ws_epilogue_stage_wait<PER_OP>(true);
+                            else if (p.res) ws_epilogue_stage_wait<3 * PER_OP>(true);
+                            else ws_epilogue_stage_wait<2 * PER_OP>(true);
+                        }
+                    } else
                     if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))); }
                     if constexpr (POLY) {
 #ifdef FASTSVC_ACT_BF16
@@ -1533,11 +1760,11 @@ void conv_hx_kernel(const ConvParams p0) {
                         if constexpr (PAIRS) {
                             if (!(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
                                 hx_epilogue8<MW, NW / 2, EPI, EST, TAILK>(p, R, acc, s1, s2, sig, mg,
-                                                                   (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew, Xw);
+                                                                   (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, EwT, Xw);
                         } else
 #endif
                         ws_epilogue_kind<MW, NW, EPI, EST, TAILK ? 2 : 0, -1>(p, R, acc, s1, s2, sig, mg,
-                                                              (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, Ew);
+                                                              (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, EwT);
                         if constexpr (LAST_OK) {
                             if (p.last_w && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
                                 hx_last_reduce<MW, NW, PAIRS>(p, acc, k_last, b, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
@@ -1665,7 +1892,23 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
         constexpr bool PAIRS = hx_pairs_epi<MW, NW, MODE_DIRECT>();
         if ((kind == EPI_AFF && hx_estage<MW, NW, MODE_DIRECT, EPI_AFF>()) || (kind == EPI_RES && hx_estage<MW, NW, MODE_DIRECT, EPI_RES>()))
             est = sizeof(float) * 4 * (size_t)(aff ? (p.res ? 3 : 2) : 1) * (PAIRS ? MW * (NW / 2) * 256 : MW * NW * EST_ITEM_FLOATS);
+        if (MW == 2 && p.nch32 == 1 && !p.x2 &&
+            ((kind == EPI_AFF && hx_est2<MW, NW, MODE_DIRECT, EPI_AFF>()) || (kind == EPI_RES && hx_est2<MW, NW, MODE_DIRECT, EPI_RES>())))
+            est *= 2;                                                              // one K chunk: two slot sets (EST2, the next tile's operands)
         if (PAIRS) est += sizeof(float) * 4 * 16 * 36;                             // the waves' re-layout patches
+        if (p.x2) {
+            // second operand (ConvParams::x2): FiLM-affine epilogue, no residual tensor, rows a multiple of 4 long; the
+            // stretch factors of the recipe's blocks per channel-tile count (C = 24: x5, one K chunk; C >= 48: x2 / x4)
+            if (kind != EPI_AFF || p.res || p.x2_T * p.s2 != p.T || (p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0)))
+                return hipErrorInvalidValue;
+#define FASTSVC_HXX(sv, stat) if (p.s2 == sv) return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE_DIRECT, EPI_AFF, sv, stat>>(grid, smem + est, stream, p);
+            if constexpr (MW * NW <= 12) {                                         // (larger tiles spill with this epilogue)
+                if constexpr (MW == 2) { if (p.nch32 == 1) { FASTSVC_HXX(5, true) } }
+                else { FASTSVC_HXX(2, false) FASTSVC_HXX(4, false) }
+            }
+#undef FASTSVC_HXX
+            return hipErrorInvalidValue;
+        }
 #define FASTSVC_HX(k) if (kind == k) return hx_launch_kind<MW, NW, WM, WN, MODE_DIRECT, k, 1>(grid, smem + est, stream, p);
         FASTSVC_HX(EPI_PLAIN) FASTSVC_HX(EPI_RES) FASTSVC_HX(EPI_RANK1) FASTSVC_HX(EPI_AFF)
 #undef FASTSVC_HX
@@ -1716,6 +1959,7 @@ hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_
 }
 
 #ifndef FASTSVC_ACT_BF16      // storage-independent host query: defined once
+bool conv_hx_x2_ok(int MW, int nch32, int s2) { return MW == 2 ? (nch32 == 1 && s2 == 5) : MW == 3 ? (s2 == 2 || s2 == 4) : false; }
 bool conv_hx_tail_ok(int mode, int MW, int epi_kind, int S) { return hx_tail_instance(MW, mode, epi_kind, S); }
 
 bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN) {

@@ -127,6 +127,18 @@ struct ConvParams {
     // number of MEASURED tensors - each costs its producer device-scope atomics - to one per stage / block.
     const float* bnd_path[2];
     long bnd_sig[2];
+    // ---- second operand of a MODE_DIRECT launch (half-precision MFMA kernels; the middle conv of an up block with the
+    // block's stretched residual conv folded in, fastsvc.py:94-100):  y = Conv3_dil(pre(x)) + Conv3_1(Stretch_s2(x2)) +
+    // bias + bias2.  x2 is the RAW (B, CIN, x2_T) tensor at 1 / s2 of the output rate (x2_T * s2 == T; a ragged batch:
+    // lens[b] * x2len_mul columns); the staging waves write every input column s2 times into a second LDS window and the
+    // consumers run three more taps (dilation 1) on it - the residual tensor is never materialised.  whx then holds, per
+    // channel group, the units [conv chunk 0 | x2 conv chunk 0 | conv chunk 1 | x2 conv chunk 1 ...] and whx_inv the two
+    // tables [conv | x2 conv]; amax_x2 / bnd_x2: the measured row and the (l1, bmax) pair that bound x2 (float32 storage)
+    const float* x2;
+    long x2_b;
+    int x2_T, ldx2, s2, x2len_mul;
+    const float* amax_x2;
+    const float* bnd_x2;
     float* amax_out;             // entry sig * amax_out_sig + b: largest |value| of y (residual epilogues and the fused
     int amax_out_sig;            //   pair's final one measure; null: not tracked)
     int no_hx;                   // host side only: keep this launch on the exact f32-input MFMA kernels (run_conv)
@@ -285,6 +297,9 @@ bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN);
 // whether the half-precision-MFMA instances of this mode / epilogue kind handle rows whose own length (ragged batch at
 // the frame rate or twice it) is not a multiple of 4 - the pitches must be
 bool conv_hx_tail_ok(int mode, int MW, int epi_kind, int S);
+// whether the MODE_DIRECT instances with a second, stretched operand (ConvParams::x2) exist for this channel-tile count,
+// number of K chunks and stretch factor
+bool conv_hx_x2_ok(int MW, int nch32, int s2);
 
 // down-sampling stage 0, first conv (C_in = 1, k = 3, d = 1, LeakyReLU on the input):
 //   y[sig][b][co][t] = bias[co] + sum_tap w[co][tap] * lrelu(x[sig][b][t + tap - 1])

@@ -205,6 +205,8 @@ struct fastsvc_plan {
     std::vector<FilmChainJob> film_chain_jobs;
     struct UpHeadJob { PackedConv* c; std::string first, res, up; int cin, C; };
     std::vector<UpHeadJob> up_head_jobs;
+    struct XrJob { PackedConv* c; std::string conv, res; };                 // c = the block's d = 3 conv
+    std::vector<XrJob> xr_jobs;
     std::vector<RawParam*> raw_jobs;
     std::vector<int> cond_bound_jobs;   // conditioning stages with cbnd tables
     double flops_per_sample = 0.0;
@@ -375,6 +377,18 @@ struct fastsvc_plan {
                                          u.Cin, u.C});
     }
 
+    // the middle conv of an up block with the block's stretched residual conv folded in (ConvParams::x2): per channel
+    // group the units [d3 chunk 0 | residual chunk 0 | d3 chunk 1 | ...], inverse scale tables [d3 | residual]
+    void add_xr_fuse(UpStage& u, const std::string& prefix) {
+        PackedConv& c = u.d3;
+        if (!c.hx || !u.res.hx || c.cin != c.cout || u.res.cin != c.cin || u.res.cout != c.cout || u.res.MW != c.MW) return;
+        for (int prec = 0; prec < 2; ++prec)
+            c.hxc_off[prec] = alloc((size_t)c.ngroups * 2 * c.nch32 * 3 * c.MW * (prec == 0 ? 2 : 1) * 256);
+        c.hxc_inv_off = alloc(2 * c.b_floats);
+        c.b2_off = u.res.b_off;
+        xr_jobs.push_back(XrJob{&c, prefix + ".conv_block1.1", prefix + ".residual_block.1"});
+    }
+
     void add_raw(RawParam* r, int npair, const std::vector<std::string>& layers, size_t wf, size_t bf) {
         for (int i = 0; i < npair; ++i) { r[i].layer = layers[i]; r[i].w_floats = wf; r[i].b_floats = bf; }
         for (int i = 0; i < npair; ++i) r[i].w_off = alloc(wf);
@@ -480,6 +494,7 @@ int build_plan(fastsvc_plan& P) {
         }
         P.add_up_head(u, p);
         P.add_conv(&u.d3, 1, u.C, u.C, 3, 3, {single(p + ".conv_block1.1")});
+        P.add_xr_fuse(u, p);
         P.add_conv(&u.d9, 1, u.C, u.C, 3, 9, {single(p + ".conv_block2.1")});
         P.add_conv(&u.d27, 1, u.C, u.C, 3, 27, {single(p + ".conv_block3.1")});
         if (c.use_spk_emb) P.add_raw(&u.emb, 1, {p + ".emb_projector"}, (size_t)u.C * c.spk_emb_size, u.C);
@@ -849,6 +864,28 @@ int fastsvc_pack_weights(const fastsvc_plan* plan, const fastsvc_tensor* tensors
             if (rc != FASTSVC_OK) return rc;
             l1_of(L1, c.cout, 3, cst[2], cst[3]);
         }
+        return FASTSVC_OK;
+    });
+    task_names.insert(task_names.end(), plan->xr_jobs.size(), "xr_fuse");
+    for (const auto& job_ : plan->xr_jobs) tasks.emplace_back([&, pj = &job_]() -> int {
+        const auto& job = *pj;
+        const PackedConv& c = *job.c;
+        HostLayer LA, LB;
+        int rc = fetch_layer(sd, job.conv, c.cout, (size_t)c.cin * 3, LA);
+        if (rc != FASTSVC_OK) return rc;
+        rc = fetch_layer(sd, job.res, c.cout, (size_t)c.cin * 3, LB);
+        if (rc != FASTSVC_OK) return rc;
+        // pack_hx's fragment format with 2 * nch32 units per group, the two convs' 32-channel chunks interleaved
+        PackedConv v = c;
+        v.nch32 = 2 * c.nch32;
+        v.cin = 2 * c.nch32 * 32;                           // the accessor below bounds the real channels
+        const int cin = c.cin;
+        pack_hx(v, c.hxc_off, 3, [&](int co, int ci, int tap) {
+            const int chv = ci >> 5;
+            const int cj = (chv >> 1) * 32 + (ci & 31);
+            if (cj >= cin) return 0.f;
+            return ((chv & 1) ? LB.w : LA.w)[((size_t)co * cin + cj) * 3 + tap];
+        }, c.hxc_inv_off, 2, [](int ci, int) { return (ci >> 5) & 1; });
         return FASTSVC_OK;
     });
     task_names.insert(task_names.end(), plan->film_chain_jobs.size(), "film_chain");
@@ -1644,6 +1681,147 @@ hipError_t run_uphead(const UpStage& u, const float* blob, ConvParams p, hipStre
         return prof->end();
     }
     return launch_conv_hx(p, L, stream);
+}
+
+// The middle conv of an up block (d = 3) with the block's stretched residual conv folded into its accumulator
+// (fastsvc_hx.hip, ConvParams::x2; fastsvc.py:94-100: xmid = conv_d3(lrelu(norm(u1))) + conv_res(stretch(a))): the residual
+// tensor xr - one launch, one write and one read of a (B, C, T) tensor per block - is never materialised.  p describes the
+// d = 3 conv's launch WITHOUT its residual operand, plus x2 / x2_b / x2_T / s2 / amax_x2 / bnd_x2.
+// what: 0 = only answer whether this call would run fused (`done`), 1 = launch, 2 = tuning pass: time the fused shapes
+// against `sep_ms` (the two separate launches) and record the winner under "<layer>|B|T" (algorithm 3 fused, 0 separate).
+hipError_t run_d3x(const UpStage& u, const float* blob, ConvParams p, hipStream_t stream, Profiler* prof, const char* layer,
+                   int what, double sep_ms, bool& done) {
+    done = false;
+    static const int hx_env = std::getenv("FASTSVC_HX") ? std::atoi(std::getenv("FASTSVC_HX")) : 1;
+    static const int x_env = std::getenv("FASTSVC_D3X") ? std::atoi(std::getenv("FASTSVC_D3X")) : 1;     // 0: never, 2: wherever it exists (A/B)
+    const PackedConv& c = u.d3;
+    const bool act_bf16 = g_tune.plan && g_tune.plan->storage == 1;
+    const int prec = act_bf16 ? 1 : 0;
+    p.ldx = p.x_T; p.ldy = p.T; p.ldx2 = p.x2_T;
+    if (p.lens) { p.len_mul = p.T / p.frames_ld; p.xlen_mul = p.x_T / p.frames_ld; p.x2len_mul = p.x2_T / p.frames_ld; }
+    if (!hx_env || !x_env || g_exact_f32 || p.no_hx || !c.hxc_off[prec] || (p.T & 3) || p.x_T != p.T || (long)p.x2_T * p.s2 != p.T ||
+        (p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0)) || !conv_hx_x2_ok(c.MW, c.nch32, p.s2) || c.dil > 28)
+        return hipSuccess;
+    p.mode = MODE_DIRECT; p.s = 1;
+    p.CIN = c.cin; p.KC = c.KC; p.nchunks = c.nchunks; p.w = blob + c.w_off; p.Q = c.Q;
+    p.COUT = c.cout; p.ngroups = c.ngroups; p.ntaps = 3; p.dil = c.dil; p.nch32 = c.nch32;
+    p.whx = blob + c.hxc_off[prec]; p.whx_sig = 0;
+    p.whx_inv = prec == 0 ? blob + c.hxc_inv_off : nullptr; p.whx_inv_sig = 0;
+    p.bias = blob + c.b_off; p.bias_sig = 0; p.bias2 = blob + c.b2_off; p.bias2_sig = 0;
+    p.res = nullptr;
+    p.vec = 1; p.tpw = 1; p.xs = 0; p.ps = 0;
+    {
+        static const int stagger = std::getenv("FASTSVC_STAGGER") ? std::atoi(std::getenv("FASTSVC_STAGGER")) : 2;
+        p.stagger = stagger;
+        static const int dbg = std::getenv("FASTSVC_DBG") ? std::atoi(std::getenv("FASTSVC_DBG")) : 0;
+        p.dbg = dbg;
+    }
+    auto launch = [&](const ConvParams& q, const ConvLaunch& Lq) {
+        return act_bf16 ? bf16::launch_conv_hx(q, Lq, stream) : launch_conv_hx(q, Lq, stream);
+    };
+    struct Cand { int NW, WM, WN; };
+    std::vector<Cand> cands;
+    static const int shapes[][3] = {{4, 2, 2}, {2, 1, 4}, {3, 1, 4}, {2, 2, 2}};      // (FiLM-affine epilogue: MW * NW <= 12)
+    for (const auto& sh : shapes)
+        if (conv_hx_shape(MODE_DIRECT, c.MW, sh[0], sh[1], sh[2]) && c.ngroups % sh[1] == 0 && sh[0] * c.MW <= 12)
+            cands.push_back(Cand{sh[0], sh[1], sh[2]});
+    if (cands.empty()) return hipSuccess;
+    char key[96];
+    std::snprintf(key, sizeof(key), act_bf16 ? "%s|%d|%d|b" : "%s|%d|%d", layer, p.B, p.T);
+    bool have = false, fused = true;
+    Cand best = cands[0];
+    if (g_tune.plan) {
+        std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
+        auto it = g_tune.plan->tuned.find(key);
+        if (it != g_tune.plan->tuned.end()) {
+            if (it->second.algo != 3 && x_env != 2) { have = true; fused = false; }
+            for (const Cand& cd : cands)
+                if (cd.NW == it->second.NW && cd.WM == it->second.WM && cd.WN == it->second.WN &&
+                    it->second.tpw >= 1 && it->second.tpw <= 64) { best = cd; p.tpw = it->second.tpw; have = true; }
+        }
+    }
+    if (what == 2) {
+        if (have || !g_tune.tuning || !g_tune.plan) return hipSuccess;
+        static const int tpws[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24};
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return hipErrorUnknown;
+        float best_ms = 1e30f;
+        ConvParams q = p;
+        q.flags &= ~F_STATS;                               // (the trial launches do not accumulate InstanceNorm sums)
+        for (const Cand& cd : cands) {
+            const long ntx = (p.T + 16 * cd.NW * cd.WN - 1) / (16 * cd.NW * cd.WN);
+            for (int tpw : tpws) {
+                q.tpw = tpw;
+                ConvLaunch Lq{c.MW, cd.NW, cd.WM, cd.WN, 1, 2};
+                hipError_t e = launch(q, Lq);
+                if (e != hipSuccess) return e;
+                hipEventRecord(e0, stream);
+                for (int r = 0; r < 3; ++r) { e = launch(q, Lq); if (e != hipSuccess) return e; }
+                hipEventRecord(e1, stream);
+                if (hipEventSynchronize(e1) != hipSuccess) return hipErrorUnknown;
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                ++g_tune.trials;
+                if (ms < best_ms) { best_ms = ms; best = cd; p.tpw = tpw; }
+                if (tpw >= ntx) break;
+            }
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        fused = sep_ms <= 0.0 || best_ms / 3.0 < sep_ms;
+        std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
+        g_tune.plan->tuned[key] = fastsvc_plan::Choice{best.NW, best.WM, best.WN, p.tpw, fused ? 3 : 0};
+        g_tune.plan->priors.clear();
+        return hipSuccess;
+    }
+    if (!have) {
+        if (g_tune.tuning) return hipSuccess;              // (a tuning pass runs the separate launches, then times this one)
+        // no table entry: the nearest entry of this layer, else the first shape; workgroups sized so that the grid
+        // fills the CUs about evenly
+        if (g_tune.plan) {
+            fastsvc_plan::Choice pr{0, 0, 0, 0, -1};
+            std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
+            if (g_tune.plan->prior_for(layer, p.B, p.T, act_bf16, pr)) {
+                if (pr.algo != 3 && x_env != 2) fused = false;
+                for (const Cand& cd : cands) if (cd.NW == pr.NW && cd.WM == pr.WM && cd.WN == pr.WN) best = cd;
+            }
+        }
+        const int NT = 16 * best.NW * best.WN;
+        const long ntx = (p.T + NT - 1) / NT;
+        const long gy = c.ngroups / best.WM;
+        double best_t = 1e30;
+        for (int tpw = 1; tpw <= 24; ++tpw) {
+            const long wgs = ((ntx + tpw - 1) / tpw) * gy * p.B;
+            const double t = (double)((wgs + 255) / 256) * (4.0 + tpw * c.nch32 * 2.0);
+            if (t < best_t * 0.999) { best_t = t; p.tpw = tpw; }
+        }
+    }
+    if (!fused) return hipSuccess;
+    done = true;
+    if (what == 0) return hipSuccess;
+    ConvLaunch L{c.MW, best.NW, best.WM, best.WN, 1, 2};
+    if (prof) {
+        const double cols = (double)p.T * p.B;
+        const double flops = 2.0 * 2.0 * 3.0 * c.cin * c.cout * cols;      // both convs at the OUTPUT rate, as the reference runs them
+        const double el = (double)c.cin * p.T + (double)c.cin * p.x2_T + 4.0 * c.cout * p.T;   // u1, a | xmid, u2, scale, shift
+        const double bytes = (act_bf16 ? 2.0 : 4.0) * el * p.B + 4.0 * 2.0 * (double)(c.w_floats + c.b_floats);
+        char kname[48];
+        std::snprintf(kname, sizeof(kname), "conv_hx<%d,%d,%d,%d,0,4,%d,%s>", L.MW, L.NW, L.WM, L.WN, p.s2, act_bf16 ? "x1" : "x3");
+        hipError_t e = prof->begin(stream, layer, kname, flops, bytes);
+        if (e != hipSuccess) return e;
+        e = launch(p, L);
+        if (e != hipSuccess) return e;
+        return prof->end();
+    }
+#ifdef FASTSVC_TIMELINE
+    {
+        const int NT = 16 * L.NW * L.WN;
+        const long ntx = (p.T + NT - 1) / NT;
+        const long wgs = ((ntx + p.tpw - 1) / p.tpw) * (long)(c.ngroups / L.WM) * p.B;
+        hipError_t e = hipSuccess;
+        if (timeline_launch(layer, p, wgs, 2 * p.nch32, L, stream, [&](const ConvParams& q) { return launch(q, L); }, e)) return e;
+    }
+#endif
+    return launch(p, L);
 }
 
 // Stage 0 of the conditioning nets as ONE launch (fastsvc_cond.hip): raw signals -> ss.0 and the compact h_0[..., ::s_1].
@@ -2720,6 +2898,20 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
             ph.amax_in = am_x;
             HIP_TRY(run_uphead(u, blob, ph, stream, prof, ("up." + s + ".head").c_str(), head_fused));
         }
+        // xmid = conv_d3(lrelu(norm(u1))) + xr with xr computed INSIDE that launch from `a` (run_d3x) where the variant
+        // exists and the launch table does not say otherwise: the residual conv's launch and the tensor xr then go
+        ConvParams pd3 = base;
+        pd3.x = u1; pd3.x_b = cb; pd3.x_T = (int)Tout; pd3.T = (int)Tout;
+        pd3.flags = pre | aff_out; pd3.st_in = st; pd3.spk = pb;
+        pd3.amax_in = spk ? am_p : nullptr;
+        pd3.no_hx = (!spk && P.storage == 0) ? 1 : 0;
+        pd3.y = xm; pd3.y_b = cb; pd3.y2 = u2; pd3.y2_b = cb;
+        pd3.ss_out = ss; pd3.ss_out_b = 2 * cb; pd3.st_out = st + stn;
+        pd3.x2 = a; pd3.x2_b = (long)u.C * Tin; pd3.x2_T = (int)Tin; pd3.s2 = u.scale;
+        pd3.amax_x2 = am_x; pd3.bnd_x2 = blob + u.first.bnd_off;   // |a| <= l1 |x| + bmax
+        const std::string nd3x = "up." + s + ".d3x";
+        bool d3_fused = false;
+        if (!head_fused) HIP_TRY(run_d3x(u, blob, pd3, stream, nullptr, nd3x.c_str(), 0, 0.0, d3_fused));
         ConvParams p = base;
         if (!head_fused) {
         p = base;                                                  // a = conv_first(x)
@@ -2733,8 +2925,10 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         p.mode = MODE_STRETCH; p.s = u.scale;
         p.y = xr; p.y_b = cb; p.T = (int)Tout;
         p.amax_in = am_x; p.bnd_path[0] = blob + u.first.bnd_off;  // |a| <= l1 |x| + bmax  (xr is only ever a residual: not tracked)
+        if (!d3_fused) {
         HIP_TRY(order_after(stream, s_side));                      // a is ready
         HIP_TRY(run_conv(u.res, blob, p, 1, 0, 0, s_side, prof, ("up." + s + ".res_stretch").c_str()));
+        }
 
         p.flags = F_PRE_LRELU | F_POST_LRELU | aff_out;            // u1 = aff(lrelu(conv_up(stretch(lrelu(a)))))
         p.y = nullptr; p.y2 = u1; p.y2_b = cb;
@@ -2762,10 +2956,41 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         // these three convs on the exact f32-input MFMA kernels instead (float32 storage; bf16 has float32's range)
         p.amax_in = spk ? am_p : nullptr;
         p.no_hx = (!spk && P.storage == 0) ? 1 : 0;
-        HIP_TRY(order_after(s_side, stream));                      // xr is ready
         p.y = xm; p.y_b = cb; p.y2 = u2; p.y2_b = cb;              // and u2 = aff(xmid)
         p.ss_out = ss; p.ss_out_b = 2 * cb; p.st_out = st + stn;
+        if (d3_fused) {
+            bool ran = false;
+            HIP_TRY(run_d3x(u, blob, pd3, stream, prof, nd3x.c_str(), 1, 0.0, ran));
+        } else {
+        HIP_TRY(order_after(s_side, stream));                      // xr is ready
         HIP_TRY(run_conv(u.d3, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d3").c_str()));
+        if (g_tune.tuning && !prof && !head_fused) {
+            // tuning pass: the two separate launches again, timed, then the fused shapes against them
+            ConvParams pr = base;
+            pr.x = a; pr.x_b = (long)u.C * Tin; pr.x_T = (int)Tin;
+            pr.mode = MODE_STRETCH; pr.s = u.scale;
+            pr.y = xr; pr.y_b = cb; pr.T = (int)Tout;
+            pr.amax_in = am_x; pr.bnd_path[0] = blob + u.first.bnd_off;
+            ConvParams pq = p;
+            pq.flags &= ~F_STATS;                                  // (the InstanceNorm sums are accumulated once)
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(FASTSVC_E_HIP, "hipEventCreate");
+            hipEventRecord(e0, stream);
+            int rc = FASTSVC_OK;
+            for (int r = 0; r < 3 && rc == FASTSVC_OK; ++r) {
+                if (run_conv(u.res, blob, pr, 1, 0, 0, stream, nullptr, ("up." + s + ".res_stretch").c_str()) != hipSuccess ||
+                    run_conv(u.d3, blob, pq, 1, 0, 0, stream, nullptr, ("up." + s + ".d3").c_str()) != hipSuccess)
+                    rc = fail(FASTSVC_E_HIP, "timing the separate residual / d3 launches");
+            }
+            hipEventRecord(e1, stream);
+            float ms = 0.f;
+            if (rc == FASTSVC_OK && hipEventSynchronize(e1) == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+            hipEventDestroy(e0); hipEventDestroy(e1);
+            if (rc != FASTSVC_OK) return rc;
+            bool dummy = false;
+            HIP_TRY(run_d3x(u, blob, pd3, stream, nullptr, nd3x.c_str(), 2, ms / 3.0, dummy));
+        }
+        }
         HIP_TRY(exact_stats(u2, st + stn));
 
         p.x = u2; p.st_in = st + stn; p.res = nullptr;             // u3 = aff(conv_d9(lrelu(norm(u2))))

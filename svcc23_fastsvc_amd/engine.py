@@ -305,6 +305,19 @@ class Plan:
 
     def keep_block_heads_separate(self, B: int, F: int) -> None:
         self.fuse_block_heads(B, F, fused=False)
+        self.keep_residual_convs_separate(B, F)
+
+    def keep_residual_convs_separate(self, B: int, F: int) -> None:
+        """By default the stretched residual conv of an up block is folded into the block's d = 3 conv (launch
+        ``up.<i>.d3x``: the tensor ``xr`` is never written).  This keeps the two launches for batches of this shape
+        (algorithm 0 under ``up.<i>.d3x|B|T_out``), so that the ``up.<i>.xr`` workspace taps hold the tensor."""
+        T = F
+        table = {}
+        for i, sc in enumerate(self.cfg.upsampling_scales):
+            T *= int(sc)
+            table[f"up.{i}.d3x|{B}|{T}"] = [2, 1, 4, 1, 0]
+            table[f"up.{i}.d3x|{B}|{T}|b"] = [2, 1, 4, 1, 0]
+        self.load_tuned(table)
 
     def load_tuned_file(self, path: str, missing_ok: bool = False) -> int:
         """Load this configuration's section of a tuned-shape JSON file (tools/tune_shapes.py)."""

@@ -316,8 +316,8 @@ def test_profile_records_cover_every_launch(dev):
     recs = []
     y = plan.forward(blob, *_to(dev, b.ppg, b.sine, b.lft, b.spk_emb), profile=recs)
     # launch_count is the unfused schedule; fused launches save up to 2 (stage 0) + 1 per stage (c2 -> c3) + 1 per
-    # stage (FiLM conv -> heads) + 1 (conv_last)
-    assert plan.launch_count(True) - (2 * cfg.n_stages + 2) <= len(recs) <= plan.launch_count(True)
+    # stage (FiLM conv -> heads) + 1 per block (the residual conv inside the d = 3 launch) + 1 (conv_last)
+    assert plan.launch_count(True) - (3 * cfg.n_stages + 2) <= len(recs) <= plan.launch_count(True)
     assert all(r["ms"] > 0 for r in recs)
     total = sum(r["flops"] for r in recs)
     assert abs(total / (2 * 20 * 160) / plan.flops_per_sample - 1) < 0.02
@@ -764,7 +764,8 @@ def test_half_precision_and_f32_mfma_families_agree(dev):
         sorted((r["layer"], r["kernel"]) for r in recs)
     p_32 = A.Plan(cfg, load_shipped_table=False)
     layers = {r["layer"] for r in recs} | {f"down.{k}.{c}" for k in range(cfg.n_stages) for c in ("c2_d2", "c3_d4", "c23")} | \
-             {f"film.{k}.{c}" for k in range(cfg.n_stages) for c in ("conv", "heads", "chain")}
+             {f"film.{k}.{c}" for k in range(cfg.n_stages) for c in ("conv", "heads", "chain")} | \
+             {f"up.{i}.{c}" for i in range(cfg.n_stages) for c in ("res_stretch", "d3")}     # (folded into up.<i>.d3x on the other plan)
     p_32.load_tuned({f"{layer}|{B}|{t}": [1, 1, 4, 1, 0] for layer in layers
                      for t in (F, 2 * F, 8 * F, 32 * F, 160 * F)})          # algo 0 = the f32-input MFMA kernels, unfused
     ws_32 = torch.zeros(p_32.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
@@ -1023,3 +1024,74 @@ def test_layer_pipelines_vs_oracle_phase_kernel_and_themselves(dev, storage):
             assert torch.equal(yp, yq)
         else:
             assert all(torch.equal(a_, b_) for a_, b_ in zip(cur, first))
+
+
+@pytest.mark.parametrize("storage", ["float32", "bfloat16"])
+def test_residual_conv_folded_into_d3(dev, storage):
+    """The stretched residual conv of every up block (fastsvc.py:72-75,94-100: xmid = conv_d3(lrelu(norm(u1))) +
+    conv_res(stretch(a))) runs INSIDE the block's d = 3 launch (`up.<i>.d3x`, ConvParams::x2: a second, stretched operand
+    accumulated with the main conv): the tensor xr is never written.  xmid / u2 / out taps and the waveform against the
+    oracle (float32) and against the separate launches (both storages), the InstanceNorm sums, a ragged batch against
+    every utterance alone."""
+    O = _oracle()
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 91)
+    B, F = 3, 52
+    b = S.synth_batch(cfg, B, F, 92)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    fused, sep = A.Plan(cfg, storage=storage), A.Plan(cfg, storage=storage)
+    for pl in (fused, sep):
+        pl.keep_last_block_output(B, F)
+    sep.keep_residual_convs_separate(B, F)
+    blob = fused.pack(sd).to(dev)
+    ref, taps = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb, return_taps=True)
+    ws_f = torch.zeros(fused.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    ws_s = torch.zeros(sep.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    recs, recs_s = [], []
+    y_f = fused.forward(blob, *ins, workspace=ws_f, profile=recs)
+    y_s = sep.forward(blob, *ins, workspace=ws_s, profile=recs_s)
+    torch.cuda.synchronize()
+    layers = {r["layer"]: r["kernel"] for r in recs}
+    for i, s in enumerate(cfg.upsampling_scales):
+        # conv_hx<MW,NW,WM,WN,mode 0,FiLM-affine epilogue 4,stretch factor,..>
+        assert layers[f"up.{i}.d3x"].split(",")[4:7] == ["0", "4", str(s)], layers
+        assert f"up.{i}.res_stretch" not in layers and f"up.{i}.d3" not in layers
+        assert f"up.{i}.res_stretch" in {r["layer"] for r in recs_s}
+    scale = max(1.0, float(ref.abs().max()))
+    if storage == "float32":
+        assert float((y_f.cpu() - ref).abs().max()) <= TIGHT * scale
+        assert float((y_f - y_s).abs().max()) <= 2e-5 * scale
+    else:
+        # bfloat16 storage rounds xmid once in both routes but accumulates the two convs in a different order in front
+        # of that rounding: the two waveforms differ like two bfloat16 runs do (mean-abs 1e-2 class)
+        d = (y_f - y_s).abs()
+        assert float(d.mean()) <= 1e-2 and float(d.max()) <= 0.2
+        assert float((y_f.cpu() - ref).abs().mean()) <= 2e-2
+    for i in range(cfg.n_stages):
+        for name in ("xmid", "u2", "out"):
+            got, want = fused.tap(f"up.{i}.{name}", B, F, ws_f).float().cpu(), taps[f"up.{i}.{name}"]
+            other = sep.tap(f"up.{i}.{name}", B, F, ws_s).float().cpu()
+            mag = max(1.0, float(want.abs().max()))
+            if storage == "float32":
+                assert float((got - want).abs().max()) <= TIGHT * mag, (i, name)
+                assert float((got - other).abs().max()) <= 2e-5 * mag, (i, name)
+            else:
+                assert float((got - want).abs().max()) <= 6e-2 * mag, (i, name)
+                assert float((got - other).abs().max()) <= 4e-2 * mag, (i, name)
+        if storage == "float32":
+            st_f = fused.tap(f"up.{i}.stats", B, F, ws_f)[:3 * B].cpu()
+            st_s = sep.tap(f"up.{i}.stats", B, F, ws_s)[:3 * B].cpu()
+            # (sums of u2 / u3 sit behind xmid: float32 partial sums over tensors that differ in the last bits)
+            assert float(((st_f - st_s).abs() / (st_s.abs() + 1.0)).max()) <= 1e-4
+    # ragged: every utterance exactly what it is alone (lengths a multiple of 4: the bfloat16 route's unpadded form)
+    lengths = [52, 28, 12]
+    y_r = fused.forward(blob, *ins, lengths=lengths)
+    for j, n in enumerate(lengths):
+        alone = fused.forward(blob, ins[0][j:j + 1, :, :n].contiguous(), ins[1][j:j + 1, :, :n * cfg.hop].contiguous(),
+                              ins[2][j:j + 1, :, :n * cfg.hop].contiguous(), ins[3][j:j + 1])
+        tol = 2e-5 * scale if storage == "float32" else 0.2
+        assert float((y_r[j:j + 1, :, :n * cfg.hop] - alone).abs().max()) <= tol, (j, n)
+        if storage == "bfloat16":
+            assert float((y_r[j:j + 1, :, :n * cfg.hop] - alone).abs().mean()) <= 1e-2
+        if n < F:
+            assert float(y_r[j, :, n * cfg.hop:].abs().max()) == 0.0

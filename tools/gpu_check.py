@@ -15,6 +15,7 @@ def check(cfg, B, F, seed_w, seed_x, with_spk=True, verbose=True):
     b = S.synth_batch(cfg, B, F, seed_x)
     plan = A.Plan(cfg)
     plan.keep_last_block_output(B, F)
+    plan.keep_residual_convs_separate(B, F)           # (the `up.k.xr` taps)
     blob = plan.pack(sd).to(dev)
     ws = torch.zeros(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
     args = [torch.from_numpy(a).to(dev) for a in (b.ppg, b.sine, b.lft)]

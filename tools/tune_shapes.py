@@ -21,6 +21,8 @@ cfg = S.FULL_CONFIG
 dev = torch.device("cuda:0")
 COMPACT = os.environ.get("TUNE_COMPACT", "1") != "0"        # the layout the module and bench.py run (whole-stage conditioning launches, compact decimated inputs)
 ROUNDS = int(os.environ.get("TUNE_ROUNDS", "3"))          # independent tunings per workload; the table that runs the whole forward fastest is kept
+# TUNE_INCREMENTAL=1: start from the shipped table and tune only the keys it lacks (a new fused variant's entries)
+INCREMENTAL = os.environ.get("TUNE_INCREMENTAL", "0") != "0"
 sig = None
 table = {}
 
@@ -53,17 +55,21 @@ for name in names:
     for rnd in range(ROUNDS):
         votes = collections.defaultdict(collections.Counter)
         for rep in range(REPS):
-            plan = A.Plan(cfg, load_shipped_table=False, storage=storage, compact_workspace=COMPACT)
+            plan = A.Plan(cfg, load_shipped_table=INCREMENTAL, storage=storage, compact_workspace=COMPACT)
+            shipped = dict(plan.tuned_shapes()) if INCREMENTAL else {}
             sig = plan.config_signature()
             blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
             ws = torch.empty(plan.workspace_bytes(wl["B"], wl["F"]), dtype=torch.uint8, device=dev)
             plan.forward(blob, *ins, workspace=ws)
             plan.forward(blob, *ins, workspace=ws, autotune=True)
             for k, v in plan.tuned_shapes().items():
-                votes[k][tuple(v)] += 1
+                if k not in shipped:
+                    votes[k][tuple(v)] += 1
         cand = {k: list(c.most_common(1)[0][0]) for k, c in sorted(votes.items())}
-        plan = A.Plan(cfg, load_shipped_table=False, storage=storage, compact_workspace=COMPACT)
+        plan = A.Plan(cfg, load_shipped_table=INCREMENTAL, storage=storage, compact_workspace=COMPACT)
         plan.load_tuned(cand)
+        if INCREMENTAL:
+            print(f"   new entries: {cand}", file=sys.stderr)
         ms = time_forward(plan, blob, ins, ws)
         print(f"{name} ({storage}) tuning {rnd}: {plan.last_autotune_trials or ''} forward {ms:.4f} ms", file=sys.stderr)
         if ms < best[0]:
