@@ -382,10 +382,10 @@ __device__ __forceinline__ f32x8 bf8_unpack(u32x4 w) {
 }
 __device__ __forceinline__ u32x4 bf8_pack(const f32x8& v) {
     u32x4 w;
-    w.x = f32_to_bf16_bits(v.lo.x) | (f32_to_bf16_bits(v.lo.y) << 16);
-    w.y = f32_to_bf16_bits(v.lo.z) | (f32_to_bf16_bits(v.lo.w) << 16);
-    w.z = f32_to_bf16_bits(v.hi.x) | (f32_to_bf16_bits(v.hi.y) << 16);
-    w.w = f32_to_bf16_bits(v.hi.z) | (f32_to_bf16_bits(v.hi.w) << 16);
+    w.x = bf16_pack2(v.lo.x, v.lo.y);
+    w.y = bf16_pack2(v.lo.z, v.lo.w);
+    w.z = bf16_pack2(v.hi.x, v.hi.y);
+    w.w = bf16_pack2(v.hi.z, v.hi.w);
     return w;
 }
 // boff: BYTE offset of the lane's first element inside the descriptor
@@ -464,7 +464,9 @@ __device__ __forceinline__ void hx_epilogue8_stage(const ConvParams& p, const Ep
 
 // TAILK (see conv_hx_kernel): rows may end inside a group of 4 - the straddling group is stored whole (the pitch is
 // a multiple of 4) and only the InstanceNorm sums are masked element by element
-template <int MW, int NP2, int EPI, bool EST, bool TAILK = false, class KT>
+// LRB: the LeakyReLU behind a wave-uniform branch (the middle convs of the up blocks have none: 32 instructions per
+// item less); off where the branch costs the instance its register budget
+template <int MW, int NP2, int EPI, bool EST, bool TAILK = false, bool LRB = true, class KT>
 __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[2 * NP2][MW],
                                              float (&s1)[MW], float (&s2)[MW], int sig, int mg, int tcol0,
                                              bool active, int lane, const KT& K, const float* Ew, float* Xw) {
@@ -520,8 +522,10 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
             for (int g = 0; g < G; ++g) {
                 f32x8 v = hx_pair(acc[2 * (k0 + g)][m], acc[2 * (k0 + g) + 1][m], Xw, lane);
                 v.lo += bias; v.hi += bias;
-                #pragma unroll
-                for (int e = 0; e < 4; ++e) { v.lo[e] = fmaxf(v.lo[e], v.lo[e] * slope); v.hi[e] = fmaxf(v.hi[e], v.hi[e] * slope); }
+                if (!LRB || (p.flags & F_POST_LRELU)) {            // (wave-uniform)
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e) { v.lo[e] = fmaxf(v.lo[e], v.lo[e] * slope); v.hi[e] = fmaxf(v.hi[e], v.hi[e] * slope); }
+                }
                 if (EPI == EPI_RES || EPI == EPI_AFF) { v.lo += l0[g].lo; v.hi += l0[g].hi; }
                 if (EPI == EPI_RANK1) { v.lo += l0[g].lo * r1w + r1b; v.hi += l0[g].hi * r1w + r1b; }
                 acc[2 * (k0 + g)][m] = v.lo; acc[2 * (k0 + g) + 1][m] = v.hi;     // (finished values, in the pair layout)
@@ -684,8 +688,8 @@ __device__ __forceinline__ void hx_epilogue_poly_staged(const ConvParams& p, con
             #pragma unroll
             for (int q = 0; q < S; ++q) {                   // 4 S samples = S pieces of 8 bytes
                 u32x2v w;
-                w.x = f32_to_bf16_bits(phase_value(4 * q)) | (f32_to_bf16_bits(phase_value(4 * q + 1)) << 16);
-                w.y = f32_to_bf16_bits(phase_value(4 * q + 2)) | (f32_to_bf16_bits(phase_value(4 * q + 3)) << 16);
+                w.x = bf16_pack2(phase_value(4 * q), phase_value(4 * q + 1));
+                w.y = bf16_pack2(phase_value(4 * q + 2), phase_value(4 * q + 3));
                 *reinterpret_cast<u32x2v*>(dst + q * 8) = w;
             }
         }
@@ -750,8 +754,8 @@ __device__ __forceinline__ void hx_epilogue_dec2_staged(const ConvParams& p, con
             unsigned char* dst = Pw + (m * 16 + (lane & 15)) * PB + (n * 16 + (lane >> 4) * 4) * 2;
             const f32x4 a = KT::finish(acc[0][n][m], iv, bias), b = KT::finish(acc[1][n][m], iv2, bias2);
             u32x2v wa, wb;
-            wa.x = f32_to_bf16_bits(a.x) | (f32_to_bf16_bits(a.y) << 16); wa.y = f32_to_bf16_bits(a.z) | (f32_to_bf16_bits(a.w) << 16);
-            wb.x = f32_to_bf16_bits(b.x) | (f32_to_bf16_bits(b.y) << 16); wb.y = f32_to_bf16_bits(b.z) | (f32_to_bf16_bits(b.w) << 16);
+            wa.x = bf16_pack2(a.x, a.y); wa.y = bf16_pack2(a.z, a.w);
+            wb.x = bf16_pack2(b.x, b.y); wb.y = bf16_pack2(b.z, b.w);
             *reinterpret_cast<u32x2v*>(dst) = wa;
             *reinterpret_cast<u32x2v*>(dst + TB) = wb;
         }
@@ -815,6 +819,11 @@ constexpr bool hx_est2() { return hx_estage<MW, NW, MODE, EPI>() && MW * NW <= 4
 
 template <int MW, int NW, int MODE, int EPI, int S = 1>
 constexpr int hx_min_waves() {
+#ifdef FASTSVC_ACT_BF16
+    // ... and the C = 24 middle conv with its second operand (bfloat16 storage): it sits at the edge of the budget, and
+    // past it the CU holds one workgroup instead of two (measured 948 -> 1147 us at 64 x 240000)
+    if (MODE == MODE_DIRECT && MW == 2 && NW == 2 && EPI == EPI_AFF && S > 1) return 4;     // (it fits without a spill: checked)
+#endif
 
     // 128 VGPRs = two 8-wave workgroups per CU (one computes while the other stores: the C = 24 layers are
     // bound by their store phase) where the producers' two register sets (2 x 32), the unit-deep weight ring
@@ -946,8 +955,8 @@ void conv_hx_kernel(const ConvParams p0) {
         }
     }
     double* sstat = reinterpret_cast<double*>(smem_raw);                               // [WM*MW*16][2]
-    float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);   // [CINp]
-    unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp);             // [2][HX_NP][W rows][64 B]
+    float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);   // [CINp + 8]: the last 8 are (0, 0)
+    unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp + 8);         // [2][HX_NP][W rows][64 B]
     // small per-workgroup constants (static LDS; HX_STATIC_LDS bounds them for the launcher's size checks)
     __shared__ unsigned s_amax, s_cnt;                 // workgroup's largest |value| written (ConvParams::amax_out), waves done
     __shared__ float s_inv[HX_NP == 2 ? 2 * 16 * MW * WM : 4];        // inverse operand scales [conv | second DEC2 output][channel]
@@ -1070,6 +1079,7 @@ void conv_hx_kernel(const ConvParams p0) {
             }
             ncoef[c] = ab;
         }
+        if (c < 8) ncoef[CINp + c] = make_float2(0.f, 0.f);       // what an item outside the utterance is staged with
         __syncthreads();
     };
 
@@ -1189,20 +1199,22 @@ void conv_hx_kernel(const ConvParams p0) {
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 // (A, Bc) of the item's 8 channels: 64 contiguous bytes
-                const f32x4* cf = reinterpret_cast<const f32x4*>(ncoef + ch * HX_KC + it_oct[i] * 8);
-                const f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
-                const float A[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
-                float Bc[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
-                // rows outside the utterance are the conv's zero padding AFTER the prologue: their loads
-                // returned 0, so only the additive term has to go
+                // rows outside the utterance are the conv's zero padding AFTER the prologue: their loads returned 0, so
+                // only the additive term has to go - such an item reads the (0, 0) coefficients behind the table (one
+                // select on the address instead of eight on the values: the staging waves' instruction count bounds
+                // the narrow layers)
                 const int nvi = TAILK ? (int)((tokmask >> (3 * i)) & 7u) : (int)((tokmask >> i) & 1u);
                 const bool tok = nvi != 0;
-                #pragma unroll
-                for (int c = 0; c < 8; ++c) Bc[c] = tok ? Bc[c] : 0.f;
+                const f32x4* cf = reinterpret_cast<const f32x4*>(ncoef + (tok ? ch * HX_KC + it_oct[i] * 8 : CINp));
+                const f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+                const float A[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
+                const float Bc[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
                 // one time step (= one 16-byte slot of 8 channels per piece) at a time: the transformed values
                 // never exist as a second copy of the register set (two steps at a time - the prologue FMA and the
                 // LeakyReLU multiply as packed float32 operations on (t, t+1) - saves 0.75 instructions per value and was
-                // measured SLOWER: cfg2 1.412 vs 1.388 ms)
+                // measured SLOWER in float32 storage: cfg2 1.412 vs 1.388 ms; in bfloat16 storage (round 5) it took 1 % off
+                // the C = 24 layers and made up.0.d27 differ from run to run - v_pk_fma_f32 / v_pk_mul_f32 behind the
+                // window loads, cause not found - and was dropped)
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float e[8];
@@ -1659,7 +1671,7 @@ void conv_hx_kernel(const ConvParams p0) {
                         for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
                         if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC); }
 #ifdef FASTSVC_ACT_BF16
-                        if constexpr (PAIRS) hx_epilogue8<MW, NW / 2, EPI, EST, false>(p, R, acc, s1, s2, sig, mg, tcolw, active, lane, K, Ew, Xw);
+                        if constexpr (PAIRS) hx_epilogue8<MW, NW / 2, EPI, EST, false, false>(p, R, acc, s1, s2, sig, mg, tcolw, active, lane, K, Ew, Xw);
                         else
 #endif
                         ws_epilogue_kind<MW, NW, EPI, EST, 0, -1>(p, R, acc, s1, s2, sig, mg, tcolw, active, lane, K, Ew);
@@ -1843,7 +1855,7 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
     constexpr bool CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1 || MODE == MODE_UPHEAD;
     const int halo_al = (MODE == MODE_DIRECT || CHAIN) ? ((p.dil + 3) & ~3) : 4;
     const int W = NT + (CHAIN ? 16 : 0) + 2 * halo_al;
-    const size_t smem = sizeof(double) * 2 * 16 * MW * WM + sizeof(float) * 2 * (size_t)p.nch32 * HX_KC +
+    const size_t smem = sizeof(double) * 2 * 16 * MW * WM + sizeof(float) * 2 * ((size_t)p.nch32 * HX_KC + 8) +
                         (size_t)2 * (MODE == MODE_DEC2 ? 2 : 1) * HX_NP * (W + 4) * HX_ROW +
                         (CHAIN ? (size_t)(MODE == MODE_UPHEAD ? 2 : 1) * p.nch32b * HX_NP * (NT + 16) * HX_ROW : 0);
     const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
@@ -1953,6 +1965,9 @@ hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_
     } else if (p.mode == MODE_DEC2) {
         if (p.dil != 1 || !p.bias2 || !p.y2) return hipErrorInvalidValue;
         FASTSVC_HXS(MODE_DEC2, 3, 2, 1, 4) FASTSVC_HXS(MODE_DEC2, 3, 3, 1, 4) FASTSVC_HXS(MODE_DEC2, 3, 2, 2, 2)
+        // every channel group of a C_out = 96 / 192 stage in ONE workgroup: the two staged windows (LeakyReLU'd and raw)
+        // serve 2 / 4 times the matrix work, and the input is fetched once instead of once per channel group
+        FASTSVC_HXS(MODE_DEC2, 3, 4, 2, 2) FASTSVC_HXS(MODE_DEC2, 3, 4, 4, 1)
     }
 #undef FASTSVC_HXS
     return hipErrorInvalidValue;
@@ -1967,7 +1982,8 @@ bool conv_hx_shape(int mode, int MW, int NW, int WM, int WN) {
         return (MW == 2 && WM == 1 && WN == 4 && (NW == 2 || NW == 3)) ||
                (MW == 3 && NW == 2 && ((WM == 1 && WN == 4) || (WM == 2 && WN == 2)));
     if (mode == MODE_DEC2)
-        return MW == 3 && ((WM == 1 && WN == 4 && (NW == 2 || NW == 3)) || (WM == 2 && WN == 2 && NW == 2));
+        return MW == 3 && ((WM == 1 && WN == 4 && (NW == 2 || NW == 3)) || (WM == 2 && WN == 2 && (NW == 2 || NW == 4)) ||
+                           (WM == 4 && WN == 1 && NW == 4));
     if (mode == MODE_CHAIN1) return MW == 2 && WM == 1 && WN == 4 && (NW == 2 || NW == 3);
     if (mode == MODE_UPHEAD)
         return (MW == 3 && ((NW == 4 && WM == 4 && WN == 1) || (NW == 2 && WM == 2 && WN == 2) || (NW == 2 && WM == 1 && WN == 4))) ||

@@ -1285,10 +1285,10 @@ void in1_conv_kernel(const float* __restrict__ x, long x_sig, const float* __res
 #ifdef FASTSVC_ACT_BF16
         if (full) {
             u32x4 q;
-            q.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-            q.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
-            q.z = f32_to_bf16_bits(o[4]) | (f32_to_bf16_bits(o[5]) << 16);
-            q.w = f32_to_bf16_bits(o[6]) | (f32_to_bf16_bits(o[7]) << 16);
+            q.x = bf16_pack2(o[0], o[1]);
+            q.y = bf16_pack2(o[2], o[3]);
+            q.z = bf16_pack2(o[4], o[5]);
+            q.w = bf16_pack2(o[6], o[7]);
             *reinterpret_cast<u32x4*>(yr) = q;
         } else {
             for (int i = 0; i < SPT && t + i < T; ++i) yr[i] = (act_t)f32_to_bf16_bits(o[i]);

@@ -2142,7 +2142,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         const bool hx_ok = hx_env != 0 && !p.no_hx && !g_exact_f32 && c.hx && hx_mode && c.ntaps == 3 && (p.T & 3) == 0 &&
                            c.dil <= 28 && !(p.flags & F_PRE_AFFINE) && hx_tail_ok;
         if (hx_ok) {
-            static const int shapes[][3] = {{8, 4, 1}, {6, 2, 2}, {4, 2, 2}, {2, 2, 2}, {3, 1, 4}, {2, 1, 4}};
+            static const int shapes[][3] = {{8, 4, 1}, {4, 4, 1}, {6, 2, 2}, {4, 2, 2}, {2, 2, 2}, {3, 1, 4}, {2, 1, 4}};
             for (const auto& sh : shapes)
                 if (conv_hx_shape(p.mode, c.MW, sh[0], sh[1], sh[2]) && c.ngroups % sh[1] == 0 &&
                     !(p.mode == MODE_DIRECT && epi_kind >= 3 && sh[0] * c.MW > 12))   // FiLM-affine / rank-1 epilogues: those tiles spill

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""GPU-box diagnostic: run the same forward several times and report which workspace taps differ between runs
+(bfloat16 storage: a tensor that differs points at a race; float32 storage differs in the last bits behind the
+float64 InstanceNorm atomics by design)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import svcc23_fastsvc_amd as A
+from svcc23_fastsvc_amd import synth as S
+
+cfg = S.FULL_CONFIG
+dev = torch.device("cuda:0")
+B, F = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 600
+storage = sys.argv[3] if len(sys.argv) > 3 else "bfloat16"
+plan = A.Plan(cfg, storage=storage)
+plan.keep_last_block_output(B, F)
+if os.environ.get("SEPARATE"):
+    plan.keep_residual_convs_separate(B, F)
+blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
+ins = list(S.device_batch(cfg, B, F, 4321, dev))
+ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+names = [f"up.{i}.{t}" for i in range(cfg.n_stages) for t in ("a", "u1", "xmid", "u2", "u3", "out", "stats")]
+first = None
+for r in range(6):
+    ws.fill_(0xFF)
+    y = plan.forward(blob, *ins, workspace=ws)
+    torch.cuda.synchronize()
+    cur = {n: plan.tap(n, B, F, ws).clone() for n in names}
+    cur["y"] = y.clone()
+    if first is None:
+        first = cur
+        continue
+    bad = [(n, int((cur[n] != first[n]).sum())) for n in cur if not torch.equal(cur[n], first[n])]
+    print(f"run {r}: differing tensors: {bad}")
