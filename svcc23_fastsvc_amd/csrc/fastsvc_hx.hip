@@ -632,45 +632,19 @@ __device__ __forceinline__ void hx_epilogue_poly8(const ConvParams& p, const Epi
 // row-major: four lanes = 64 contiguous bytes of a row, sixteen rows per instruction, for the scale / shift loads, the
 // affine, its InstanceNorm sums and both stores.  LDS executes a wave's accesses in order: no barrier, a wave fence.
 template <int MW, int NW, int S> constexpr int hx_poly_patch_bytes() { return MW * 16 * (NW * 16 * S * 2 + 16); }
-template <int MW, int NW, int EPI, int S, class KT>
-__device__ __forceinline__ void hx_epilogue_poly_staged(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[3][NW][MW],
-                                                        float (&s1)[MW], float (&s2)[MW], int mg, int tcol0, bool active, int lane,
-                                                        const KT& K, unsigned char* Pw) {
-    if (!active) return;
+// The staged epilogue runs in two passes and the second one needs nothing but the patch: the consumer wave converts its
+// finished tile into the patch (pass 1) and, behind a workgroup barrier, takes the first channel tile of the row-major
+// pass while its STAGING partner (wave + 4, idle by then: timeline of up.3.up_stretch - 10.7k of 13.5k cycles per tile in
+// this epilogue, the staging waves 76 % of theirs at the barrier) takes the others.
+// channel tiles the consumer keeps in pass 2
+template <int MW> constexpr int hx_poly_mc() { return 1; }
+
+template <int MW, int NW, int S, class KT>
+__device__ __forceinline__ void hx_poly_pass1(const ConvParams& p, const f32x4 (&acc)[3][NW][MW], int mg, int lane, const KT& K,
+                                              unsigned char* Pw) {
     constexpr int NC = NW * 16 * S;                         // output samples per row of this wave's tile
     constexpr int PB = NC * 2 + 16;                         // patch row pitch, bytes
-    constexpr int NCH = (NC + 31) / 32;                     // 64-byte chunks per row
     const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
-    const int T_out = p.ldy;
-    const int shift_soff = p.COUT * T_out * 2;             // bytes
-    // the row-major pass's operands: requested FIRST where they fit the registers (MW * NCH <= 10 pieces of scale and shift
-    // each: their round trip then runs under the conversion and the LDS writes - one workgroup per CU, four consumer waves,
-    // nothing else hides it: up.3 691 -> 626 us), else row tile by row tile inside the pass (three channel tiles at once
-    // spilled: up.2 264 -> 350 us)
-    constexpr bool HOIST = MW * NCH <= 10;
-    const int rsub = lane >> 2, piece = lane & 3;
-    const int ncv = max(0, min(NW * 16, p.T - tcol0)) * S;  // valid output samples of a row of this tile
-    f32x8 l1[HOIST ? MW : 1][NCH], l2[HOIST ? MW : 1][NCH];
-    int off[HOIST ? MW : 1][NCH], nv[HOIST ? MW : 1][NCH];
-    auto request = [&](int m, int slot) {
-        const int cot = (mg * MW + m) * 16 + rsub;
-        const bool cok = cot < p.COUT;
-        const int rowb = ((cok ? cot : 0) * T_out + tcol0 * S) * 2;
-        #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int col = c * 32 + piece * 8;
-            nv[slot][c] = (cok && col < NC) ? max(0, min(8, ncv - col)) : 0;
-            off[slot][c] = nv[slot][c] > 0 ? rowb + col * 2 : OOB_OFF;
-            if (EPI == EPI_AFF) {
-                l1[slot][c] = act_load8(R.ss, off[slot][c], 0);
-                l2[slot][c] = act_load8(R.ss, off[slot][c], shift_soff);
-            }
-        }
-    };
-    if constexpr (HOIST) {
-        #pragma unroll
-        for (int m = 0; m < MW; ++m) request(m, m);
-    }
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const float bias = K.bias(p, 0, m, (mg * MW + m) * 16 + (lane & 15));
@@ -694,44 +668,78 @@ __device__ __forceinline__ void hx_epilogue_poly_staged(const ConvParams& p, con
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const unsigned char* src = Pw + (m * 16 + rsub) * PB + piece * 16;
-        float a1 = 0.f, a2 = 0.f;
-        const int sl = HOIST ? m : 0;
-        if constexpr (!HOIST) request(m, 0);
+}
+
+// pass 2 over the channel tiles [M0, M1): a lane owns 16 bytes (8 samples) of a row per 64-byte chunk.  request(): the
+// scale / shift operands, issued ahead (the consumer's in front of its pass 1, the staging partner's in front of the
+// barrier) where they fit the registers, else row tile by row tile inside run().
+template <int MW, int NW, int EPI, int S, int M0, int M1>
+struct HxPolyPass2 {
+    static constexpr int NC = NW * 16 * S, PB = NC * 2 + 16, NCH = (NC + 31) / 32, NM = M1 - M0;
+    static constexpr bool HOIST = NM * NCH <= 10;
+    f32x8 l1[HOIST ? NM : 1][NCH], l2[HOIST ? NM : 1][NCH];
+    int off[HOIST ? NM : 1][NCH], nv[HOIST ? NM : 1][NCH];
+    __device__ __forceinline__ void fetch(const ConvParams& p, const EpiRsrc& R, int mg, int tcol0, int lane, int m, int slot) {
+        const int rsub = lane >> 2, piece = lane & 3;
+        const int T_out = p.ldy;
+        const int shift_soff = p.COUT * T_out * 2;         // bytes
+        const int ncv = max(0, min(NW * 16, p.T - tcol0)) * S;  // valid output samples of a row of this tile
+        const int cot = (mg * MW + m) * 16 + rsub;
+        const bool cok = cot < p.COUT;
+        const int rowb = ((cok ? cot : 0) * T_out + tcol0 * S) * 2;
         #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int col = c * 32 + piece * 8;
-            f32x8 v = bf8_unpack(*reinterpret_cast<const u32x4*>(src + (col < NC ? c * 64 : 0)));
-            const int nvs = min(8, (nv[sl][c] + 3) & ~3);    // (ragged rows: the straddling group of 4 is stored whole)
-            act_store8(R.y, off[sl][c], v, nvs);             // dropped when y is absent
+            nv[slot][c] = (cok && col < NC) ? max(0, min(8, ncv - col)) : 0;
+            off[slot][c] = nv[slot][c] > 0 ? rowb + col * 2 : OOB_OFF;
             if (EPI == EPI_AFF) {
-                f32x8 u;
-                u.lo = l1[sl][c].lo * v.lo + l2[sl][c].lo; u.hi = l1[sl][c].hi * v.hi + l2[sl][c].hi;
-                u = keep8_exact(u, nv[sl][c]);
-                act_store8(R.y2, off[sl][c], u, nvs);
-                a1 += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
-                a2 += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
-                      ((u.hi.x * u.hi.x + u.hi.y * u.hi.y) + (u.hi.z * u.hi.z + u.hi.w * u.hi.w));
+                l1[slot][c] = act_load8(R.ss, off[slot][c], 0);
+                l2[slot][c] = act_load8(R.ss, off[slot][c], shift_soff);
             }
         }
-        if (EPI == EPI_AFF) {
-            // the caller folds s1 / s2 over the lane >> 4 groups and takes channel lane & 15 from lanes 0..15: hand the row
-            // sums over in that layout (row r lives in lanes 4 r .. 4 r + 3 here)
-            a1 += __shfl_xor(a1, 1); a2 += __shfl_xor(a2, 1);
-            a1 += __shfl_xor(a1, 2); a2 += __shfl_xor(a2, 2);
-            const float r1 = __shfl(a1, 4 * (lane & 15)), r2 = __shfl(a2, 4 * (lane & 15));
-            if (lane < 16) { s1[m] += r1; s2[m] += r2; }
+    }
+    __device__ __forceinline__ void request(const ConvParams& p, const EpiRsrc& R, int mg, int tcol0, int lane) {
+        if constexpr (HOIST) {
+            #pragma unroll
+            for (int m = M0; m < M1; ++m) fetch(p, R, mg, tcol0, lane, m, m - M0);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+    __device__ __forceinline__ void run(const ConvParams& p, const EpiRsrc& R, const unsigned char* Pw, float (&s1)[MW], float (&s2)[MW],
+                                        int mg, int tcol0, int lane) {
+        const int rsub = lane >> 2, piece = lane & 3;
+        #pragma unroll
+        for (int m = M0; m < M1; ++m) {
+            const unsigned char* src = Pw + (m * 16 + rsub) * PB + piece * 16;
+            float a1 = 0.f, a2 = 0.f;
+            const int sl = HOIST ? m - M0 : 0;
+            if constexpr (!HOIST) fetch(p, R, mg, tcol0, lane, m, 0);
+            #pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = c * 32 + piece * 8;
+                f32x8 v = bf8_unpack(*reinterpret_cast<const u32x4*>(src + (col < NC ? c * 64 : 0)));
+                const int nvs = min(8, (nv[sl][c] + 3) & ~3);    // (ragged rows: the straddling group of 4 is stored whole)
+                act_store8(R.y, off[sl][c], v, nvs);             // dropped when y is absent
+                if (EPI == EPI_AFF) {
+                    f32x8 u;
+                    u.lo = l1[sl][c].lo * v.lo + l2[sl][c].lo; u.hi = l1[sl][c].hi * v.hi + l2[sl][c].hi;
+                    u = keep8_exact(u, nv[sl][c]);
+                    act_store8(R.y2, off[sl][c], u, nvs);
+                    a1 += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
+                    a2 += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
+                          ((u.hi.x * u.hi.x + u.hi.y * u.hi.y) + (u.hi.z * u.hi.z + u.hi.w * u.hi.w));
+                }
+            }
+            if (EPI == EPI_AFF) {
+                // the caller folds s1 / s2 over the lane >> 4 groups and takes channel lane & 15 from lanes 0..15: hand the row
+                // sums over in that layout (row r lives in lanes 4 r .. 4 r + 3 here)
+                a1 += __shfl_xor(a1, 1); a2 += __shfl_xor(a2, 1);
+                a1 += __shfl_xor(a1, 2); a2 += __shfl_xor(a2, 2);
+                const float r1 = __shfl(a1, 4 * (lane & 15)), r2 = __shfl(a2, 4 * (lane & 15));
+                if (lane < 16) { s1[m] += r1; s2[m] += r2; }
+            }
+        }
+    }
+};
 // The decimating pair's two outputs (c1 and the 1x1 residual r) the same way: ws_epilogue_dec2 stores 8-byte pieces, sixteen
 // rows x four pieces per instruction and tensor - the pairs ran at 8-10 % matrix-pipe occupancy, 5 k of 6 k cycles per unit outside
 // the matrix work.  Both finished tiles go to the wave's LDS patch and leave row-major: NW * 32 contiguous bytes per row.
@@ -1321,6 +1329,50 @@ void conv_hx_kernel(const ConvParams p0) {
                 stamp(6);
             }
         } else {
+        // staged polyphase epilogue: this staging wave runs pass 2 for the channel tiles its consumer partner (wave - 4)
+        // leaves it (HxPolyPass2) - descriptors, group and statistics as the consumer has them
+        constexpr bool PSPLIT = POLY && hx_poly_staged<MW, NW, MODE, EPI, S>();
+        EpiRsrc Rp;
+        const bool pact = mg < p.ngroups;
+        if constexpr (PSPLIT) {
+            const long ct = (long)p.COUT * p.ldy;
+            const float* nul = p.bias;
+            Rp.y = act_rsrc(p.y ? p.y : nul, p.y ? (long)sig * p.y_sig + (long)b * p.y_b : 0, p.y ? ct : 0);
+            const bool has_y2 = (flags & F_AFF_OUT) != 0;
+            Rp.y2 = act_rsrc(has_y2 ? p.y2 : nul, has_y2 ? (long)sig * p.y2_sig + (long)b * p.y2_b : 0, has_y2 ? ct : 0);
+            const bool has_ss = (flags & (F_STATS | F_AFF_OUT)) != 0;
+            Rp.ss = act_rsrc(has_ss ? p.ss_out : nul, has_ss ? (long)b * p.ss_out_b : 0, has_ss ? 2 * ct : 0);
+            Rp.res = Rp.y; Rp.r1x = Rp.y;
+        }
+        auto ppass2 = [&](int un) {
+#ifdef FASTSVC_ACT_BF16
+            if constexpr (PSPLIT) {
+                if (un < nunits && (un % nch) == nch - 1) {    // (wave-uniform) this unit ends a tile
+                    const int tcolw = (tile0 + un / nch) * NT + wave_n * (NW * 16);
+                    const unsigned char* Pw = tiles + 2 * bufsz + cw * hx_poly_patch_bytes<MW, NW, S>();
+                    HxPolyPass2<MW, NW, EPI, S, hx_poly_mc<MW>(), MW> P2;
+                    float s1p[MW], s2p[MW];
+                    #pragma unroll
+                    for (int m = 0; m < MW; ++m) { s1p[m] = 0.f; s2p[m] = 0.f; }
+                    if (pact) P2.request(p, Rp, mg, tcolw, lane);
+                    __syncthreads();                           // the consumers' patches are complete
+                    if (pact) {
+                        P2.run(p, Rp, Pw, s1p, s2p, mg, tcolw, lane);
+                        if (flags & F_STATS) {
+                            #pragma unroll
+                            for (int m = hx_poly_mc<MW>(); m < MW; ++m) {
+                                if (lane < 16) {               // (run() left the row sums in lanes 0..15)
+                                    const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
+                                    atomicAdd(&sstat[slot + 0], (double)s1p[m]);
+                                    atomicAdd(&sstat[slot + 1], (double)s2p[m]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#endif
+        };
         f32x4 pa[ITEMS][8], pb[ITEMS][8];
         unsigned oka = 0, okb = 0;                       // per-item "rows inside the utterance" bits
         // No branch may sit between a load and its use (hipcc then counts vmcnt for the path WITHOUT the
@@ -1346,6 +1398,7 @@ void conv_hx_kernel(const ConvParams p0) {
             stamp(9);
             pcommit(u + 1, pb, okb, tiles + bufsz);
             stamp(5);
+            ppass2(u);
             __syncthreads();                           // end of unit u
             if (CHAIN && (u % nch) == nch - 1) __syncthreads();        // the consumers wrote the intermediate tile
             stamp(6);
@@ -1359,6 +1412,7 @@ void conv_hx_kernel(const ConvParams p0) {
             stamp(9);
             pcommit(u + 2, pa, oka, tiles);
             stamp(5);
+            ppass2(u + 1);
             __syncthreads();                           // end of unit u+1 (or the phantom one)
             if (CHAIN && u + 1 < nunits && ((u + 1) % nch) == nch - 1) __syncthreads();
             stamp(6);
@@ -1748,10 +1802,18 @@ void conv_hx_kernel(const ConvParams p0) {
                     if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))); }
                     if constexpr (POLY) {
 #ifdef FASTSVC_ACT_BF16
-                        if constexpr (hx_poly_staged<MW, NW, MODE, EPI, S>())
-                            hx_epilogue_poly_staged<MW, NW, EPI, S>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K,
-                                                                    tiles + 2 * bufsz + cw * hx_poly_patch_bytes<MW, NW, S>());
-                        else
+                        if constexpr (hx_poly_staged<MW, NW, MODE, EPI, S>()) {
+                            // pass 1, workgroup barrier, then this wave's share of pass 2 (the staging partner runs the rest)
+                            const int tcolw = (tile0 + tl) * NT + wave_n * (NW * 16);
+                            unsigned char* Pw = tiles + 2 * bufsz + cw * hx_poly_patch_bytes<MW, NW, S>();
+                            HxPolyPass2<MW, NW, EPI, S, 0, hx_poly_mc<MW>()> P2;
+                            if (active) {
+                                P2.request(p, R, mg, tcolw, lane);
+                                hx_poly_pass1<MW, NW, S>(p, acc3, mg, lane, K, Pw);
+                            }
+                            __syncthreads();               // every wave's patch is complete
+                            if (active) P2.run(p, R, Pw, s1, s2, mg, tcolw, lane);
+                        } else
                             hx_epilogue_poly8<MW, NW, EPI, S, TAILK>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
 #else
                         ws_epilogue_poly<MW, NW, EPI, S, TAILK ? 2 : 0>(p, R, acc3, s1, s2, mg, (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K);
