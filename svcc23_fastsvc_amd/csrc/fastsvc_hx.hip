@@ -66,6 +66,10 @@ __device__ __forceinline__ f32x4 hx_mfma(hx8 a, hx8 b, f32x4 c) {
 #endif
 }
 
+// what a staging thread holds of one channel of its item between the request and the commit: the loaded words as they
+// are (bfloat16 storage: two dwords, converted in the commit - see act4_t); the raw float32 signal of MODE_CHAIN1
+template <bool IN1> struct HxWin { typedef act4_t type; };
+template <> struct HxWin<true> { typedef f32x4 type; };
 constexpr int HX_KC = 32;                // input channels per K chunk = one MFMA K step per tap
 constexpr int HX_ROW = 64;               // bytes of one LDS tile row (32 channels)
 constexpr int HX_FRAG = 1024;            // bytes of one packed weight fragment (64 lanes x 8 halves)
@@ -1128,10 +1132,16 @@ void conv_hx_kernel(const ConvParams p0) {
         }
         // unconditional loads of unit `un`: 8 channels x 4 time steps per item; whatever lies outside the
         // tensor or the utterance reads as 0 through the descriptor (offset pushed out of range)
-        auto pload = [&](int un, f32x4 (&px)[ITEMS][8], unsigned& tokmask) {
-            const int uk = XR ? un >> 1 : un;          // (XR: the main units are the even ones)
-            const int tl = uk / nch;
-            const int ch = uk - tl * nch;
+        // (tile, chunk) of the unit each of the lambdas below is called with next: they are called once per unit, in
+        // unit order, and count along - `un / nch` and `un % nch` inside them were scalar divisions that hipcc moved
+        // into skip-if-no-lane regions between the window loads and their use, and behind such a region it waits
+        // vmcnt(0): for the loads just issued as well (the two-deep prefetch ran one deep in every second unit)
+        int l_tl = 0, l_ch = 0, c_ch = 0, xl_tl = 0, xl_ch = 0, xc_tl = 0, xc_ch = 0, e_tl = 0, e_ch = 0;
+        auto pos_next = [&](int& tl_, int& ch_) { const bool wrap = ch_ + 1 == nch; ch_ = wrap ? 0 : ch_ + 1; tl_ += wrap ? 1 : 0; };
+        typedef typename HxWin<IN1>::type pwin_t;
+        auto pload = [&](int un, pwin_t (&px)[ITEMS][8], unsigned& tokmask) {
+            const int tl = l_tl, ch = l_ch;
+            pos_next(l_tl, l_ch);
             const int t_start = (tile0 + tl) * NT - HB - halo_al;
             const int soff = ch * HX_KC * p.ldx * 4;
             const int rows_left = p.CIN - ch * HX_KC;
@@ -1139,7 +1149,9 @@ void conv_hx_kernel(const ConvParams p0) {
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const int t = t_start + 4 * it_q[i];
-                const bool tok = it_in[i] && (unsigned)t < (unsigned)p.T && un < nunits && !(FASTSVC_DBG_ON(p, DBG_NO_LOAD));
+                // (bitwise: the short-circuit form compiles to a lane-divergent region, and behind one hipcc waits vmcnt(0)
+                // in front of the commit - for the loads just issued as well: the two-deep prefetch ran one deep)
+                const bool tok = it_in[i] & ((unsigned)t < (unsigned)p.T) & (un < nunits) & !(FASTSVC_DBG_ON(p, DBG_NO_LOAD));
                 // how many of the item's 4 time steps lie inside the row (a ragged batch's own row lengths need not
                 // be a multiple of 4: the float4 that straddles the row end also holds whatever the pitch holds)
                 if constexpr (TAILK) tokmask |= (tok ? (unsigned)min(4, p.T - t) : 0u) << (3 * i);
@@ -1150,39 +1162,39 @@ void conv_hx_kernel(const ConvParams p0) {
                     px[i][0] = buf_load4(xr, tok ? t * 4 : OOB_OFF, 0);
                     px[i][1].x = buf_load1(xr, tok ? (t - 1) * 4 : OOB_OFF, 0);
                     px[i][1].y = buf_load1(xr, tok ? (t + 4) * 4 : OOB_OFF, 0);
-                    continue;
-                }
+                } else {
                 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const int r = it_oct[i] * 8 + c;
                     if constexpr (DEC2 && S == 2) {
                         // the input IS the compact decimated copy h[..., ::s] a whole-stage launch wrote (fastsvc_cond.hip):
                         // unit stride, one vector load per channel like any direct window
-                        px[i][c] = act_load4(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
+                        px[i][c] = act_load4_raw(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
                     } else if constexpr (DEC2) {
                         // x[..., ::s] (Squeeze2d): four strided elements; negative t lies before the tensor -> 0
                         const int o = (tok && r < rows_left) ? (r * p.ldx + t * p.s) * 4 : OOB_OFF;
-                        px[i][c].x = act_load1(xr, o, soff);
-                        px[i][c].y = act_load1(xr, o + 4 * p.s, soff);
-                        px[i][c].z = act_load1(xr, o + 8 * p.s, soff);
-                        px[i][c].w = act_load1(xr, o + 12 * p.s, soff);
+                        px[i][c] = act_pack4_raw(act_load1_raw(xr, o, soff), act_load1_raw(xr, o + 4 * p.s, soff),
+                                                 act_load1_raw(xr, o + 8 * p.s, soff), act_load1_raw(xr, o + 12 * p.s, soff));
                     } else if constexpr (CHAIN) {
                         // (general addressing: the channel may live in the second signal's tensor, ConvParams::xsplit)
                         const int cc = ch * HX_KC + r;
                         const bool second = p.xsplit > 0 && cc >= p.xsplit;
                         const int row = second ? cc - p.xsplit : cc;
-                        px[i][c] = act_load4(xr, (tok && r < rows_left) ? (row * p.ldx + t) * 4 + (second ? xsplit_off : 0) : OOB_OFF, 0);
+                        px[i][c] = act_load4_raw(xr, (tok && r < rows_left) ? (row * p.ldx + t) * 4 + (second ? xsplit_off : 0) : OOB_OFF, 0);
                     } else {
-                        px[i][c] = act_load4(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
+                        px[i][c] = act_load4_raw(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
                     }
+                }
                 }
             }
         };
         // prologue transform (one FMA: InstanceNorm-apply + speaker bias; LeakyReLU), split, transpose, LDS write
-        auto pcommit = [&](int un, const f32x4 (&px)[ITEMS][8], unsigned tokmask, unsigned char* tile) {
+        auto pcommit = [&](int un, const pwin_t (&pw)[ITEMS][8], unsigned tokmask, unsigned char* tile) {
             if (FASTSVC_DBG_ON(p, DBG_NO_COMMIT)) return;
-            const int ch = (XR ? un >> 1 : un) % nch;
+            const int ch = c_ch;
+            { int dummy = 0; pos_next(dummy, c_ch); }
             if constexpr (IN1) {
+                const pwin_t (&px)[ITEMS][8] = pw;
                 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) {
                     const float keep = ((tokmask >> i) & 1u) ? 1.f : 0.f;      // rows outside the utterance: the NEXT conv's zero padding
@@ -1223,11 +1235,16 @@ void conv_hx_kernel(const ConvParams p0) {
                 // measured SLOWER in float32 storage: cfg2 1.412 vs 1.388 ms; in bfloat16 storage (round 5) it took 1 % off
                 // the C = 24 layers and made up.0.d27 differ from run to run - v_pk_fma_f32 / v_pk_mul_f32 behind the
                 // window loads, cause not found - and was dropped)
+                f32x4 px[8];                                   // (the conversion of bfloat16 words happens HERE, a unit after the request)
+                #pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if constexpr (IN1) px[c] = f32x4{0.f, 0.f, 0.f, 0.f}; else px[c] = act_unpack4(pw[i][c]);
+                }
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float e[8];
                     #pragma unroll
-                    for (int c = 0; c < 8; ++c) e[c] = px[i][c][j] * A[c] + Bc[c];
+                    for (int c = 0; c < 8; ++c) e[c] = px[c][j] * A[c] + Bc[c];
                     if (TAILK && tail_rows) {                  // (wave-uniform; rows a multiple of 4 long skip it)
                         #pragma unroll
                         for (int c = 0; c < 8; ++c) e[c] = j < nvi ? e[c] : 0.f;
@@ -1253,11 +1270,10 @@ void conv_hx_kernel(const ConvParams p0) {
         const __amdgpu_buffer_rsrc_t x2r = XR ? act_rsrc(p.x2, (long)b * p.x2_b, (long)p.CIN * p.ldx2) : xr;
         const int x2T = !XR ? 0 : p0.lens ? p0.lens[b] * p0.x2len_mul : p.x2_T;
         const int xoct = ptid & 3, xg = ptid >> 2;
-        auto ploadX = [&](int un, float (&px)[XJ][8]) {
+        auto ploadX = [&](int un, act1_t (&px)[XJ][8]) {
             if constexpr (XR) {
-                const int uk = un >> 1;                // (the odd units)
-                const int tl = uk / nch;
-                const int ch = uk - tl * nch;
+                const int tl = xl_tl, ch = xl_ch;        // (the odd units)
+                pos_next(xl_tl, xl_ch);
                 const int t_start = (tile0 + tl) * NT - halo_al;
                 const int g0 = (t_start + 8 * XROWS) / XROWS - 8;                 // floor(t_start / XROWS), t_start >= -28
                 const int soff = ch * HX_KC * p.ldx2 * 4;
@@ -1265,23 +1281,27 @@ void conv_hx_kernel(const ConvParams p0) {
                 #pragma unroll
                 for (int jj = 0; jj < XJ; ++jj) {
                     const int j = (g0 + xg) * XJ + jj;
-                    const bool ok = (unsigned)j < (unsigned)x2T && un < nunits;
+                    const bool ok = ((unsigned)j < (unsigned)x2T) & (un < nunits);
                     #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const int r = xoct * 8 + c;
-                        px[jj][c] = act_load1(x2r, (ok && r < rows_left) ? (r * p.ldx2 + j) * 4 : OOB_OFF, soff);
+                        px[jj][c] = act_load1_raw(x2r, (ok && r < rows_left) ? (r * p.ldx2 + j) * 4 : OOB_OFF, soff);
                     }
                 }
             }
         };
-        auto pcommitX = [&](int un, const float (&px)[XJ][8], unsigned char* tile) {
+        auto pcommitX = [&](int un, const act1_t (&pw)[XJ][8], unsigned char* tile) {
             if constexpr (XR) {
-                const int tl = (un >> 1) / nch;
+                const int tl = xc_tl;
+                pos_next(xc_tl, xc_ch);
                 const int t_start = (tile0 + tl) * NT - halo_al;
                 const int g0 = (t_start + 8 * XROWS) / XROWS - 8;
                 const int r0 = (g0 + xg) * XROWS - t_start;
                 #pragma unroll
                 for (int jj = 0; jj < XJ; ++jj) {
+                    float px[XJ][8];
+                    #pragma unroll
+                    for (int c = 0; c < 8; ++c) px[jj][c] = act_unpack1(pw[jj][c]);
                     hx8 h;
                     #pragma unroll
                     for (int c = 0; c < 8; ++c) h[c] = (hx_t)(HX_NP == 2 ? px[jj][c] * sx2 : px[jj][c]);
@@ -1303,8 +1323,8 @@ void conv_hx_kernel(const ConvParams p0) {
             }
         };
         if constexpr (XR) {
-            f32x4 pa[ITEMS][8];
-            float xb[XJ][8];
+            pwin_t pa[ITEMS][8];
+            act1_t xb[XJ][8];
             unsigned oka = 0;
             pload(0, pa, oka);
             ploadX(1, xb);
@@ -1347,8 +1367,10 @@ void conv_hx_kernel(const ConvParams p0) {
         auto ppass2 = [&](int un) {
 #ifdef FASTSVC_ACT_BF16
             if constexpr (PSPLIT) {
-                if (un < nunits && (un % nch) == nch - 1) {    // (wave-uniform) this unit ends a tile
-                    const int tcolw = (tile0 + un / nch) * NT + wave_n * (NW * 16);
+                const int etl = e_tl, ech = e_ch;
+                pos_next(e_tl, e_ch);
+                if (un < nunits && ech == nch - 1) {            // (wave-uniform) this unit ends a tile
+                    const int tcolw = (tile0 + etl) * NT + wave_n * (NW * 16);
                     const unsigned char* Pw = tiles + 2 * bufsz + cw * hx_poly_patch_bytes<MW, NW, S>();
                     HxPolyPass2<MW, NW, EPI, S, hx_poly_mc<MW>(), MW> P2;
                     float s1p[MW], s2p[MW];
@@ -1373,7 +1395,7 @@ void conv_hx_kernel(const ConvParams p0) {
             }
 #endif
         };
-        f32x4 pa[ITEMS][8], pb[ITEMS][8];
+        pwin_t pa[ITEMS][8], pb[ITEMS][8];
         unsigned oka = 0, okb = 0;                       // per-item "rows inside the utterance" bits
         // No branch may sit between a load and its use (hipcc then counts vmcnt for the path WITHOUT the
         // newer loads and so waits for them too - a full memory latency per unit): loads and commits are
