@@ -493,6 +493,7 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
         for (int k0 = 0; k0 < NP2; k0 += G) {
             int boff[G], nv[G];
             f32x8 l0[G], l1[G], l2[G];
+            u32x4 w0[G], w1[G], w2[G];                             // (direct loads: raw words, converted behind the re-layout below)
             #pragma unroll
             for (int g = 0; g < G; ++g) {                          // every load of the group first
                 const int k = k0 + g;
@@ -501,6 +502,7 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
                 nv[g] = ok ? min(8, p.T - t) : 0;                  // (TAILK: any count; the stores round it up to 4)
                 boff[g] = ok ? (rowoff + t) * 2 : OOB_OFF;
                 l0[g] = zero8; l1[g] = zero8; l2[g] = zero8;
+                w0[g] = w1[g] = w2[g] = u32x4{0u, 0u, 0u, 0u};
                 if constexpr (EST) {
                     const u32x4* slot = reinterpret_cast<const u32x4*>(Ew) + (m * NP2 + k) * 64 + lane;
                     if (EPI == EPI_RES) l0[g] = bf8_unpack(slot[0]);
@@ -510,21 +512,25 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
                         if (p.res) l0[g] = bf8_unpack(slot[2 * MW * NP2 * 64]);
                     }
                 } else {
-                    if (EPI == EPI_RES) l0[g] = act_load8(R.res, boff[g], 0);
+                    if (EPI == EPI_RES) w0[g] = __builtin_amdgcn_raw_buffer_load_b128(R.res, boff[g], 0, 0);
                     if (EPI == EPI_RANK1) {                        // the raw float32 signal
                         l0[g].lo = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
                         l0[g].hi = buf_load4(R.r1x, (ok && nv[g] > 4) ? t * 4 + 16 : OOB_OFF, 0);
                     }
                     if (EPI == EPI_AFF) {
-                        l0[g] = act_load8(R.res, boff[g], 0);      // zero-length descriptor when absent
-                        l1[g] = act_load8(R.ss, boff[g], 0);
-                        l2[g] = act_load8(R.ss, boff[g], shift_soff);
+                        w0[g] = __builtin_amdgcn_raw_buffer_load_b128(R.res, boff[g], 0, 0);      // zero-length descriptor when absent
+                        w1[g] = __builtin_amdgcn_raw_buffer_load_b128(R.ss, boff[g], 0, 0);
+                        w2[g] = __builtin_amdgcn_raw_buffer_load_b128(R.ss, boff[g], shift_soff, 0);
                     }
                 }
             }
             #pragma unroll
             for (int g = 0; g < G; ++g) {
                 f32x8 v = hx_pair(acc[2 * (k0 + g)][m], acc[2 * (k0 + g) + 1][m], Xw, lane);
+                if constexpr (!EST) {
+                    if (EPI == EPI_RES || EPI == EPI_AFF) l0[g] = bf8_unpack(w0[g]);
+                    if (EPI == EPI_AFF) { l1[g] = bf8_unpack(w1[g]); l2[g] = bf8_unpack(w2[g]); }
+                }
                 v.lo += bias; v.hi += bias;
                 if (!LRB || (p.flags & F_POST_LRELU)) {            // (wave-uniform)
                     #pragma unroll
@@ -681,7 +687,7 @@ template <int MW, int NW, int EPI, int S, int M0, int M1>
 struct HxPolyPass2 {
     static constexpr int NC = NW * 16 * S, PB = NC * 2 + 16, NCH = (NC + 31) / 32, NM = M1 - M0;
     static constexpr bool HOIST = NM * NCH <= 10;
-    f32x8 l1[HOIST ? NM : 1][NCH], l2[HOIST ? NM : 1][NCH];
+    u32x4 l1[HOIST ? NM : 1][NCH], l2[HOIST ? NM : 1][NCH];     // (raw words: converted where they are used, see act4_t)
     int off[HOIST ? NM : 1][NCH], nv[HOIST ? NM : 1][NCH];
     __device__ __forceinline__ void fetch(const ConvParams& p, const EpiRsrc& R, int mg, int tcol0, int lane, int m, int slot) {
         const int rsub = lane >> 2, piece = lane & 3;
@@ -697,8 +703,8 @@ struct HxPolyPass2 {
             nv[slot][c] = (cok && col < NC) ? max(0, min(8, ncv - col)) : 0;
             off[slot][c] = nv[slot][c] > 0 ? rowb + col * 2 : OOB_OFF;
             if (EPI == EPI_AFF) {
-                l1[slot][c] = act_load8(R.ss, off[slot][c], 0);
-                l2[slot][c] = act_load8(R.ss, off[slot][c], shift_soff);
+                l1[slot][c] = __builtin_amdgcn_raw_buffer_load_b128(R.ss, off[slot][c], 0, 0);
+                l2[slot][c] = __builtin_amdgcn_raw_buffer_load_b128(R.ss, off[slot][c], shift_soff, 0);
             }
         }
     }
@@ -725,7 +731,8 @@ struct HxPolyPass2 {
                 act_store8(R.y, off[sl][c], v, nvs);             // dropped when y is absent
                 if (EPI == EPI_AFF) {
                     f32x8 u;
-                    u.lo = l1[sl][c].lo * v.lo + l2[sl][c].lo; u.hi = l1[sl][c].hi * v.hi + l2[sl][c].hi;
+                    const f32x8 sc = bf8_unpack(l1[sl][c]), sh = bf8_unpack(l2[sl][c]);
+                    u.lo = sc.lo * v.lo + sh.lo; u.hi = sc.hi * v.hi + sh.hi;
                     u = keep8_exact(u, nv[sl][c]);
                     act_store8(R.y2, off[sl][c], u, nvs);
                     a1 += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
