@@ -163,16 +163,21 @@ template <int MW, int NW, bool RELOAD, bool OPT_LAST = false, int NS = 3 * MW * 
 __device__ __forceinline__ void hx_unit_direct(f32x4 (&acc)[NW][MW], const unsigned char* tile, const int (&aoff)[3],
                                                int lo_off, HxWeightStream<NS>& ws, bool do_last = true) {
     constexpr int NSTEP = 3 * NW;
-    HxFrag a[2];
-    a[0] = hx_read(tile, aoff[0], lo_off);
+    // The A fragments are read PF steps ahead.  bfloat16 storage: a step is MW products = 16 MW cycles of the matrix
+    // pipe, less than an LDS round trip - one step ahead the consumer stalled at every step (film.3.heads: 2.0k cycles
+    // per unit for 1.15k of products); the split-binary16 steps (3 MW products) cover it one step ahead.
+    constexpr int PF = HX_NP == 1 ? (MW >= 3 ? 2 : 3) : 1;
+    HxFrag a[PF + 1];
+    #pragma unroll
+    for (int q = 0; q < PF && q < NSTEP; ++q) a[q] = hx_read(tile, aoff[q / NW] + (q % NW) * 16 * HX_ROW, lo_off);
     #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
         const int tap = s / NW, n = s % NW;
-        if (s + 1 < NSTEP) {
-            a[(s + 1) & 1] = hx_read(tile, aoff[(s + 1) / NW] + ((s + 1) % NW) * 16 * HX_ROW, lo_off);
+        if (s + PF < NSTEP) {
+            a[(s + PF) % (PF + 1)] = hx_read(tile, aoff[(s + PF) / NW] + ((s + PF) % NW) * 16 * HX_ROW, lo_off);
             __builtin_amdgcn_sched_barrier(0);                 // reads stay ahead of the MFMAs
         }
-        if (!OPT_LAST || n + 1 < NW || do_last) hx_step<MW, OPT_LAST>(acc[n], a[s & 1], &ws.wr[SOFF + tap * MW * HX_NP]);
+        if (!OPT_LAST || n + 1 < NW || do_last) hx_step<MW, OPT_LAST>(acc[n], a[s % (PF + 1)], &ws.wr[SOFF + tap * MW * HX_NP]);
         if (RELOAD && n + 1 == NW) {                            // last use of this tap's fragments
             #pragma unroll
             for (int q = 0; q < MW * HX_NP; ++q) ws.request(SOFF + tap * MW * HX_NP + q);
