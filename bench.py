@@ -487,7 +487,7 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
     elapsed = time_steps(lambda i: plan.forward(blob, *args_dev, out=out, workspace=ws),
                          torch.cuda.synchronize, steps, warmup, None, dev)
     ms = elapsed / steps * 1e3
-    roof = roofline(plan, blob, args_dev, ms, n_prof=n_prof, pmc_file=f"r5_{name}_{storage}_pmc_traffic.json")
+    roof = roofline(plan, blob, args_dev, ms, n_prof=n_prof, pmc_file=f"r5c_{name}_{storage}_pmc_traffic.json")
     top = sorted(roof["per_kernel"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]
     res = {"workload": f"{name}: {wl['desc']}, F={F}, T={T}", "storage": storage,
            "dtype": plan.arithmetic, "ms_per_step": ms, "value": B * T * steps / elapsed, "unit": "samples/s",
@@ -956,7 +956,7 @@ def main(argv=None):
             args_dev = roofline_batch()
         batch_share = B * T / (float(sum(n_frames[i] for i in mine)) * cfg.hop) if strong else 1.0
         roof = roofline(plan, blob, args_dev, ms_per_step * batch_share,
-                        pmc_file=f"r5_{'cfg3' if strong else args.workload}_{args.storage}_pmc_traffic.json")
+                        pmc_file=f"r5c_{'cfg3' if strong else args.workload}_{args.storage}_pmc_traffic.json")
         secondary = None
         if world == 1 and not args.no_secondary and default_workload:
             del ws
