@@ -1181,20 +1181,20 @@ void conv_hx_kernel(const ConvParams p0) {
                     if constexpr (DEC2 && S == 2) {
                         // the input IS the compact decimated copy h[..., ::s] a whole-stage launch wrote (fastsvc_cond.hip):
                         // unit stride, one vector load per channel like any direct window
-                        px[i][c] = act_load4_raw(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
+                        px[i][c] = act_load4_raw(xr, (tok & (r < rows_left)) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
                     } else if constexpr (DEC2) {
                         // x[..., ::s] (Squeeze2d): four strided elements; negative t lies before the tensor -> 0
-                        const int o = (tok && r < rows_left) ? (r * p.ldx + t * p.s) * 4 : OOB_OFF;
+                        const int o = (tok & (r < rows_left)) ? (r * p.ldx + t * p.s) * 4 : OOB_OFF;
                         px[i][c] = act_pack4_raw(act_load1_raw(xr, o, soff), act_load1_raw(xr, o + 4 * p.s, soff),
                                                  act_load1_raw(xr, o + 8 * p.s, soff), act_load1_raw(xr, o + 12 * p.s, soff));
                     } else if constexpr (CHAIN) {
                         // (general addressing: the channel may live in the second signal's tensor, ConvParams::xsplit)
                         const int cc = ch * HX_KC + r;
-                        const bool second = p.xsplit > 0 && cc >= p.xsplit;
+                        const bool second = (p.xsplit > 0) & (cc >= p.xsplit);
                         const int row = second ? cc - p.xsplit : cc;
-                        px[i][c] = act_load4_raw(xr, (tok && r < rows_left) ? (row * p.ldx + t) * 4 + (second ? xsplit_off : 0) : OOB_OFF, 0);
+                        px[i][c] = act_load4_raw(xr, (tok & (r < rows_left)) ? (row * p.ldx + t) * 4 + (second ? xsplit_off : 0) : OOB_OFF, 0);
                     } else {
-                        px[i][c] = act_load4_raw(xr, (tok && r < rows_left) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
+                        px[i][c] = act_load4_raw(xr, (tok & (r < rows_left)) ? (r * p.ldx + t) * 4 : OOB_OFF, soff);
                     }
                 }
                 }
@@ -1250,7 +1250,14 @@ void conv_hx_kernel(const ConvParams p0) {
                 f32x4 px[8];                                   // (the conversion of bfloat16 words happens HERE, a unit after the request)
                 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    if constexpr (IN1) px[c] = f32x4{0.f, 0.f, 0.f, 0.f}; else px[c] = act_unpack4(pw[i][c]);
+                    if constexpr (IN1) px[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    else {
+                        // (pinned HERE: hipcc otherwise hoists the conversion - pure VALU on the loaded registers - above the
+                        // unit barrier into the half that issued the request, and waits for the request there)
+                        act4_t w = pw[i][c];
+                        asm volatile("" : "+v"(w));
+                        px[c] = act_unpack4(w);
+                    }
                 }
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1297,7 +1304,7 @@ void conv_hx_kernel(const ConvParams p0) {
                     #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const int r = xoct * 8 + c;
-                        px[jj][c] = act_load1_raw(x2r, (ok && r < rows_left) ? (r * p.ldx2 + j) * 4 : OOB_OFF, soff);
+                        px[jj][c] = act_load1_raw(x2r, (ok & (r < rows_left)) ? (r * p.ldx2 + j) * 4 : OOB_OFF, soff);
                     }
                 }
             }
@@ -1338,24 +1345,31 @@ void conv_hx_kernel(const ConvParams p0) {
             pwin_t pa[ITEMS][8];
             act1_t xb[XJ][8];
             unsigned oka = 0;
+            // one register set per operand, each re-requested right after its commit: the main window of tile t + 1 is
+            // requested under tile t's x2 unit (the long one: it carries the consumers' epilogue) and committed under tile
+            // t + 1's - a whole tile of lead (requested in the half BEFORE its commit it had the main unit's 1-2k cycles)
+            // (C >= 48: measured 558 -> 539 us on up.2.d3x at cfg3 bfloat16.  C = 24 keeps the request in the half before the
+            // commit: with the whole-tile lead it ran 940 -> 967 us - its window requests then fall into the consumers' epilogue)
             pload(0, pa, oka);
             ploadX(1, xb);
             stamp(2);
             setup_shared();
             pcommit(0, pa, oka, tiles);
+            unsigned okn = 0;
+            if constexpr (!WSTATIC) pload(2, pa, okn);
             stamp(3);
             __syncthreads();                           // unit 0 staged
             stamp(4);
             for (int u = 0; u < nunits; u += 2) {       // (an even number of units: every main unit has its x2 unit)
-                pload(u + 2, pa, oka);
-                stamp(9);
+                if constexpr (WSTATIC) pload(u + 2, pa, oka);
                 pcommitX(u + 1, xb, tiles + bufsz);
+                if constexpr (!WSTATIC) ploadX(u + 3, xb);
                 stamp(5);
                 __syncthreads();                       // end of unit u
                 stamp(6);
-                ploadX(u + 3, xb);
-                stamp(9);
+                if constexpr (WSTATIC) ploadX(u + 3, xb); else oka = okn;
                 pcommit(u + 2, pa, oka, tiles);
+                if constexpr (!WSTATIC) pload(u + 4, pa, okn);
                 stamp(5);
                 __syncthreads();                       // end of unit u + 1
                 stamp(6);
