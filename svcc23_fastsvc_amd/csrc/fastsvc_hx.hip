@@ -545,7 +545,7 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
                 if (EPI == EPI_RANK1) { v.lo += l0[g].lo * r1w + r1b; v.hi += l0[g].hi * r1w + r1b; }
                 acc[2 * (k0 + g)][m] = v.lo; acc[2 * (k0 + g) + 1][m] = v.hi;     // (finished values, in the pair layout)
                 const int nvs = TAILK ? ((nv[g] + 3) & ~3) : nv[g];
-                act_store8(R.y, boff[g], v, nvs);                  // dropped when y is absent
+                if (!LRB || p.y) act_store8(R.y, boff[g], v, nvs);  // (wave-uniform; a store to the absent tensor's empty descriptor still costs its issue and the conversion)
                 if (EPI == EPI_AFF) {
                     f32x8 u;
                     u.lo = l1[g].lo * v.lo + l2[g].lo; u.hi = l1[g].hi * v.hi + l2[g].hi;
@@ -733,7 +733,7 @@ struct HxPolyPass2 {
                 const int col = c * 32 + piece * 8;
                 f32x8 v = bf8_unpack(*reinterpret_cast<const u32x4*>(src + (col < NC ? c * 64 : 0)));
                 const int nvs = min(8, (nv[sl][c] + 3) & ~3);    // (ragged rows: the straddling group of 4 is stored whole)
-                act_store8(R.y, off[sl][c], v, nvs);             // dropped when y is absent
+                if (p.y) act_store8(R.y, off[sl][c], v, nvs);    // (wave-uniform: the FiLM-affine layers write y2 only)
                 if (EPI == EPI_AFF) {
                     f32x8 u;
                     const f32x8 sc = bf8_unpack(l1[sl][c]), sh = bf8_unpack(l2[sl][c]);
