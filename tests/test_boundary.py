@@ -266,6 +266,30 @@ def test_launch_shape_table_roundtrip_and_shipped_file():
     assert A.Plan(S.FULL_CONFIG, storage="bfloat16").tuned_shapes() == shipped.tuned_shapes()
 
 
+def test_table_switches_for_fused_launches_set_the_documented_keys():
+    """`keep_last_block_output`, `keep_block_heads_separate` and `keep_residual_convs_separate` are table entries with
+    algorithm 0 under the keys INTEGRATION.md documents (conv_last|B|T, up.<i>.head|B|T_in, up.<i>.d3x|B|T_out, both
+    storages); the shipped table says "fused" (algorithm 3) for every up.<i>.d3x entry it holds."""
+    cfg = S.FULL_CONFIG
+    plan = A.Plan(cfg, load_shipped_table=False)
+    B, F = 3, 40
+    plan.keep_residual_convs_separate(B, F)
+    t = plan.tuned_shapes()
+    T = F
+    for i, sc in enumerate(cfg.upsampling_scales):
+        T *= sc
+        for sfx in ("", "|b"):
+            assert t[f"up.{i}.d3x|{B}|{T}{sfx}"][4] == 0
+    assert len(t) == 2 * cfg.n_stages
+    plan.keep_block_heads_separate(B, F)
+    plan.keep_last_block_output(B, F)
+    t = plan.tuned_shapes()
+    assert t[f"up.0.head|{B}|{F}"][4] == 0 and t[f"conv_last|{B}|{F * cfg.hop}"][4] == 0
+    shipped = A.Plan(cfg).tuned_shapes()
+    d3x = {k: v for k, v in shipped.items() if ".d3x|" in k}
+    assert len(d3x) >= 24 and all(v[4] == 3 for v in d3x.values()), {k: v for k, v in d3x.items() if v[4] != 3}
+
+
 def test_decode_harness_f0_statistics_match_reference_golden(tmp_path):
     """F0Statistics.estimate / .convert vs the live reference (decode_chain.npz), the
     device variant of convert, PCM-16 writer round trip, feature-container loader."""
