@@ -551,9 +551,13 @@ __device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc&
                     u.lo = l1[g].lo * v.lo + l2[g].lo; u.hi = l1[g].hi * v.hi + l2[g].hi;
                     u = TAILK ? keep8_exact(u, nv[g]) : keep8(u, nv[g]);
                     act_store8(R.y2, boff[g], u, nvs);
-                    s1[m] += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
-                    s2[m] += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
-                             ((u.hi.x * u.hi.x + u.hi.y * u.hi.y) + (u.hi.z * u.hi.z + u.hi.w * u.hi.w));
+                    // (two lanes of packed float32 per instruction: 3 + 1 adds and 4 FMAs + 1 add instead of 7 + 15)
+                    typedef float f32x2s __attribute__((ext_vector_type(2)));
+                    const f32x2s p0 = {u.lo.x, u.lo.y}, p1 = {u.lo.z, u.lo.w}, p2 = {u.hi.x, u.hi.y}, p3 = {u.hi.z, u.hi.w};
+                    const f32x2s sm = (p0 + p1) + (p2 + p3);
+                    const f32x2s sq = p0 * p0 + p1 * p1 + (p2 * p2 + p3 * p3);
+                    s1[m] += sm.x + sm.y;
+                    s2[m] += sq.x + sq.y;
                 }
             }
         }
