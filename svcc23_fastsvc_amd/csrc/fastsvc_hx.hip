@@ -82,6 +82,21 @@ __device__ __forceinline__ int hx_lds_off(int row, int oct) {
     return ((row ^ ((row >> 2) & 1)) * HX_ROW) + ((oct ^ ((row >> 1) & 2)) << 4);
 }
 
+// s_waitcnt vmcnt(k) for a wave-uniform run-time count: the largest supported k <= n (a smaller k only waits for more)
+__device__ __forceinline__ void hx_wait_vmcnt(int n) {
+    if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Unit-deep weight ring: NSLOT fragments = every fragment of one (tile, chunk) unit of this wave's channel
 // group, statically indexed; slot s is re-requested with the NEXT unit's fragment s right after its last use.
 template <int NSLOT>
@@ -1842,16 +1857,25 @@ void conv_hx_kernel(const ConvParams p0) {
                     for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
                     // the staged pieces are older than the NSLOT ring re-requests of this unit
                     if constexpr (EST2) {
-                        // everything but the NEXT tile's pieces (the youngest requests of this wave) has landed
+                        // This tile's pieces have landed when everything but the wave's YOUNGER requests is back: the next
+                        // tile's pieces and - issued behind this tile's pieces, a tile ago - the previous tile's STORES.  Counting
+                        // only the pieces made every tile wait for those stores' acknowledgement (timeline of up.3.d9: 1.4k of 6.4k
+                        // cycles per tile between the products and the epilogue).  The store count is the guaranteed minimum
+                        // (a straddling row end stores twice: more younger requests only make the wait stricter).
                         if (active) {
                             constexpr int PER_OP = PAIRS ? MW * (NW / 2) : MW * NW * EST_DMA_PER_ITEM;
-                            if (tl + 1 >= ntiles) ws_epilogue_stage_wait<0>(false);
-                            else if (EPI == EPI_RES) ws_epilogue_stage_wait<PER_OP>(true);
-                            else if (p.res) ws_epilogue_stage_wait<3 * PER_OP>(true);
-                            else ws_epilogue_stage_wait<2 * PER_OP>(true);
+                            constexpr int EITEMS = PAIRS ? MW * (NW / 2) : MW * NW;
+                            const int ndma = tl + 1 < ntiles ? (EPI == EPI_RES ? 1 : p.res ? 3 : 2) * PER_OP : 0;
+                            int nst = 0;
+                            if (tl > 0 && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
+                                if (EPI == EPI_AFF) nst = EITEMS * (p.y ? 2 : 1);
+                                else nst = (p.y ? EITEMS : 0) + ((LAST_OK && p.last_w) ? NW : 0);
+                            }
+                            hx_wait_vmcnt(ndma + nst);
                         }
                     } else
                     if constexpr (EST) { if (active) ws_epilogue_stage_wait<NSLOT>(!WSTATIC && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA))); }
+                    stamp(10);                         // (timeline build: the staged operands have landed)
                     if constexpr (POLY) {
 #ifdef FASTSVC_ACT_BF16
                         if constexpr (hx_poly_staged<MW, NW, MODE, EPI, S>()) {
@@ -1896,6 +1920,7 @@ void conv_hx_kernel(const ConvParams p0) {
                                 hx_last_reduce<MW, NW, PAIRS>(p, acc, k_last, b, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                         }
                     }
+                    stamp(11);                         // (timeline build: tile epilogue issued)
                     if constexpr (TRACKS) { if (p.amax_out) amax_tile_flush(R); }
                     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
                         #pragma unroll

@@ -30,5 +30,6 @@ for r in range(6):
     if first is None:
         first = cur
         continue
-    bad = [(n, int((cur[n] != first[n]).sum())) for n in cur if not torch.equal(cur[n], first[n])]
+    bad = [(n, int((cur[n] != first[n]).sum()), float(((cur[n].double() - first[n].double()).abs() / (first[n].double().abs() + 1e-30)).max()))
+           for n in cur if not torch.equal(cur[n], first[n])]
     print(f"run {r}: differing tensors: {bad}")

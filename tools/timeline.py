@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("FASTSVC_HIP_LIB", os.path.join(ROOT, "svcc23_fastsvc_amd", "libfastsvc_hip_timeline.so"))
 
-TAGS = {1: "entry", 2: "issued", 3: "commit0", 4: "bar0", 5: "staged", 6: "bar", 7: "mfma", 8: "epi", 9: "loaded"}
+TAGS = {1: "entry", 2: "issued", 3: "commit0", 4: "bar0", 5: "staged", 6: "bar", 7: "mfma", 8: "epi", 9: "loaded",
+        10: "operands", 11: "tile_out"}
 
 
 def analyse(path, layer):
