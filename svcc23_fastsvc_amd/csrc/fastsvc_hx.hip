@@ -1699,8 +1699,7 @@ void conv_hx_kernel(const ConvParams p0) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
                             float a1 = s1[m], a2 = s2[m];
-                            a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
-                            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                            a1 = row_xsum(a1); a2 = row_xsum(a2);
                             if (active && lane < 16) {
                                 const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
                                 atomicAdd(&sstat[slot + 0], (double)a1);
@@ -1800,8 +1799,7 @@ void conv_hx_kernel(const ConvParams p0) {
                             #pragma unroll
                             for (int m = 0; m < MW; ++m) {
                                 float a1 = s1[m], a2 = s2[m];
-                                a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
-                                a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                                a1 = row_xsum(a1); a2 = row_xsum(a2);
                                 if (active && lane < 16) {
                                     const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
                                     atomicAdd(&sstat[slot + 0], (double)a1);
@@ -1926,8 +1924,7 @@ void conv_hx_kernel(const ConvParams p0) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
                             float a1 = s1[m], a2 = s2[m];
-                            a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
-                            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                            a1 = row_xsum(a1); a2 = row_xsum(a2);
                             if (active && lane < 16) {
                                 const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
                                 atomicAdd(&sstat[slot + 0], (double)a1);

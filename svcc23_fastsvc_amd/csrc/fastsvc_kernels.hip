@@ -455,8 +455,7 @@ __device__ __forceinline__ void stats_flush(const ConvParams& p, double (&d1a)[M
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         double d1 = d1a[m], d2 = d2a[m];
-        d1 += __shfl_xor(d1, 16); d2 += __shfl_xor(d2, 16);
-        d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
+        d1 = row_xsum(d1); d2 = row_xsum(d2);
         if (active && lane < 16) {      // waves that hold no sums (producer waves) pass active = false
             const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
             atomicAdd(&sstat[slot + 0], d1);
@@ -1019,8 +1018,7 @@ void conv_mfma_ws_kernel(const ConvParams p0) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
                             float a1 = s1[m], a2 = s2[m];
-                            a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
-                            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                            a1 = row_xsum(a1); a2 = row_xsum(a2);
                             if (active && lane < 16) {
                                 const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
                                 atomicAdd(&sstat[slot + 0], (double)a1);
