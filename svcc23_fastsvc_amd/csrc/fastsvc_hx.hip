@@ -1493,6 +1493,12 @@ void conv_hx_kernel(const ConvParams p0) {
         constexpr bool XSPLIT = XR && HX_NP == 2;     // second operand, float32 storage: its own accumulator set (other operand scales)
         f32x4 accX[XSPLIT ? NW : 1][MW];
         float s1[MW], s2[MW];
+        // small tiles: the lane's InstanceNorm sums of ALL tiles stay in registers and the rows are joined once, after the
+        // loop (larger tiles have no registers to spare: per tile, through LDS atomics)
+        constexpr bool GSTAT = MODE == MODE_DIRECT && MW * NW <= 6;
+        double g1[GSTAT ? MW : 1], g2[GSTAT ? MW : 1];
+        #pragma unroll
+        for (int m = 0; m < (GSTAT ? MW : 1); ++m) g1[m] = g2[m] = 0.0;
         HxWeightStream<NSLOT> wst;
         const int wunits = UPH ? nch + 2 * p.nch32b : CHAIN ? nch + p.nch32b : XR ? 2 * nch : nch;    // weight units per tile (CHAIN: first conv's, then the second's; XR: interleaved)
         wst.init(reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
@@ -1798,12 +1804,15 @@ void conv_hx_kernel(const ConvParams p0) {
                         if (flags & F_STATS) {
                             #pragma unroll
                             for (int m = 0; m < MW; ++m) {
-                                float a1 = s1[m], a2 = s2[m];
-                                a1 = row_xsum(a1); a2 = row_xsum(a2);
-                                if (active && lane < 16) {
-                                    const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
-                                    atomicAdd(&sstat[slot + 0], (double)a1);
-                                    atomicAdd(&sstat[slot + 1], (double)a2);
+                                if constexpr (GSTAT) { g1[m] += (double)s1[m]; g2[m] += (double)s2[m]; }
+                                else {
+                                    float a1 = s1[m], a2 = s2[m];
+                                    a1 = row_xsum(a1); a2 = row_xsum(a2);
+                                    if (active && lane < 16) {
+                                        const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
+                                        atomicAdd(&sstat[slot + 0], (double)a1);
+                                        atomicAdd(&sstat[slot + 1], (double)a2);
+                                    }
                                 }
                             }
                         }
@@ -1923,12 +1932,15 @@ void conv_hx_kernel(const ConvParams p0) {
                     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
                         #pragma unroll
                         for (int m = 0; m < MW; ++m) {
-                            float a1 = s1[m], a2 = s2[m];
-                            a1 = row_xsum(a1); a2 = row_xsum(a2);
-                            if (active && lane < 16) {
-                                const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
-                                atomicAdd(&sstat[slot + 0], (double)a1);
-                                atomicAdd(&sstat[slot + 1], (double)a2);
+                            if constexpr (GSTAT) { g1[m] += (double)s1[m]; g2[m] += (double)s2[m]; }
+                            else {
+                                float a1 = s1[m], a2 = s2[m];
+                                a1 = row_xsum(a1); a2 = row_xsum(a2);
+                                if (active && lane < 16) {
+                                    const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
+                                    atomicAdd(&sstat[slot + 0], (double)a1);
+                                    atomicAdd(&sstat[slot + 1], (double)a2);
+                                }
                             }
                         }
                     }
@@ -1939,6 +1951,23 @@ void conv_hx_kernel(const ConvParams p0) {
             }
         }
         if constexpr (TRACKS) amax_flush(p, R, &s_amax, &s_cnt, 4, sig, b, lane, blockIdx.x);   // (float32 storage: the next conv's split-binary16 scale)
+        if constexpr (GSTAT) {
+            // the lanes' InstanceNorm partial sums of all tiles: rows joined once per workgroup (per tile that was two
+            // cross-row exchanges and two LDS atomics per channel tile inside a divergent region)
+            if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {
+                #pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    double a1 = g1[m], a2 = g2[m];
+                    a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+                    a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+                    if (active && lane < 16) {
+                        const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
+                        atomicAdd(&sstat[slot + 0], a1);
+                        atomicAdd(&sstat[slot + 1], a2);
+                    }
+                }
+            }
+        }
         if (nunits & 1) __syncthreads();               // the staging waves' loop runs in pairs of units
     }
     if ((flags & F_STATS) && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE))) {   // one f64 global atomic per channel per workgroup
