@@ -1495,7 +1495,7 @@ void conv_hx_kernel(const ConvParams p0) {
         float s1[MW], s2[MW];
         // small tiles: the lane's InstanceNorm sums of ALL tiles stay in registers and the rows are joined once, after the
         // loop (larger tiles have no registers to spare: per tile, through LDS atomics)
-        constexpr bool GSTAT = MODE == MODE_DIRECT && MW * NW <= 6;
+        constexpr bool GSTAT = MODE == MODE_DIRECT && (MW * NW <= 6 || (MW == 3 && NW == 4));   // (3 x 4: 202 -> 214 registers of 256)
         double g1[GSTAT ? MW : 1], g2[GSTAT ? MW : 1];
         #pragma unroll
         for (int m = 0; m < (GSTAT ? MW : 1); ++m) g1[m] = g2[m] = 0.0;
