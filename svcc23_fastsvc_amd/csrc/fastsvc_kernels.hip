@@ -455,7 +455,8 @@ __device__ __forceinline__ void stats_flush(const ConvParams& p, double (&d1a)[M
     #pragma unroll
     for (int m = 0; m < MW; ++m) {
         double d1 = d1a[m], d2 = d2a[m];
-        d1 = row_xsum(d1); d2 = row_xsum(d2);
+        d1 += __shfl_xor(d1, 16); d2 += __shfl_xor(d2, 16);
+        d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
         if (active && lane < 16) {      // waves that hold no sums (producer waves) pass active = false
             const int slot = ((wave_m * MW + m) * 16 + lane) * 2;
             atomicAdd(&sstat[slot + 0], d1);
