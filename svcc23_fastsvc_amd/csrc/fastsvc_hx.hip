@@ -417,8 +417,7 @@ __device__ __forceinline__ f32x8 act_load8(__amdgpu_buffer_rsrc_t r, int boff, i
     return bf8_unpack(__builtin_amdgcn_raw_buffer_load_b128(r, boff, soff, 0));
 }
 // nv: valid elements of the lane (0, 4 or 8 - rows are a multiple of 4 long)
-__device__ __forceinline__ void act_store8(__amdgpu_buffer_rsrc_t r, int boff, const f32x8& v, int nv) {
-    const u32x4 w = bf8_pack(v);
+__device__ __forceinline__ void act_store8_raw(__amdgpu_buffer_rsrc_t r, int boff, const u32x4& w, int nv) {
     if (__builtin_amdgcn_ballot_w64(nv == 4) == 0) {           // wave-uniform: no half lane (nearly always)
         __builtin_amdgcn_raw_buffer_store_b128(w, r, nv > 0 ? boff : OOB_OFF, 0, 0);
     } else {
@@ -427,6 +426,9 @@ __device__ __forceinline__ void act_store8(__amdgpu_buffer_rsrc_t r, int boff, c
         __builtin_amdgcn_raw_buffer_store_b64(a, r, nv >= 4 ? boff : OOB_OFF, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64(b, r, nv >= 8 ? boff + 8 : OOB_OFF, 0, 0);
     }
+}
+__device__ __forceinline__ void act_store8(__amdgpu_buffer_rsrc_t r, int boff, const f32x8& v, int nv) {
+    act_store8_raw(r, boff, bf8_pack(v), nv);
 }
 __device__ __forceinline__ f32x8 keep8_exact(f32x8 v, int nv) {       // zero the elements at and past index nv (any nv)
     #pragma unroll
@@ -747,22 +749,38 @@ struct HxPolyPass2 {
             float a1 = 0.f, a2 = 0.f;
             const int sl = HOIST ? m - M0 : 0;
             if constexpr (!HOIST) fetch(p, R, mg, tcol0, lane, m, 0);
+            // Every chunk's arithmetic first, every store after: act_store8's half-lane branch hides the stores from hipcc's
+            // vmcnt count, so a chunk's operand words behind the previous chunk's stores were waited for with counts that
+            // ended in vmcnt(0) - the row's last chunk waited for the acknowledgement of all its stores, once per tile and role
+            u32x4 yw[EPI == EPI_AFF ? NCH : 1];
             #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int col = c * 32 + piece * 8;
-                f32x8 v = bf8_unpack(*reinterpret_cast<const u32x4*>(src + (col < NC ? c * 64 : 0)));
-                const int nvs = min(8, (nv[sl][c] + 3) & ~3);    // (ragged rows: the straddling group of 4 is stored whole)
-                if (p.y) act_store8(R.y, off[sl][c], v, nvs);    // (wave-uniform: the FiLM-affine layers write y2 only)
                 if (EPI == EPI_AFF) {
+                    const f32x8 v = bf8_unpack(*reinterpret_cast<const u32x4*>(src + (col < NC ? c * 64 : 0)));
                     f32x8 u;
                     const f32x8 sc = bf8_unpack(l1[sl][c]), sh = bf8_unpack(l2[sl][c]);
                     u.lo = sc.lo * v.lo + sh.lo; u.hi = sc.hi * v.hi + sh.hi;
                     u = keep8_exact(u, nv[sl][c]);
-                    act_store8(R.y2, off[sl][c], u, nvs);
+                    yw[c] = bf8_pack(u);
                     a1 += ((u.lo.x + u.lo.y) + (u.lo.z + u.lo.w)) + ((u.hi.x + u.hi.y) + (u.hi.z + u.hi.w));
                     a2 += ((u.lo.x * u.lo.x + u.lo.y * u.lo.y) + (u.lo.z * u.lo.z + u.lo.w * u.lo.w)) +
                           ((u.hi.x * u.hi.x + u.hi.y * u.hi.y) + (u.hi.z * u.hi.z + u.hi.w * u.hi.w));
                 }
+            }
+            // (hipcc sinks a chunk's arithmetic back behind the previous chunk's stores unless the words are pinned here)
+            if (EPI == EPI_AFF) {
+                #pragma unroll
+                for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(yw[c]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            #pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = c * 32 + piece * 8;
+                const int nvs = min(8, (nv[sl][c] + 3) & ~3);    // (ragged rows: the straddling group of 4 is stored whole)
+                // (y is the patch itself, already bfloat16; wave-uniform: the FiLM-affine layers write y2 only)
+                if (p.y) act_store8_raw(R.y, off[sl][c], *reinterpret_cast<const u32x4*>(src + (col < NC ? c * 64 : 0)), nvs);
+                if (EPI == EPI_AFF) act_store8_raw(R.y2, off[sl][c], yw[c], nvs);
             }
             if (EPI == EPI_AFF) {
                 // the caller folds s1 / s2 over the lane >> 4 groups and takes channel lane & 15 from lanes 0..15: hand the row
@@ -880,9 +898,10 @@ constexpr int hx_min_waves() {
 // the 8-wide pair layout of hx_epilogue8 (tile 2k = samples 0..3, tile 2k+1 = samples 4..7 of the lane's 8).
 template <int MW, int NW, bool PAIRS>
 __device__ __forceinline__ void hx_last_reduce(const ConvParams& p, const f32x4 (&acc)[NW][MW], const float (&kw)[MW],
-                                               int b, int tcol0, int lane) {
+                                               float bias, int b, int tcol0, int lane) {
+    // (bias = last_b[0], read ONCE by the caller: read here it was a global load per tile and, behind it, a vmcnt(0) in the
+    // consumer's chain - an L2 round trip and every younger request of the wave waited for, tile after tile)
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.last_y + (long)b * p.last_y_b, p.ldy);
-    const float bias = p.last_b[0];
     #pragma unroll
     for (int n = 0; n < NW; ++n) {
         f32x4 s = acc[n][0] * kw[0];
@@ -1564,6 +1583,7 @@ void conv_hx_kernel(const ConvParams p0) {
         }
         constexpr bool LAST_OK = MODE == MODE_DIRECT && EPI == EPI_RES && WM == 1;     // conv_last may ride on this instance
         float k_last[MW];
+        const float b_last = (LAST_OK && p.last_w) ? p.last_b[0] : 0.f;
         #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int cot = (mg * MW + m) * 16 + (lane & 15);
@@ -1924,7 +1944,7 @@ void conv_hx_kernel(const ConvParams p0) {
                                                               (tile0 + tl) * NT + wave_n * (NW * 16), active, lane, K, EwT);
                         if constexpr (LAST_OK) {
                             if (p.last_w && !(FASTSVC_DBG_ON(p, DBG_NO_EPILOGUE)))
-                                hx_last_reduce<MW, NW, PAIRS>(p, acc, k_last, b, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
+                                hx_last_reduce<MW, NW, PAIRS>(p, acc, k_last, b_last, b, (tile0 + tl) * NT + wave_n * (NW * 16), lane);
                         }
                     }
                     stamp(11);                         // (timeline build: tile epilogue issued)
