@@ -1583,7 +1583,8 @@ void conv_hx_kernel(const ConvParams p0) {
         }
         constexpr bool LAST_OK = MODE == MODE_DIRECT && EPI == EPI_RES && WM == 1;     // conv_last may ride on this instance
         float k_last[MW];
-        const float b_last = (LAST_OK && p.last_w) ? p.last_b[0] : 0.f;
+        // (wave-uniform: kept in a scalar register - the float32 <2,3> instance has no vector register to spare)
+        const float b_last = (LAST_OK && p.last_w) ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.last_b[0]))) : 0.f;
         #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int cot = (mg * MW + m) * 16 + (lane & 15);
