@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip.so")
 # the stamped diagnostic build (--timeline) is a separate file: loaded only when FASTSVC_HIP_LIB names it
 TIMELINE_LIB_PATH = os.path.join(PKG_DIR, "libfastsvc_hip_timeline.so")
-SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_cond.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip", "fastsvc_loudness.hip", "fastsvc_stftloss.hip", "fastsvc_convgrad.hip", "fastsvc_filmnorm.hip", "fastsvc_gconv.hip"]
+SOURCES = ["fastsvc_kernels.hip", "fastsvc_hx.hip", "fastsvc_wx.hip", "fastsvc_cond.hip", "fastsvc_plan.cpp", "fastsvc_signal.hip", "fastsvc_loudness.hip", "fastsvc_stftloss.hip", "fastsvc_convgrad.hip", "fastsvc_filmnorm.hip", "fastsvc_gconv.hip"]
 HEADERS = [os.path.join(CSRC, "fastsvc_kernels.h"), os.path.join(ROOT, "include", "fastsvc_hip.h")]
 ARCH = "gfx950"
 
@@ -44,6 +44,8 @@ UNITS = [
     ("fastsvc_kernels.hip", ["-DFASTSVC_ACT_BF16=1"], "kernels_bf16.o"),
     ("fastsvc_hx.hip", [], "hx_f32.o"),
     ("fastsvc_hx.hip", ["-DFASTSVC_ACT_BF16=1"], "hx_bf16.o"),
+    ("fastsvc_wx.hip", [], "wx_f32.o"),
+    ("fastsvc_wx.hip", ["-DFASTSVC_ACT_BF16=1"], "wx_bf16.o"),
     # (-fno-honor-nans: LeakyReLU as max(v, 0.2 v) without the canonicalising v_max v, v, v in front of it)
     ("fastsvc_cond.hip", ["-fno-honor-nans"], "cond_f32.o"),
     ("fastsvc_cond.hip", ["-fno-honor-nans", "-DFASTSVC_ACT_BF16=1"], "cond_bf16.o"),
@@ -85,7 +87,8 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
     for src, extra, obj in UNITS:
         key = hashlib.sha1(open(os.path.join(CSRC, src), "rb").read() + hdr_hash.digest() +
                            " ".join(common + extra).encode()).hexdigest()[:16]
-        stem = os.path.splitext(obj)[0] + ("_tl" if timeline else "")
+        # (developer A/B builds keep their own objects: they must not evict the product build's from the cache)
+        stem = os.path.splitext(obj)[0] + ("_tl" if timeline else "") + ("_ab" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:6] if extra_flags else "")
         path = os.path.join(cache, f"{stem}_{key}.o")
         objs.append(path)
         if os.path.exists(path) and not force:

@@ -194,12 +194,10 @@ __device__ __forceinline__ void cs_layer(const unsigned char* in_plane, unsigned
         f32x4 acc[G];
         #pragma unroll
         for (int ii = 0; ii < G; ++ii) {
-            const int jr = CS_NQ * (grp * G + ii);     // tile index minus q
-            if constexpr (KIND == 1) acc[ii] = r1w * xs_sig[out_row0 + 16 * (q + jr) + l15] + kbv;
-            else acc[ii] = kbv;
+            // every accumulator starts from the bias vector - a register written long before the products; the rank-1
+            // residual joins AFTER them (see p0_layer_chunk: no VALU result is ever an MFMA's C operand)
+            acc[ii] = kbv;
         }
-        // (initial values written by the VALU just above: see the initial-value fence of p0_layer_chunk)
-        if constexpr (KIND == 1) asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
         #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
             #pragma unroll
@@ -213,6 +211,7 @@ __device__ __forceinline__ void cs_layer(const unsigned char* in_plane, unsigned
             // outside the utterance: the next conv's zero padding - applied to the PACKED values (one AND per register)
             const unsigned keep = (unsigned)(tbase + 16 * (q + jr)) < (unsigned)Tv ? 0xffffffffu : 0u;
             f32x4 v = acc[ii];
+            if constexpr (KIND == 1) v = r1w * xs_sig[out_row0 + 16 * (q + jr) + l15] + v;
             if constexpr (CS_NP == 2) v = v * kivv;
             if constexpr (KIND != 1) v = cs_lrelu4(v);
             cs_store4_masked(out_planes + wbase + jr * 16 * CS_ROW, lo_off, v, keep);
@@ -715,19 +714,15 @@ __device__ __forceinline__ void p0_layer_chunk(const unsigned char* in_plane, un
     for (int i = 0; i < N; ++i)
         #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            if constexpr (KIND == 1) acc[i][m] = r1wv[m] * xv[i] + kbv[m]; else acc[i][m] = kbv[m];
+            // Every accumulator starts from the bias vector, a register written long before the products; the rank-1 residual
+            // (KIND 1) joins AFTER them.  Round 5 computed r1w * x + bias here, (packed) float32 FMAs right in front of the
+            // v_mfma that read the result as its C operand, and the float32-storage pipeline returned run-to-run DIFFERENT values:
+            // single registers of lanes 48-63 of an initial value stale, in a handful of tiles per 10^6 at 64 x 1500
+            // (tools/cond_pipe_determinism.py) - hipcc's two wait states between such a write and the MFMA were not enough under
+            // this kernel's load; eight (`s_nop 7`) hid it, empirically.  Now no VALU result is ever an MFMA's C operand in these
+            // kernels: nothing to fence (tests/test_parity_gpu.py runs the determinism check at the shape that exposed it).
+            acc[i][m] = kbv[m];
         }
-    if constexpr (KIND == 1) {
-        // THE INITIAL-VALUE FENCE.  Here the accumulators' initial values come out of (packed) float32 FMAs, and hipcc puts
-        // two wait states between such a VALU write and the v_mfma_f32_16x16x32_f16 that reads the register as its C
-        // operand.  On gfx950 under this kernel's load that is not enough: the float32-storage pipeline returned
-        // run-to-run DIFFERENT values - single registers of lanes 48-63 of an initial value stale, i.e. output channels
-        // 12 / 14 of h off by the residual term in a handful of tiles per 10^6 (tools/cond_pipe_determinism.py: every one
-        // of 10 runs at 64 x 1500 differed; none with eight wait states here, 2 x 10 runs).  Layers whose accumulators
-        // start from registers written long before (bias vectors) have no such window.
-        #pragma unroll
-        for (int i = 0; i < N; ++i) asm volatile("s_nop 7" : "+v"(acc[i][0]), "+v"(acc[i][1]));
-    }
     #pragma unroll
     for (int tap = 0; tap < 3; ++tap)
         #pragma unroll
@@ -744,6 +739,7 @@ __device__ __forceinline__ void p0_layer_chunk(const unsigned char* in_plane, un
         #pragma unroll
         for (int m = 0; m < 2; ++m) {
             f32x4 v = acc[i][m];
+            if constexpr (KIND == 1) v = r1wv[m] * xv[i] + v;
             if constexpr (CS_NP == 2) v = v * kivv[m];
             if constexpr (KIND != 1) v = cs_lrelu4(v);
             unsigned char* dst = out_base + wr[m] + P * 16 * CS_ROW;
@@ -1226,12 +1222,13 @@ __device__ __forceinline__ void c1_layer(const unsigned char* in_planes, unsigne
         f32x4 acc[G];
         #pragma unroll
         for (int ii = 0; ii < G; ++ii) {
+            // KIND 1, bfloat16 storage: the residual conv's finished tile (an MFMA result) is the initial value; float32
+            // storage: it needs a multiply first, and a VALU result must not be an MFMA's C operand (see p0_layer_chunk):
+            // the products start from zero (an inline constant) and the scaled tile joins after them
             if constexpr (KIND == 1) {
-                if constexpr (CS_NP == 2) acc[ii] = racc[j0 + ii] * krv; else acc[ii] = racc[j0 + ii];
+                if constexpr (CS_NP == 2) acc[ii] = f32x4{0.f, 0.f, 0.f, 0.f}; else acc[ii] = racc[j0 + ii];
             } else acc[ii] = kbv;
         }
-        // (initial values written by the VALU just above: see the initial-value fence of p0_layer_chunk)
-        if constexpr (KIND == 1) asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
         #pragma unroll
         for (int ch = 0; ch < NC; ++ch)
             #pragma unroll
@@ -1245,6 +1242,7 @@ __device__ __forceinline__ void c1_layer(const unsigned char* in_planes, unsigne
         for (int ii = 0; ii < G; ++ii) {
             const unsigned keep = (unsigned)(tbase + 16 * (j0 + ii)) < (unsigned)Tv ? 0xffffffffu : 0u;
             f32x4 v = acc[ii];
+            if constexpr (CS_NP == 2 && KIND == 1) v = racc[j0 + ii] * krv + v;
             if constexpr (CS_NP == 2) v = v * kivv;
             if constexpr (KIND != 1) v = cs_lrelu4(v);
             cs_store4_masked(out_planes + wbase + (j0 + ii) * 16 * CS_ROW, lo_off, v, keep);

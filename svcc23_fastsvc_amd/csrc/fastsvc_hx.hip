@@ -48,124 +48,7 @@ namespace bf16 {
 
 #include "fastsvc_device.inc"
 
-#ifdef FASTSVC_ACT_BF16
-typedef __bf16 hx_t;
-constexpr int HX_NP = 1;                 // operand pieces: bf16 product of the rounded operands
-#else
-typedef _Float16 hx_t;
-constexpr int HX_NP = 2;                 // hi + lo binary16 pieces, three products
-#endif
-typedef hx_t hx8 __attribute__((ext_vector_type(8)));
-typedef hx_t hx2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x4 hx_mfma(hx8 a, hx8 b, f32x4 c) {
-#ifdef FASTSVC_ACT_BF16
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-#else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-#endif
-}
-
-// what a staging thread holds of one channel of its item between the request and the commit: the loaded words as they
-// are (bfloat16 storage: two dwords, converted in the commit - see act4_t); the raw float32 signal of MODE_CHAIN1
-template <bool IN1> struct HxWin { typedef act4_t type; };
-template <> struct HxWin<true> { typedef f32x4 type; };
-constexpr int HX_KC = 32;                // input channels per K chunk = one MFMA K step per tap
-constexpr int HX_ROW = 64;               // bytes of one LDS tile row (32 channels)
-constexpr int HX_FRAG = 1024;            // bytes of one packed weight fragment (64 lanes x 8 halves)
-
-// LDS byte offset of 16-byte slot `oct` of tile row `row`: rows with bit 2 set swap places inside their pair,
-// slots 0/1 swap with 2/3 in those rows.  Conflict-free for ds_read_b128 at ANY row offset (four 16-lane
-// service groups over 64 banks) and for the producers' ds_write_b128 (8-lane groups = 4 slots x 2 row quads over
-// 32 banks) - searched exhaustively, see DESIGN.md.
-__device__ __forceinline__ int hx_lds_off(int row, int oct) {
-    return ((row ^ ((row >> 2) & 1)) * HX_ROW) + ((oct ^ ((row >> 1) & 2)) << 4);
-}
-
-// s_waitcnt vmcnt(k) for a wave-uniform run-time count: the largest supported k <= n (a smaller k only waits for more)
-__device__ __forceinline__ void hx_wait_vmcnt(int n) {
-    if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// Unit-deep weight ring: NSLOT fragments = every fragment of one (tile, chunk) unit of this wave's channel
-// group, statically indexed; slot s is re-requested with the NEXT unit's fragment s right after its last use.
-template <int NSLOT>
-struct HxWeightStream {
-    u32x4 wr[NSLOT];
-    __amdgpu_buffer_rsrc_t rsrc;
-    int voff, next, total;
-    __device__ __forceinline__ void init(const unsigned char* group_base, int nunits, int lane) {
-        total = nunits * NSLOT * HX_FRAG;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(group_base), 0, total, 0x00020000);
-        voff = lane * 16;
-        #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) wr[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s * HX_FRAG, 0);
-        next = NSLOT * HX_FRAG;
-        if (next >= total) next = 0;
-    }
-    __device__ __forceinline__ void request(int s) { wr[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, next + s * HX_FRAG, 0); }
-    __device__ __forceinline__ void advance() { next += NSLOT * HX_FRAG; if (next >= total) next = 0; }
-};
-
-struct HxFrag { hx8 p[HX_NP]; };
-
-__device__ __forceinline__ HxFrag hx_read(const unsigned char* tile, int off, int lo_off) {
-    HxFrag f;
-    f.p[0] = *reinterpret_cast<const hx8*>(tile + off);
-    if constexpr (HX_NP == 2) f.p[1] = *reinterpret_cast<const hx8*>(tile + lo_off + off);
-    return f;
-}
-
-// acc += a (.) w for one 16x16 tile and 32 input channels: hh + hl + lh (split) or one product (bf16).
-// Callers interleave independent accumulators between the products of one (the loops below run the product
-// index outermost) so that no MFMA waits for the previous one's result.
-// SWAP: the operands trade places, i.e. the result tile comes out transposed - a lane then owns 4 consecutive
-// CHANNELS of one time step instead of 4 time steps of one channel (MODE_CHAIN writes that tile back to LDS in
-// the time-major operand format: 8-byte stores instead of 2-byte ones).
-template <int PROD, bool SWAP = false>
-__device__ __forceinline__ f32x4 hx_prod(const HxFrag& a, const u32x4 (&w)[HX_NP], f32x4 acc) {
-    constexpr int ia = (HX_NP == 2 && PROD == 2) ? 1 : 0, iw = (HX_NP == 2 && PROD == 1) ? 1 : 0;
-    if constexpr (SWAP) return hx_mfma(__builtin_bit_cast(hx8, w[iw]), a.p[ia], acc);
-    else return hx_mfma(a.p[ia], __builtin_bit_cast(hx8, w[iw]), acc);
-}
-constexpr int HX_NPROD = HX_NP == 2 ? 3 : 1;
-
-// One step = the MFMAs of ONE weight slot (MW channel tiles) on ONE time tile.  The steps of a unit run
-// slot-major, so that a slot's fragments are re-requested (for the next unit) right after their last use and
-// fly for a whole unit; the A fragments of step s+1 are read from LDS before the MFMAs of step s.
-template <int MW, bool SWAP = false>
-__device__ __forceinline__ void hx_step(f32x4 (&acc)[MW], const HxFrag& a, const u32x4* w /* [MW][HX_NP] */) {
-    #pragma unroll
-    for (int pr = 0; pr < HX_NPROD; ++pr)
-        #pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            u32x4 wm[HX_NP];
-            #pragma unroll
-            for (int q = 0; q < HX_NP; ++q) wm[q] = w[m * HX_NP + q];
-            if (pr == 0) acc[m] = hx_prod<0, SWAP>(a, wm, acc[m]);
-            else if (pr == 1) acc[m] = hx_prod<1, SWAP>(a, wm, acc[m]);
-            else acc[m] = hx_prod<2, SWAP>(a, wm, acc[m]);
-        }
-}
-__device__ __forceinline__ HxFrag hx_neg(HxFrag a) {
-    #pragma unroll
-    for (int q = 0; q < HX_NP; ++q) {
-        u32x4 b = __builtin_bit_cast(u32x4, a.p[q]);
-        b ^= 0x80008000u;
-        a.p[q] = __builtin_bit_cast(hx8, b);
-    }
-    return a;
-}
+#include "fastsvc_hx_common.inc"
 
 // DIRECT unit: acc[n][m] += sum_tap X[t + (tap-1) d] W[tap].  aoff[tap]: this lane's byte offset of (row of
 // time tile 0 shifted by the tap, its octet).
@@ -295,42 +178,6 @@ __device__ __forceinline__ void hx_unit_dec2(f32x4 (&acc)[2][NW][MW], const unsi
     if (RELOAD) ws.advance();
 }
 
-// convert / split 8 channel values of one time step into the tile's 16-byte slot(s)
-// Low pieces of a pair of staged values: lo = f16(e - (float)hi), ONE mixed-precision FMA each (binary16 source from
-// either half of the packed hi register, f32 addend, binary16 result into the low / high half of the destination).
-// e - hi is exact in float32, so the single rounding is the one the convert-back / subtract / convert sequence made:
-// bit-identical.  hipcc forms this instruction from the plain expression in a few instances only; in the hot ones it
-// emitted v_cvt_f32_f16 + v_sub / v_fma + v_cvt_pk_f16_f32 - 2.5 instructions per value where this is 1 - and the
-// staging waves are the critical path of every narrow layer.
-__device__ __forceinline__ unsigned hx_lo_pair(unsigned hi_pair, float e0, float e1) {
-    unsigned d;
-    const float minus1 = -1.0f;
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi_pair), "s"(minus1), "v"(e0));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi_pair), "s"(minus1), "v"(e1));
-    return d;
-}
-
-__device__ __forceinline__ void hx_commit_slot(unsigned char* tile, int off, int lo_off, const float (&e)[8]) {
-    // float32 storage: the staged values are pre-scaled so that |e| < 2^15 by construction (hx_scale_for of a
-    // measured maximum, of a bound derived from one through the layers' l1 / bmax, or of the bound of a normalised
-    // row): binary16 cannot overflow and no clamp is needed - the staging waves are the critical path of every
-    // narrow layer, and the two v_med3 per pair were 1 of their ~5.5 instructions per value.
-    hx8 h;
-    #pragma unroll
-    for (int c = 0; c < 8; ++c) h[c] = (hx_t)e[c];
-    *reinterpret_cast<hx8*>(tile + off) = h;
-    if constexpr (HX_NP == 2) {
-        // low piece = f16(e - hi): written as an FMA on the binary16 value so that it maps onto the mixed-precision
-        // FMA (f16 source, f32 source, f16 result) instead of convert-back, subtract, convert
-        typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
-        const u32x4w hp = __builtin_bit_cast(u32x4w, h);
-        u32x4w lp;
-        #pragma unroll
-        for (int k = 0; k < 4; ++k) lp[k] = hx_lo_pair(hp[k], e[2 * k], e[2 * k + 1]);
-        *reinterpret_cast<u32x4w*>(tile + lo_off + off) = lp;
-    }
-}
-
 // MODE_CHAIN: the first conv's result tiles -> the intermediate LDS tile the second conv reads, in the
 // producers' format (time-major rows of 32 channels, hi + lo pieces, same swizzle):
 //   T2[row][co] = split(lrelu(acc + bias_mid)),  0 where the column lies outside the utterance (the second
@@ -386,200 +233,6 @@ __device__ __forceinline__ void hx_chain_store(const f32x4 (&acc)[NA][MW], int n
 }
 
 #ifdef FASTSVC_ACT_BF16
-// ---------------------------------------------------------------------------------------------------------
-// bfloat16 storage: 8-wide tile epilogue.  In the MFMA result layout a lane owns 4 consecutive time steps of
-// one channel = 8 BYTES of bf16, so every epilogue access of a wave was 16 rows x 32-byte segments (measured:
-// 4.2 TB/s for that shape against 5.8 TB/s for 16-byte lanes, tools/micro/rw_pattern.hip, and twice the
-// memory instructions).  Two neighbouring 16-column tiles are therefore re-laid through a wave-private LDS
-// patch so that a lane owns 8 consecutive time steps (16 B): lane (co = lane & 15, g = lane >> 4) of the pair
-// k holds columns 32 k + 8 g .. + 8.  Every load / store / LDS-DMA piece of the epilogue is then 16 B per lane.
-// ---------------------------------------------------------------------------------------------------------
-struct f32x8 { f32x4 lo, hi; };
-
-__device__ __forceinline__ f32x8 bf8_unpack(u32x4 w) {
-    f32x8 r;
-    r.lo = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
-                 __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
-    r.hi = f32x4{__builtin_bit_cast(float, w.z << 16), __builtin_bit_cast(float, w.z & 0xffff0000u),
-                 __builtin_bit_cast(float, w.w << 16), __builtin_bit_cast(float, w.w & 0xffff0000u)};
-    return r;
-}
-__device__ __forceinline__ u32x4 bf8_pack(const f32x8& v) {
-    u32x4 w;
-    w.x = bf16_pack2(v.lo.x, v.lo.y);
-    w.y = bf16_pack2(v.lo.z, v.lo.w);
-    w.z = bf16_pack2(v.hi.x, v.hi.y);
-    w.w = bf16_pack2(v.hi.z, v.hi.w);
-    return w;
-}
-// boff: BYTE offset of the lane's first element inside the descriptor
-__device__ __forceinline__ f32x8 act_load8(__amdgpu_buffer_rsrc_t r, int boff, int soff) {
-    return bf8_unpack(__builtin_amdgcn_raw_buffer_load_b128(r, boff, soff, 0));
-}
-// nv: valid elements of the lane (0, 4 or 8 - rows are a multiple of 4 long)
-__device__ __forceinline__ void act_store8_raw(__amdgpu_buffer_rsrc_t r, int boff, const u32x4& w, int nv) {
-    if (__builtin_amdgcn_ballot_w64(nv == 4) == 0) {           // wave-uniform: no half lane (nearly always)
-        __builtin_amdgcn_raw_buffer_store_b128(w, r, nv > 0 ? boff : OOB_OFF, 0, 0);
-    } else {
-        u32x2v a, b;
-        a.x = w.x; a.y = w.y; b.x = w.z; b.y = w.w;
-        __builtin_amdgcn_raw_buffer_store_b64(a, r, nv >= 4 ? boff : OOB_OFF, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(b, r, nv >= 8 ? boff + 8 : OOB_OFF, 0, 0);
-    }
-}
-__device__ __forceinline__ void act_store8(__amdgpu_buffer_rsrc_t r, int boff, const f32x8& v, int nv) {
-    act_store8_raw(r, boff, bf8_pack(v), nv);
-}
-__device__ __forceinline__ f32x8 keep8_exact(f32x8 v, int nv) {       // zero the elements at and past index nv (any nv)
-    #pragma unroll
-    for (int e = 0; e < 4; ++e) { v.lo[e] = e < nv ? v.lo[e] : 0.f; v.hi[e] = 4 + e < nv ? v.hi[e] : 0.f; }
-    return v;
-}
-__device__ __forceinline__ f32x8 keep8(f32x8 v, int nv) {
-    if (nv < 8) v.hi = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nv < 4) v.lo = f32x4{0.f, 0.f, 0.f, 0.f};
-    return v;
-}
-constexpr int EST8_ITEM_BYTES = 1024;                       // one 16-byte LDS-DMA piece per lane
-
-// two neighbouring 16 x 16 result tiles of one channel tile -> pair layout, through the wave's LDS patch
-// Xw ([16][36] floats; LDS executes a wave's accesses in order, so the patch is reused tile pair after tile pair)
-__device__ __forceinline__ f32x8 hx_pair(const f32x4& a0, const f32x4& a1, float* Xw, int lane) {
-    constexpr int XS8 = 36;
-    float* row = Xw + (lane & 15) * XS8;
-    *reinterpret_cast<f32x4*>(row + (lane >> 4) * 4) = a0;
-    *reinterpret_cast<f32x4*>(row + 16 + (lane >> 4) * 4) = a1;
-    // lanes read what OTHER lanes of the wave wrote: per thread the addresses never overlap, so without a
-    // wave-level fence hipcc hoists the first read above the second write (seen in the ISA)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    f32x8 out;
-    out.lo = *reinterpret_cast<const f32x4*>(row + (lane >> 4) * 8);
-    out.hi = *reinterpret_cast<const f32x4*>(row + (lane >> 4) * 8 + 4);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return out;
-}
-
-// LDS-DMA pieces of the pair epilogue's operands (see ws_epilogue_stage): [scale, shift, residual][m][k][64 lanes] x 16 B
-template <int MW, int NP2, int EPI>
-__device__ __forceinline__ void hx_epilogue8_stage(const ConvParams& p, const EpiRsrc& R, const float* Ew, int mg, int tcol0, int lane) {
-    const int shift_soff = p.COUT * p.ldy * 2;
-    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)Ew;
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int cot = (mg * MW + m) * 16 + (lane & 15);
-        const bool cok = cot < p.COUT;
-        const int rowoff = (cok ? cot : 0) * p.ldy;
-        #pragma unroll
-        for (int k = 0; k < NP2; ++k) {
-            const int t = tcol0 + k * 32 + (lane >> 4) * 8;
-            const int boff = (cok && t < p.T) ? (rowoff + t) * 2 : OOB_OFF;
-            const unsigned slot = base + (m * NP2 + k) * EST8_ITEM_BYTES;
-            if (EPI == EPI_RES) lds_dma16(R.res, slot, boff, 0);
-            if (EPI == EPI_AFF) {
-                lds_dma16(R.ss, slot, boff, 0);
-                lds_dma16(R.ss, slot + MW * NP2 * EST8_ITEM_BYTES, boff, shift_soff);
-                if (p.res) lds_dma16(R.res, slot + 2 * MW * NP2 * EST8_ITEM_BYTES, boff, 0);
-            }
-        }
-    }
-}
-
-// TAILK (see conv_hx_kernel): rows may end inside a group of 4 - the straddling group is stored whole (the pitch is
-// a multiple of 4) and only the InstanceNorm sums are masked element by element
-// LRB: the LeakyReLU behind a wave-uniform branch (the middle convs of the up blocks have none: 32 instructions per
-// item less); off where the branch costs the instance its register budget
-template <int MW, int NP2, int EPI, bool EST, bool TAILK = false, bool LRB = true, class KT>
-__device__ __forceinline__ void hx_epilogue8(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[2 * NP2][MW],
-                                             float (&s1)[MW], float (&s2)[MW], int sig, int mg, int tcol0,
-                                             bool active, int lane, const KT& K, const float* Ew, float* Xw) {
-    if (!active) return;
-    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;
-    const int shift_soff = p.COUT * p.ldy * 2;
-    const f32x8 zero8 = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int cot = (mg * MW + m) * 16 + (lane & 15);
-        const bool cok = cot < p.COUT;
-        const int co = cok ? cot : 0;
-        const float bias = K.bias(p, sig, m, cot);
-        float r1w = 0.f, r1b = 0.f;
-        if (EPI == EPI_RANK1) { r1w = K.r1w(p, sig, m, co); r1b = K.r1b(p, sig, m, co); }
-        const int rowoff = co * p.ldy;
-        // pairs whose loads fly together (register budget: 24 registers per pair with the FiLM operands)
-        constexpr int G = (EPI == EPI_AFF) ? 1 : (NP2 % 2 == 0 ? 2 : 1);
-        #pragma unroll
-        for (int k0 = 0; k0 < NP2; k0 += G) {
-            int boff[G], nv[G];
-            f32x8 l0[G], l1[G], l2[G];
-            u32x4 w0[G], w1[G], w2[G];                             // (direct loads: raw words, converted behind the re-layout below)
-            #pragma unroll
-            for (int g = 0; g < G; ++g) {                          // every load of the group first
-                const int k = k0 + g;
-                const int t = tcol0 + k * 32 + (lane >> 4) * 8;
-                const bool ok = cok && t < p.T;
-                nv[g] = ok ? min(8, p.T - t) : 0;                  // (TAILK: any count; the stores round it up to 4)
-                boff[g] = ok ? (rowoff + t) * 2 : OOB_OFF;
-                l0[g] = zero8; l1[g] = zero8; l2[g] = zero8;
-                w0[g] = w1[g] = w2[g] = u32x4{0u, 0u, 0u, 0u};
-                if constexpr (EST) {
-                    const u32x4* slot = reinterpret_cast<const u32x4*>(Ew) + (m * NP2 + k) * 64 + lane;
-                    if (EPI == EPI_RES) l0[g] = bf8_unpack(slot[0]);
-                    if (EPI == EPI_AFF) {
-                        l1[g] = bf8_unpack(slot[0]);
-                        l2[g] = bf8_unpack(slot[MW * NP2 * 64]);
-                        if (p.res) l0[g] = bf8_unpack(slot[2 * MW * NP2 * 64]);
-                    }
-                } else {
-                    if (EPI == EPI_RES) w0[g] = __builtin_amdgcn_raw_buffer_load_b128(R.res, boff[g], 0, 0);
-                    if (EPI == EPI_RANK1) {                        // the raw float32 signal
-                        l0[g].lo = buf_load4(R.r1x, ok ? t * 4 : OOB_OFF, 0);
-                        l0[g].hi = buf_load4(R.r1x, (ok && nv[g] > 4) ? t * 4 + 16 : OOB_OFF, 0);
-                    }
-                    if (EPI == EPI_AFF) {
-                        w0[g] = __builtin_amdgcn_raw_buffer_load_b128(R.res, boff[g], 0, 0);      // zero-length descriptor when absent
-                        w1[g] = __builtin_amdgcn_raw_buffer_load_b128(R.ss, boff[g], 0, 0);
-                        w2[g] = __builtin_amdgcn_raw_buffer_load_b128(R.ss, boff[g], shift_soff, 0);
-                    }
-                }
-            }
-            #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                f32x8 v = hx_pair(acc[2 * (k0 + g)][m], acc[2 * (k0 + g) + 1][m], Xw, lane);
-                if constexpr (!EST) {
-                    if (EPI == EPI_RES || EPI == EPI_AFF) l0[g] = bf8_unpack(w0[g]);
-                    if (EPI == EPI_AFF) { l1[g] = bf8_unpack(w1[g]); l2[g] = bf8_unpack(w2[g]); }
-                }
-                v.lo += bias; v.hi += bias;
-                if (!LRB || (p.flags & F_POST_LRELU)) {            // (wave-uniform)
-                    #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v.lo[e] = fmaxf(v.lo[e], v.lo[e] * slope); v.hi[e] = fmaxf(v.hi[e], v.hi[e] * slope); }
-                }
-                if (EPI == EPI_RES || EPI == EPI_AFF) { v.lo += l0[g].lo; v.hi += l0[g].hi; }
-                if (EPI == EPI_RANK1) { v.lo += l0[g].lo * r1w + r1b; v.hi += l0[g].hi * r1w + r1b; }
-                acc[2 * (k0 + g)][m] = v.lo; acc[2 * (k0 + g) + 1][m] = v.hi;     // (finished values, in the pair layout)
-                const int nvs = TAILK ? ((nv[g] + 3) & ~3) : nv[g];
-                if (!LRB || p.y) act_store8(R.y, boff[g], v, nvs);  // (wave-uniform; a store to the absent tensor's empty descriptor still costs its issue and the conversion)
-                if (EPI == EPI_AFF) {
-                    f32x8 u;
-                    u.lo = l1[g].lo * v.lo + l2[g].lo; u.hi = l1[g].hi * v.hi + l2[g].hi;
-                    u = TAILK ? keep8_exact(u, nv[g]) : keep8(u, nv[g]);
-                    act_store8(R.y2, boff[g], u, nvs);
-                    // (two lanes of packed float32 per instruction: 3 + 1 adds and 4 FMAs + 1 add instead of 7 + 15)
-                    typedef float f32x2s __attribute__((ext_vector_type(2)));
-                    const f32x2s p0 = {u.lo.x, u.lo.y}, p1 = {u.lo.z, u.lo.w}, p2 = {u.hi.x, u.hi.y}, p3 = {u.hi.z, u.hi.w};
-                    const f32x2s sm = (p0 + p1) + (p2 + p3);
-                    const f32x2s sq = p0 * p0 + p1 * p1 + (p2 * p2 + p3 * p3);
-                    s1[m] += sm.x + sm.y;
-                    s2[m] += sq.x + sq.y;
-                }
-            }
-        }
-    }
-}
 // Polyphase epilogue in bfloat16 storage: a lane's 4 S consecutive output samples go out as 16-byte pieces
 // (8 samples; one 8-byte piece left over for odd S) instead of S 8-byte ones (see ws_epilogue_poly).
 template <int MW, int NW, int EPI, int S, bool TAILK = false, class KT>
@@ -836,15 +489,15 @@ __device__ __forceinline__ void hx_epilogue_dec2_staged(const ConvParams& p, con
         const unsigned char* src = Pw + (idx < ITEMS ? row * PB + piece * 16 : 0);
         const u32x4 wa = *reinterpret_cast<const u32x4*>(src), wb = *reinterpret_cast<const u32x4*>(src + TB);
         if (__builtin_amdgcn_ballot_w64(nvs == 4) == 0) {   // wave-uniform: no half piece (nearly always)
-            __builtin_amdgcn_raw_buffer_store_b128(wa, R.y, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(wb, R.y2, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(wa, R.y, off, 0, FASTSVC_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(wb, R.y2, off, 0, FASTSVC_ST_AUX);
         } else {
             u32x2v a0, a1, b0, b1;
             a0.x = wa.x; a0.y = wa.y; a1.x = wa.z; a1.y = wa.w; b0.x = wb.x; b0.y = wb.y; b1.x = wb.z; b1.y = wb.w;
-            __builtin_amdgcn_raw_buffer_store_b64(a0, R.y, nvs >= 4 ? off : OOB_OFF, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(a1, R.y, nvs >= 8 ? off + 8 : OOB_OFF, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(b0, R.y2, nvs >= 4 ? off : OOB_OFF, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(b1, R.y2, nvs >= 8 ? off + 8 : OOB_OFF, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(a0, R.y, nvs >= 4 ? off : OOB_OFF, 0, FASTSVC_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(a1, R.y, nvs >= 8 ? off + 8 : OOB_OFF, 0, FASTSVC_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(b0, R.y2, nvs >= 4 ? off : OOB_OFF, 0, FASTSVC_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(b1, R.y2, nvs >= 8 ? off + 8 : OOB_OFF, 0, FASTSVC_ST_AUX);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

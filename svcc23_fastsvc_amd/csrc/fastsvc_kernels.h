@@ -272,7 +272,7 @@ struct ConvLaunch {
     int NW;      // 16-column time tiles per wave (1, 2 or 4)
     int WM, WN;  // waves per workgroup along output channels / time (WM * WN == 4)
     int nsig;
-    int pipe;    // 1: pipelined float4 kernel, 0: generic scalar-staging kernel (WM=1, WN=4)
+    int pipe;    // 1: pipelined float4 kernel, 0: generic scalar-staging kernel (WM=1, WN=4), 2: conv_hx, 3: conv_wx
 };
 
 // the pipelined kernel needs 24-channel K chunks and no fused input affine; any row length
@@ -300,6 +300,11 @@ bool conv_hx_tail_ok(int mode, int MW, int epi_kind, int S);
 // whether the MODE_DIRECT instances with a second, stretched operand (ConvParams::x2) exist for this channel-tile count,
 // number of K chunks and stretch factor
 bool conv_hx_x2_ok(int MW, int nch32, int s2);
+
+// the wide-layer kernel in which every wave multiplies (fastsvc_wx.hip): MODE_DIRECT, 48-channel groups (MW = 3), weights
+// through LDS by LDS-DMA; bfloat16 storage.  cfg.pipe is ignored; same ConvParams as launch_conv_hx.
+hipError_t launch_conv_wx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
+bool conv_wx_shape(int mode, int MW, int NW, int WM, int WN);
 
 // down-sampling stage 0, first conv (C_in = 1, k = 3, d = 1, LeakyReLU on the input):
 //   y[sig][b][co][t] = bias[co] + sum_tap w[co][tap] * lrelu(x[sig][b][t + tap - 1])
@@ -348,6 +353,7 @@ hipError_t launch_spk_proj(const float* emb, const SpkBlock* blocks, int nblocks
 namespace bf16 {
 hipError_t launch_conv(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 hipError_t launch_conv_hx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
+hipError_t launch_conv_wx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 hipError_t launch_in1_conv(const float* x, long x_sig, const float* w, const float* bias, long w_sig, long b_sig,
                            float* y, int nsig, int B, int C, int T, const int* lens, int len_mul, hipStream_t stream,
                            float* amax_out = nullptr);

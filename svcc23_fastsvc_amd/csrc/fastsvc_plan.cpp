@@ -2053,6 +2053,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
     p.w = blob + c.w_off; p.w_sig = pair_w_stride;
     const bool act_bf16 = g_tune.plan && g_tune.plan->storage == 1;
     auto launch = [&](const ConvParams& q, const ConvLaunch& Lq, hipStream_t st) {
+        if (Lq.pipe == 3) return act_bf16 ? bf16::launch_conv_wx(q, Lq, st) : launch_conv_wx(q, Lq, st);
         if (Lq.pipe == 2) return act_bf16 ? bf16::launch_conv_hx(q, Lq, st) : launch_conv_hx(q, Lq, st);
         return act_bf16 ? bf16::launch_conv(q, Lq, st) : launch_conv(q, Lq, st);
     };
@@ -2148,6 +2149,22 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                     !(p.mode == MODE_DIRECT && epi_kind >= 3 && sh[0] * c.MW > 12))   // FiLM-affine / rank-1 epilogues: those tiles spill
                     cands.push_back(Cand{sh[0], sh[1], sh[2], 3});
         }
+        // The wide-layer kernel (fastsvc_wx.hip, algorithm 6): every wave multiplies, weights through LDS.  Direct launches of
+        // the 48-channel-group layers (C >= 96) in bfloat16 storage with a plain / residual / FiLM-affine epilogue.
+        // FASTSVC_WX = 0: off, 2: wherever it exists (A/B, tests), else by the launch table / tuning
+        static const int wx_env = std::getenv("FASTSVC_WX") ? std::atoi(std::getenv("FASTSVC_WX")) : 1;
+        const bool wx_ok = hx_ok && wx_env != 0 && act_bf16 && p.mode == MODE_DIRECT && c.MW == 3 && !ragged_tail && !p.last_w &&
+                           !p.r1x && !p.x2 && !p.xsplit && (epi_kind == 1 || epi_kind == 2 || epi_kind == 4);
+        bool wx_have = false;                            // ... and the layer has a shape of it
+        if (wx_ok) {
+            static const int wshapes[][3] = {{8, 4, 2}, {4, 4, 2}, {6, 2, 4}};
+            for (const auto& sh : wshapes)
+                if (conv_wx_shape(p.mode, c.MW, sh[0], sh[1], sh[2]) && c.ngroups % sh[1] == 0) {
+                    cands.push_back(Cand{sh[0], sh[1], sh[2], 6});
+                    wx_have = true;
+                }
+        }
+        const bool wx_force = wx_env == 2 && wx_have;
         if (p.last_w) {
             // conv_last rides on the half-precision instances with one workgroup row of channel groups; it saves a
             // launch and a write + read of the block's output, more than any shape of the other family wins back:
@@ -2163,7 +2180,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             // whatever the padded maximum is): only the variants compiled with the row-end handling
             std::vector<Cand> keep;
             for (const Cand& cd : cands)
-                if (cd.algo == 3 ? (p.T & 3) == 0 :            // (hx candidates are only there when hx_tail_ok)
+                if (cd.algo == 6 ? false : cd.algo == 3 ? (p.T & 3) == 0 :            // (hx candidates are only there when hx_tail_ok)
                     conv_ws_tail_ok(cd.algo == 2 ? 2 : c.MW, cd.NW, is_wino(cd.algo) ? (int)MODE_WINO : p.mode, epi_kind,
                                     poly ? p.s : 1)) keep.push_back(cd);
             if (!keep.empty()) cands.swap(keep);       // (never empty: NW <= 2 variants always have it)
@@ -2172,13 +2189,15 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         // LDS geometry of a candidate: row stride (== 16 mod 32) and, for Winograd, the phase-plane
         // stride that keeps the component reads conflict-free (planes land 16/D banks apart)
         auto geometry = [&](const Cand& cd, ConvParams& q) {
-            if (cd.algo == 3) {
+            if (cd.algo == 3 || cd.algo == 6) {
                 const int prec = act_bf16 ? 1 : 0;
                 q.whx = blob + (p.mode == MODE_POLY ? c.hxp_off[prec] : c.hx_off[prec]); q.whx_sig = c.hx_pair[prec]; q.nch32 = c.nch32;
                 const size_t inv_off = p.mode == MODE_POLY ? c.hxp_inv_off : c.hx_inv_off;
                 q.whx_inv = (prec == 0 && inv_off) ? blob + inv_off : nullptr; q.whx_inv_sig = c.hx_inv_pair;
                 static const int stagger = std::getenv("FASTSVC_STAGGER") ? std::atoi(std::getenv("FASTSVC_STAGGER")) : 2;
-                q.stagger = stagger;
+                // (conv_wx: start delay between the workgroups of an XCD, in 64-cycle steps per K chunk - an eighth of a unit)
+                static const int wx_stagger = std::getenv("FASTSVC_WX_STAGGER") ? std::atoi(std::getenv("FASTSVC_WX_STAGGER")) : 6;
+                q.stagger = cd.algo == 6 ? wx_stagger : stagger;
                 q.xs = 0; q.ps = 0;
             } else if (cd.algo >= 1) {
                 const int NTo = 32 * cd.NW * cd.WN, D = c.dil;
@@ -2208,7 +2227,8 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 for (const Cand& cd : cands)
                     if (cd.NW == it->second.NW && cd.WM == it->second.WM && cd.WN == it->second.WN &&
                         cd.algo == it->second.algo && it->second.tpw >= 1 && it->second.tpw <= 64 &&
-                        !(hx_env == 2 && hx_ok && cd.algo != 3)) {        // FASTSVC_HX=2: older tables do not hold it back
+                        !(hx_env == 2 && hx_ok && cd.algo != 3 && cd.algo != 6) &&   // FASTSVC_HX=2: older tables do not hold it back
+                        !(wx_force && cd.algo != 6)) {
                         best = cd; p.tpw = it->second.tpw;
                         have = true;
                     }
@@ -2227,12 +2247,14 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             for (const Cand& cd : cands) {
                 const int NT = (is_wino(cd.algo) ? 32 : 16) * cd.NW * cd.WN;
                 const long ntx = (p.T + NT - 1) / NT;
+                if (wx_force && cd.algo != 6) continue;                   // FASTSVC_WX=2: only the wide-layer kernel's shapes
                 q = p; q.flags &= ~F_STATS;
                 geometry(cd, q);
                 for (int tpw : tpws) {
                     q.tpw = tpw;
-                    ConvLaunch Lq{cd.algo == 2 ? 2 : c.MW, cd.NW, cd.WM, cd.WN, nsig, cd.algo == 3 ? 2 : 1};
+                    ConvLaunch Lq{cd.algo == 2 ? 2 : c.MW, cd.NW, cd.WM, cd.WN, nsig, cd.algo == 6 ? 3 : cd.algo == 3 ? 2 : 1};
                     hipError_t e = launch(q, Lq, stream);                 // warm
+                    if (e != hipSuccess && cd.algo == 6) break;           // (this shape does not fit the layer's LDS budget)
                     if (e != hipSuccess) return e;
                     hipEventRecord(e0, stream);
                     for (int r = 0; r < 3; ++r) { e = launch(q, Lq, stream); if (e != hipSuccess) return e; }
@@ -2257,7 +2279,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         // tools/costmodel_gap.py) - and only the tiles per workgroup from the model.
         bool prior_pick = false;
         static const int prior_env = std::getenv("FASTSVC_PRIOR") ? std::atoi(std::getenv("FASTSVC_PRIOR")) : 1;
-        if (!have && g_tune.plan && prior_env) {
+        if (!have && g_tune.plan && prior_env && !wx_force) {
             fastsvc_plan::Choice pr{0, 0, 0, 0, -1};
             {
                 std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
@@ -2291,6 +2313,19 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             // Winograd variant loses to the scalar phase-plane staging.  FASTSVC_WINO = 0 / 1 / 2
             // forces direct / layer grouping / 32-channel grouping.
             const int wino_pref = wino_env >= 0 ? wino_env : (c.MW == 2 ? 0 : 2);
+            if (cd.algo == 6) {
+                // no model of its own: taken by table / prior, or wherever it exists with FASTSVC_WX=2 (first shape that fits,
+                // one round of workgroups where the batch allows)
+                if (!(prior_pick || wx_force)) continue;
+                const int NT = 16 * cd.NW * cd.WN;
+                const long ntx = (p.T + NT - 1) / NT;
+                const long gy = c.ngroups / cd.WM;
+                int tpw = 1;
+                while (tpw < 24 && ((ntx + tpw - 1) / tpw) * gy * zb > 256) ++tpw;
+                if (best_t > 0.0) { best_t = 0.0; best = cd; p.tpw = tpw; }
+                continue;
+            }
+            if (wx_force) continue;
             if (!prior_pick && hx_ok != (cd.algo == 3)) continue;          // the half-precision MFMA variant wherever the layer has one
             if (cd.algo == 3) {
                 // data-movement model: one workgroup per CU; a unit moves its window in and (per tile) its
@@ -2345,7 +2380,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             }
         }
         }
-        L.pipe = best.algo == 3 ? 2 : 1;
+        L.pipe = best.algo == 6 ? 3 : best.algo == 3 ? 2 : 1;
         L.NW = best.NW; L.WM = best.WM; L.WN = best.WN;
         if (p.last_w) g_last_fused = true;                  // (the candidates were restricted to the instances that have it)
         if (best.algo == 2) L.MW = 2;
@@ -2385,7 +2420,10 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
             bytes += 4.0 * cols;
         }
         char kname[40];
-        if (L.pipe == 2) {
+        if (L.pipe == 3) {
+            const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+            std::snprintf(kname, sizeof(kname), "conv_wx<%d,%d,%d,%d,%d,%s>", L.MW, L.NW, L.WM, L.WN, aff ? 4 : p.res ? 2 : 1, act_bf16 ? "x1" : "x3");
+        } else if (L.pipe == 2) {
             const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
             const int kind = aff ? 4 : p.r1x ? 3 : p.res ? 2 : 1;
             const bool tail_inst = p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0);      // the row-end (TAILK) instance

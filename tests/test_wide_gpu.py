@@ -1,0 +1,126 @@
+"""The wide-layer kernel (csrc/fastsvc_wx.hip: every wave multiplies, weights through LDS by LDS-DMA) against the
+wave-specialised kernels it replaces (csrc/fastsvc_hx.hip) and against the oracle.
+
+Reference layers: the C >= 96 convolutions of `FastSVCDownsampleNet` / `FastSVCFiLMNet` / `FastSVCUpsampleNet`
+(harana/models/fastsvc.py:164-178, 209-232, 94-112)."""
+import numpy as np
+import pytest
+import torch
+
+import svcc23_fastsvc_amd as A
+from svcc23_fastsvc_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (and fail loudly without one)"
+    A.load_library()
+    return torch.device("cuda:0")
+
+
+def _to(dev, *arrs):
+    return [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+
+
+def _wide_table(B, F, tpw=2):
+    """launch-table entries (bfloat16 storage) that put every eligible layer on conv_wx (algorithm 6)"""
+    t = {}
+    for layer, T, shape in [
+        ("down.2.c2_d2", 8 * F, (6, 2, 4)), ("down.2.c3_d4", 8 * F, (6, 2, 4)),
+        ("film.2.conv", 8 * F, (6, 2, 4)), ("film.2.heads", 8 * F, (8, 4, 2)),
+        ("down.3.c2_d2", 2 * F, (8, 4, 2)), ("down.3.c3_d4", 2 * F, (4, 4, 2)),
+        ("film.3.conv", 2 * F, (8, 4, 2)), ("film.3.heads", 2 * F, (8, 4, 2)),
+        ("up.0.conv_first", F, (4, 4, 2)), ("up.0.d9", 2 * F, (8, 4, 2)), ("up.0.d27", 2 * F, (8, 4, 2)),
+        ("up.1.conv_first", 2 * F, (6, 2, 4)), ("up.1.d9", 8 * F, (6, 2, 4)), ("up.1.d27", 8 * F, (6, 2, 4)),
+    ]:
+        t[f"{layer}|{B}|{T}|b"] = [shape[0], shape[1], shape[2], tpw, 6]
+    for k in (2, 3):
+        t[f"down.{k}.c23|{B}|{(8 if k == 2 else 2) * F}|b"] = [1, 1, 4, 1, 0]      # c2 / c3 as separate launches
+    return t
+
+
+WIDE_LAYERS = {"down.2.c2_d2", "down.2.c3_d4", "film.2.conv", "film.2.heads", "down.3.c2_d2", "down.3.c3_d4", "film.3.conv",
+               "film.3.heads", "up.0.conv_first", "up.0.d9", "up.0.d27", "up.1.conv_first", "up.1.d9", "up.1.d27"}
+
+
+@pytest.mark.parametrize("B,F,lens", [(2, 96, None), (3, 140, None), (3, 100, [100, 64, 36])])
+def test_wide_layer_kernel_equals_the_wave_specialised_kernels(dev, B, F, lens):
+    """Same bf16 products in the same order of accumulation, same epilogue arithmetic: the conditioning tensors must
+    be bit-identical; behind an InstanceNorm (float64 atomics, order-dependent last bit) equal to bf16 rounding."""
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 91)
+    b = S.synth_batch(cfg, B, F, 92)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    ref = A.Plan(cfg, storage="bfloat16", load_shipped_table=False)
+    ref.load_tuned({k: v for k, v in _wide_table(B, F).items() if ".c23|" in k})
+    blob = ref.pack(sd).to(dev)
+    ws_r = torch.zeros(ref.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    recs_r = []
+    y_r = ref.forward(blob, *ins, workspace=ws_r, profile=recs_r, lengths=lens)
+    assert not any(r["kernel"].startswith("conv_wx<") for r in recs_r)
+
+    wide = A.Plan(cfg, storage="bfloat16", load_shipped_table=False)
+    wide.load_tuned(_wide_table(B, F))
+    ws_w = torch.empty(wide.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    ws_w.fill_(0xFF)
+    recs_w = []
+    y_w = wide.forward(blob, *ins, workspace=ws_w, profile=recs_w, lengths=lens)
+    on_wx = {r["layer"] for r in recs_w if r["kernel"].startswith("conv_wx<")}
+    # (a ragged batch: rows at the frame rate or twice it may end inside a group of 4 - those launches stay on conv_hx's
+    # row-end instances; the 8F-rate layers are eligible)
+    expect = WIDE_LAYERS if lens is None else {l for l in WIDE_LAYERS if l.startswith(("down.2.", "film.2.", "up.1.d"))}
+    assert on_wx == expect, sorted(expect ^ on_wx)
+
+    def valid(t, tap):
+        if lens is None:
+            return t
+        # a ragged batch: compare each utterance's own columns (what lies behind them is nobody's data)
+        rate = t.shape[-1] // F
+        nb = t.shape[0] // B
+        out = []
+        for j in range(t.shape[0]):
+            out.append(t[j, :, : lens[j % B] * rate].reshape(-1))
+        assert nb in (1, 2)
+        return torch.cat(out)
+
+    for tap in ("down_c2.2", "down_h.2", "film_u.2", "ss.2", "down_c2.3", "down_h.3", "film_u.3", "ss.3"):
+        a, c = valid(ref.tap(tap, B, F, ws_r), tap), valid(wide.tap(tap, B, F, ws_w), tap)
+        assert torch.equal(a, c), (tap, float((a.float() - c.float()).abs().max()))
+    for tap in ("up.0.out", "up.1.out"):
+        a, c = valid(ref.tap(tap, B, F, ws_r), tap).float(), valid(wide.tap(tap, B, F, ws_w), tap).float()
+        # (the InstanceNorm sums come out of other partial sums - other tiles - and differ in their last float32 bits: a
+        # staged value's bfloat16 rounding flips here and there, and with it an output's)
+        assert float((a - c).abs().max()) <= 2.0 ** -6 * float(a.abs().max()), tap
+        assert float((a - c).abs().mean()) <= 1e-3 * float(a.abs().mean()), tap
+    for i in (0, 1):
+        a, c = ref.tap(f"up.{i}.stats", B, F, ws_r), wide.tap(f"up.{i}.stats", B, F, ws_w)      # (3B, C, 2): sum, sum of squares
+        n = (2 if i == 0 else 8) * F
+        scale = (a[..., 1] * n).sqrt() + 1.0                                                      # >= sum |u|
+        assert float(((a[..., 0] - c[..., 0]).abs() / scale).max()) <= 2e-4, i     # (block 1 sits behind block 0's flipped roundings)
+        assert float(((a[..., 1] - c[..., 1]).abs() / (a[..., 1] + 1.0)).max()) <= 2e-4, i
+    ya, yc = (y_r, y_w) if lens is None else (torch.cat([y_r[j, :, : lens[j] * cfg.hop].reshape(-1) for j in range(B)]),
+                                              torch.cat([y_w[j, :, : lens[j] * cfg.hop].reshape(-1) for j in range(B)]))
+    assert float((ya - yc).abs().max()) <= 2e-2 * max(1.0, float(ya.abs().max()))
+
+
+def test_wide_layer_kernel_forward_vs_oracle(dev):
+    """bfloat16 forward with the wide layers on conv_wx against the float64-exact oracle, at the tolerance of the
+    bfloat16 storage mode (tests/test_parity_gpu.py::test_bfloat16_activation_storage_mode)."""
+    from oracle import fastsvc_oracle as O
+    cfg = S.FULL_CONFIG
+    sd = S.synth_state_dict(cfg, 93)
+    B, F = 2, 200
+    b = S.synth_batch(cfg, B, F, 94)
+    ins = _to(dev, b.ppg, b.sine, b.lft, b.spk_emb)
+    wide = A.Plan(cfg, storage="bfloat16", load_shipped_table=False)
+    wide.load_tuned(_wide_table(B, F, tpw=3))
+    blob = wide.pack(sd).to(dev)
+    recs = []
+    y = wide.forward(blob, *ins, profile=recs).cpu().double().numpy()
+    assert {r["layer"] for r in recs if r["kernel"].startswith("conv_wx<")} == WIDE_LAYERS
+    wf = S.fold_weight_norm(sd)
+    ref = O.forward_dedup(wf, cfg.upsampling_scales, b.ppg, b.sine, b.lft, b.spk_emb).double().numpy()
+    err = np.abs(y - ref)
+    assert err.mean() <= 2e-2 and err.max() <= 0.25, (err.mean(), err.max())

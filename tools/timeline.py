@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("FASTSVC_HIP_LIB", os.path.join(ROOT, "svcc23_fastsvc_amd", "libfastsvc_hip_timeline.so"))
 
+PER_WAVE = os.environ.get("TL_PER_WAVE") == "1"      # conv_wx: every wave multiplies - roles by wave, not consumer / producer
 TAGS = {1: "entry", 2: "issued", 3: "commit0", 4: "bar0", 5: "staged", 6: "bar", 7: "mfma", 8: "epi", 9: "loaded",
         10: "operands", 11: "tile_out"}
 
@@ -73,7 +74,7 @@ def analyse(path, layer):
         for wave in range(8):
             tg, cy = tag[w, wave, :62], cyc[w, wave, :62]
             n = int((tg > 0).sum())
-            role = "cons" if wave < 4 else "prod"
+            role = f"wave{wave}" if PER_WAVE else ("cons" if wave < 4 else "prod")
             for i in range(1, n):
                 seg[(role, TAGS.get(int(tg[i - 1]), "?"), TAGS.get(int(tg[i]), "?"))].append(int(cy[i] - cy[i - 1]))
     tot = defaultdict(int)
@@ -87,7 +88,7 @@ def analyse(path, layer):
     # one example workgroup, relative cycles
     w = int(np.flatnonzero(ok)[len(np.flatnonzero(ok)) // 2])
     print(f"example workgroup {w} (cycles since its entry):")
-    for wave in (0, 4):
+    for wave in ((0, 4, 5, 7) if PER_WAVE else (0, 4)):
         tg, cy = tag[w, wave, :62], cyc[w, wave, :62]
         n = int((tg > 0).sum())
         print(f"  wave {wave}: " + " ".join(f"{TAGS.get(int(tg[i]), '?')}@{int(cy[i] - t_in[w])}" for i in range(min(n, 40))))
@@ -102,7 +103,7 @@ def main():
     cfg = S.FULL_CONFIG
     dev = torch.device("cuda:0")
     storage = os.environ.get("FASTSVC_TIMELINE_STORAGE", "float32")
-    plan = A.Plan(cfg, storage=storage)
+    plan = A.Plan(cfg, storage=storage, compact_workspace=True)
     blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
     if wl["B"] * wl["F"] > 20000:
         ins = list(S.device_batch(cfg, wl["B"], wl["F"], wl["seed"], dev))
