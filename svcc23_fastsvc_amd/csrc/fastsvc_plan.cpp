@@ -2157,7 +2157,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                            !p.r1x && !p.x2 && !p.xsplit && (epi_kind == 1 || epi_kind == 2 || epi_kind == 4);
         bool wx_have = false;                            // ... and the layer has a shape of it
         if (wx_ok) {
-            static const int wshapes[][3] = {{8, 4, 2}, {4, 4, 2}, {6, 2, 4}};
+            static const int wshapes[][3] = {{6, 4, 2}};
             for (const auto& sh : wshapes)
                 if (conv_wx_shape(p.mode, c.MW, sh[0], sh[1], sh[2]) && c.ngroups % sh[1] == 0) {
                     cands.push_back(Cand{sh[0], sh[1], sh[2], 6});

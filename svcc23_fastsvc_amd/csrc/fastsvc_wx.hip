@@ -1,27 +1,31 @@
-// fastsvc_wx.hip - the WIDE-layer (C >= 96) implicit-GEMM convolution kernel of the FastSVC generator forward for gfx950
-// (CDNA4 / MI355X): the same k=3 dilated "same" convolutions, prologues and epilogues as fastsvc_hx.hip (reference:
+// fastsvc_wx.hip - the WIDE-layer (C_out = 192 / 384) implicit-GEMM convolution kernel of the FastSVC generator forward for
+// gfx950 (CDNA4 / MI355X): the same k=3 dilated "same" convolutions, prologues and epilogues as fastsvc_hx.hip (reference:
 // Conv1d1x3 / Conv2d1x3, harana/layers/upsample.py:76-83,99-106, used by harana/models/fastsvc.py:94-112,164-178,209-232),
-// laid out for the layers whose roofline is the MATRIX pipe rather than HBM.
+// laid out for the layers whose roofline is the MATRIX pipe as much as HBM.
 //
 // What differs from conv_hx_kernel (4 consumer + 4 staging waves, weights in a per-wave register ring):
-//   * EVERY wave multiplies.  A workgroup is 8 waves = WM channel groups (of 16 MW = 48 output channels) x WN time slices
-//     (of 16 NW columns); two waves share each SIMD's matrix pipe, so one wave's LDS round trips, staging work and
-//     epilogue sit under the other's products.  conv_hx's consumer wave is alone on its SIMD's pipe: its serial
+//   * EVERY wave multiplies.  A workgroup is 8 waves = 4 channel groups (of 48 output channels) x 2 time slices (of 96
+//     columns): 192 channels x 192 columns per tile; two waves share each SIMD's matrix pipe, so one wave's LDS round trips,
+//     staging work and epilogue sit under the other's products.  conv_hx's consumer wave is alone on its SIMD's pipe: its serial
 //     fragment-read -> product chain kept the pipe 21-32 % busy on these layers (profiles/r5c_cfg3_bfloat16_sq_counters.csv).
-//   * Weights go through LDS ONCE per workgroup: a unit's fragments of all WM groups ([group][tap][tile][piece] KB-sized,
-//     already in MFMA operand order in the blob) arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`, no registers, no VALU)
-//     one unit ahead, double-buffered; every wave reads its group's with conflict-free lane-linear ds_read_b128.
-//     conv_hx streams them from L2 into registers per wave: WN times the L2 traffic, and the ring's depth ties the
-//     products to the L2 latency.
-//   * The workgroup tile is 256-384 columns (conv_hx: 128), so a staged window and a unit's weights serve 2-3 x the
-//     products.
-//   * Activation windows are staged by the first waves of the workgroup - as many as the window has (octet of 8 channels,
-//     quad of 4 rows) items - with the SAME item code as conv_hx's staging waves (prologue FMA = InstanceNorm + speaker bias,
-//     LeakyReLU, convert, 4 x 8 transpose in registers, ds_write_b128 into the swizzled time-major tile).  A unit's window
-//     is requested at the end of the previous unit and committed at the end of its own: one register set, a whole unit
-//     (>= 2k cycles of products) of lead.
-//   * Epilogue of tile t runs AFTER the barrier that ends its last unit and after the next unit's weight DMA is issued.
-// bfloat16 storage only for now (float32 storage: hi + lo planes and fragments need twice the LDS).
+//   * Roles by wave, one of each per SIMD: waves 0-3 STAGE the activation window of the next unit (a 192-column tile plus its
+//     halo is at most 248 rows: one (octet of 8 channels, quad of 4 rows) item per lane), waves 4-7 bring the next unit's
+//     WEIGHTS - wave 4 + g the nine KB-sized fragments of channel group g: global -> registers a unit ahead, registers -> LDS
+//     (lane-linear ds_write_b128) at the top of the unit.  Every wave reads its group's fragments back with conflict-free
+//     ds_read_b128: the weights cross L2 -> CU ONCE per workgroup (conv_hx: once per consumer wave and tile).
+//     (First version: LDS-DMA pieces - `buffer_load_dwordx4 ... lds` - measured ~195 cycles of issue PER PIECE inside this loop,
+//     2.3k cycles per unit for the three waves that issued them, profiles/r6a_timeline_conv_wx_v1.txt.)
+//   * Window requests run TWO units ahead through two register sets (one unit of products is shorter than a memory round trip
+//     under load), each role's loop is straight-line in what concerns its memory requests (a branch between a request and
+//     its use makes hipcc wait for the younger set as well: fastsvc_hx.hip's lesson).
+//   * The staging commit is specialised by prologue (PRO): 0 = none (the tensor is already what the conv reads: film.conv,
+//     the FiLM heads, conv_first) - a 4 x 8 bfloat16 transpose by 16 byte-permutes per item; 1 = LeakyReLU only (c2 / c3 of a
+//     conditioning stage); 2 = InstanceNorm + speaker bias + LeakyReLU as one FMA per value (the up blocks' d = 9 / 27 convs).
+//   * Epilogue of tile t runs AFTER the barrier that ends its last unit and behind the next unit's requests: bias / LeakyReLU /
+//     residual / FiLM affine in the MFMA layout with ALL of the tile's operands requested up front, bfloat16 pairs through a
+//     wave-private LDS patch of 16 channel rows, out in 16-byte pieces of 192-byte row runs (one LDS hand-over per channel
+//     tile instead of two round trips per 16 x 32 item).
+// bfloat16 storage only (float32 storage: hi + lo planes and fragments need twice the LDS).
 #include "fastsvc_kernels.h"
 
 namespace fastsvc {
@@ -34,21 +38,21 @@ namespace bf16 {
 
 constexpr int WX_NWAVES = 8;
 constexpr int WX_NT = WX_NWAVES * 64;
+constexpr int WX_MW = 3, WX_NW = 6, WX_WM = 4, WX_WN = 2;          // the one shape: 48 channels x 96 columns per wave
+constexpr int WX_TILE = 16 * WX_NW * WX_WN;                        // 192 columns per workgroup tile
+constexpr int WX_PATCH_PITCH = 208;                                // bytes of a patch row: 96 bfloat16 + 16 (16-byte aligned pieces; the 8-byte writes of a 16-lane group are 2-way: 8 cycles for a 6-cycle issue)
+constexpr int WX_PATCH = 16 * WX_PATCH_PITCH;                      // one wave's epilogue patch
 
 // One unit = (32-channel K chunk) x 3 taps on this wave's NW time tiles and MW channel tiles.
 //   tile: the staged window (time-major rows of 32 channels), aoff[tap]: this lane's fragment offset of time tile 0
 //   wl:   this wave's group's fragments of the unit in LDS, [tap][m][piece] x 1 KB, lane-linear
 // A fragments are read PF steps ahead, a tap's weight fragments while the previous tap's last steps run.
-// on_step(s): called in front of step s's products (the waves that request the next unit's weights issue one LDS-DMA piece
-// per step there: issued in one burst at the top of the unit, twelve pieces cost the wave ~1.8k cycles before its first product)
+// on_step(s): the wave's memory work of this unit, a slice per step in front of the step's products (see conv_wx_kernel).
 template <int MW, int NW, class F>
 __device__ __forceinline__ void wx_unit(f32x4 (&acc)[NW][MW], const unsigned char* tile, const int (&aoff)[3], int lo_off,
                                         const unsigned char* wl, int lane, F&& on_step) {
     constexpr int NSTEP = 3 * NW;
-#ifndef WX_PF
-#define WX_PF 2
-#endif
-    constexpr int PF = HX_NP == 1 ? WX_PF : 1;
+    constexpr int PF = HX_NP == 1 ? 2 : 1;
     constexpr int NF = MW * HX_NP;
     HxFrag a[PF + 1];
     u32x4 w[2][NF];
@@ -72,26 +76,123 @@ __device__ __forceinline__ void wx_unit(f32x4 (&acc)[NW][MW], const unsigned cha
     }
 }
 
-template <int V> struct WxSet { static constexpr int value = V; };      // a compile-time register-set index
+template <int V> struct WxC { static constexpr int value = V; };        // a compile-time index (register set, role)
 
-// MW x NW: 16-channel x 16-column result tiles per wave; WM x WN = 8 waves; EPI: epilogue kind (fastsvc_device.inc)
-template <int MW, int NW, int WM, int WN, int EPI>
+#ifdef FASTSVC_ACT_BF16
+// Plain / residual epilogue of a wave's 48-channel x 96-column tile (see the file header).  acc: [n][m] result tiles in the
+// MFMA layout (lane (co = lane & 15, q = lane >> 4): channel co, columns 16 n + 4 q ..+3).
+//   v = lrelu?(acc + bias) [+ residual]  ->  bfloat16, 8 bytes per tile into the patch row of the channel;
+//   per channel tile: 16 rows x 192 bytes = 192 16-byte pieces = 3 per lane, stored as row runs.
+// The residual is fetched in the MFMA layout (8 bytes per lane: 16 rows x 32-byte segments per request - a poor shape for
+// HBM, but it keeps the float32 sum in the order conv_hx computes it: bit-identical results).
+// EPI_AFF (the middle convs of an up block, fastsvc.py:98-104 + 115-140): v = lrelu?(acc + bias) -> y (when the block needs the
+// pre-affine tensor), u = scale * v + shift -> y2, InstanceNorm partial sums of u into s1 / s2 (per lane; the caller joins them).
+// The operands - residual, or scale and shift, 8 bytes per lane and result tile - are requested a channel tile (6 - 12 requests)
+// ahead of their use: one exposed memory round trip per tile (fetched item by item, as conv_hx's pair epilogue does with
+// its smaller tiles, each of the 9-12 items waited out its own: 23-37k cycles per tile, profiles/r6a_timeline_conv_wx_v1.txt).
+template <int EPI>
+__device__ __forceinline__ void wx_epilogue_rows(const ConvParams& p, const EpiRsrc& R, f32x4 (&acc)[WX_NW][WX_MW], const float (&k_bias)[WX_MW],
+                                                 float (&s1)[WX_MW], float (&s2)[WX_MW], int mg, int tcol0, int lane, unsigned char* patch) {
+    const float slope = (p.flags & F_POST_LRELU) ? LRELU_SLOPE : 1.0f;     // max(v, slope * v): identity for 1
+    const int co = lane & 15, q = lane >> 4;
+    unsigned char* wrow = patch + co * WX_PATCH_PITCH + q * 8;
+    // this lane's three pieces of a channel tile: piece id = 64 k + lane -> (row, 16-byte piece of the row's 12)
+    int prow[3], pcol[3];
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) { const int pid = 64 * k + lane; prow[k] = pid / 12; pcol[k] = pid - prow[k] * 12; }
+    const int shift_soff = p.COUT * p.ldy * 4;                 // ("float bytes": the helpers halve them)
+    constexpr int NOP = EPI == EPI_AFF ? 2 : EPI == EPI_RES ? 1 : 0;
+    // (a channel tile's operands are requested while the tile before it is finished: two sets; all three tiles' at once -
+    // 72 registers for the FiLM kind - spilled)
+    constexpr int NSET = EPI == EPI_AFF ? 1 : 2;               // (FiLM kind: 24 registers per set - two sets spill; its tiles wait out a round trip each)
+    act4_t ops[NSET][NOP > 0 ? NOP : 1][WX_NW];
+    auto request = [&](int m, act4_t (&o)[NOP > 0 ? NOP : 1][WX_NW]) __attribute__((always_inline)) {
+        if constexpr (NOP > 0) {
+            const int cot = (mg * WX_MW + m) * 16 + co;
+            #pragma unroll
+            for (int n = 0; n < WX_NW; ++n) {
+                const int t = tcol0 + n * 16 + q * 4;
+                const int off = (cot < p.COUT && t < p.T) ? (cot * p.ldy + t) * 4 : OOB_OFF;
+                if constexpr (EPI == EPI_RES) o[0][n] = act_load4_raw(R.res, off, 0);
+                if constexpr (EPI == EPI_AFF) { o[0][n] = act_load4_raw(R.ss, off, 0); o[1][n] = act_load4_raw(R.ss, off, shift_soff); }
+            }
+        }
+    };
+    request(0, ops[0]);
+    auto rows_out = [&](__amdgpu_buffer_rsrc_t dst, int m) __attribute__((always_inline)) {
+        // lanes read what OTHER lanes of the wave wrote (a wave's LDS operations execute in order: no barrier, but hipcc
+        // must not move the reads above the writes - per thread the addresses never overlap)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        #pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(patch + prow[k] * WX_PATCH_PITCH + pcol[k] * 16);
+            const int cr = (mg * WX_MW + m) * 16 + prow[k];
+            const int t = tcol0 + pcol[k] * 8;
+            // (rows are a multiple of 4 long: a piece is whole, half, or outside)
+            const int nv = (cr < p.COUT && t < p.T) ? min(8, p.T - t) : 0;
+            act_store8_raw(dst, (cr * p.ldy + t) * 2, w, nv);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    #pragma unroll
+    for (int m = 0; m < WX_MW; ++m) {
+        const bool cok = (mg * WX_MW + m) * 16 + co < p.COUT;
+        if (NSET == 2 && m + 1 < WX_MW) request(m + 1, ops[(m + 1) % NSET]);
+        if (NSET == 1 && m > 0) request(m, ops[0]);
+        #pragma unroll
+        for (int n = 0; n < WX_NW; ++n) {
+            f32x4 v = acc[n][m] + k_bias[m];
+            v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+            v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+            if constexpr (EPI == EPI_RES) v += act_unpack4(ops[m % NSET][0][n]);
+            acc[n][m] = v;
+            u32x2v w;
+            w.x = bf16_pack2(v.x, v.y);
+            w.y = bf16_pack2(v.z, v.w);
+            *reinterpret_cast<u32x2v*>(wrow + n * 32) = w;
+        }
+        if (EPI != EPI_AFF || p.y) rows_out(R.y, m);            // (wave-uniform)
+        if constexpr (EPI == EPI_AFF) {
+            #pragma unroll
+            for (int n = 0; n < WX_NW; ++n) {
+                const int t = tcol0 + n * 16 + q * 4;
+                f32x4 u = act_unpack4(ops[m % NSET][0][n]) * acc[n][m] + act_unpack4(ops[m % NSET][1][n]);
+                if (!(cok && t < p.T)) u = f32x4{0.f, 0.f, 0.f, 0.f};      // (rows are a multiple of 4 long)
+                s1[m] += (u.x + u.y) + (u.z + u.w);
+                s2[m] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+                u32x2v w;
+                w.x = bf16_pack2(u.x, u.y);
+                w.y = bf16_pack2(u.z, u.w);
+                *reinterpret_cast<u32x2v*>(wrow + n * 32) = w;
+            }
+            rows_out(R.y2, m);
+        }
+    }
+}
+#endif
+
+// PRO: staging prologue (0 none, 1 LeakyReLU, 2 InstanceNorm + speaker bias + LeakyReLU); EPI: epilogue kind (fastsvc_device.inc)
+template <int PRO, int EPI>
 __global__ __launch_bounds__(WX_NT, 2)
 void conv_wx_kernel(const ConvParams p0) {
-    static_assert(WM * WN == WX_NWAVES, "eight waves");
-    constexpr int NT = 16 * NW * WN;                                   // columns per workgroup tile
-    constexpr int MAXW = NT + 56;                                      // window rows: halo <= 28 per side
-    constexpr int ITEMS = (MAXW + WX_NT - 1) / WX_NT;                  // (octet, quad of rows) items per thread
+    constexpr int MW = WX_MW, NW = WX_NW, WM = WX_WM, WN = WX_WN;
+    constexpr int NT = WX_TILE;
     constexpr int NSLOT = 3 * MW * HX_NP;                              // fragments of one (group, chunk)
     constexpr int WUNIT = WM * NSLOT * HX_FRAG;                        // bytes of one unit's weights (all groups)
-    constexpr bool TRACKS = AMAX_TRACK && (EPI == EPI_RES);
+    constexpr bool ROWS_EPI = HX_NP == 1;                              // (bfloat16 storage: the row-run epilogue for every kind)
+    static_assert(WM * WN == WX_NWAVES, "eight waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave / WN;
-    const int wave_n = wave - wave_m * WN;
+    const bool stager = wave < 4;                                      // (wave-uniform) waves 0-3 stage windows, 4-7 bring weights
+    const int wave_m = wave & 3;                                       // waves w and w + 4 share a SIMD: one of each role per SIMD,
+    const int wave_n = wave >> 2;                                      //   channel group w & 3, time slice w >> 2
     const int z = blockIdx.z;
     const int sig = z / p0.B;
     const int b = z - sig * p0.B;
@@ -104,7 +205,7 @@ void conv_wx_kernel(const ConvParams p0) {
     const int mg = blockIdx.y * WM + wave_m;                           // (ngroups is a multiple of WM: every wave is active)
     const int halo = p.dil;
     const int halo_al = (halo + 3) & ~3;
-    const int W = NT + 2 * halo_al;                                    // window rows
+    const int W = NT + 2 * halo_al;                                    // window rows (<= 248)
     const int nch = p.nch32;
     const int CINp = nch * HX_KC;
     const int flags = p.flags;
@@ -116,14 +217,14 @@ void conv_wx_kernel(const ConvParams p0) {
 
     double* sstat = reinterpret_cast<double*>(smem_raw);                               // [WM*MW*16][2]
     float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);   // [CINp + 8]: the last 8 are (0, 0)
-    unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp + 8);         // [2][HX_NP][W + 4 rows][64 B]
+    unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp + 8);         // [2][W + 4 rows][64 B]
     const int lo_off = (W + 4) * HX_ROW;
     const int bufsz = HX_NP * (W + 4) * HX_ROW;
-    unsigned char* wbuf = tiles + 2 * bufsz;                                           // [2][WM][tap][m][piece] fragments
-    float* Xw = reinterpret_cast<float*>(wbuf + 2 * WUNIT) + wave * (16 * 36);         // bfloat16 pair epilogue: this wave's patch
+    unsigned char* wbuf = tiles + 2 * bufsz;                                           // [2][WM][tap][m] fragments
+    unsigned char* patch = wbuf + 2 * WUNIT + wave * WX_PATCH;                         // this wave's epilogue patch (>= hx_pair's 16 x 36 floats)
+    float* Xw = reinterpret_cast<float*>(patch);
     (void)Xw;
-    __shared__ unsigned s_amax, s_cnt;
-    __shared__ float s_inv[HX_NP == 2 ? 16 * MW * WM : 4];
+    __shared__ float s_inv[4];
 
 #ifdef FASTSVC_TIMELINE
     // diagnostic build (tools/timeline.py): lane 0 of every wave stamps s_memtime at its phase boundaries
@@ -141,96 +242,115 @@ void conv_wx_kernel(const ConvParams p0) {
 #else
     auto stamp = [](int) {};
 #endif
-    // ---- weight units by LDS-DMA: unit un -> buffer un & 1.  Piece j of the unit = fragment j % NSLOT of group j / NSLOT;
-    // the pieces are dealt to the waves from the LAST wave down (the first waves stage the windows).
+
+    // ---- weights (waves 4-7): group g = wave - 4, unit un -> its nine fragments [tap][m], contiguous in the blob ----
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.whx) + (long)sig * p.whx_sig +
-                                (long)(blockIdx.y * WM) * nch * NSLOT * HX_FRAG;
-    // one descriptor over the WM groups' fragments (group stride nch * NSLOT KB)
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wsrc), 0, WM * nch * NSLOT * HX_FRAG, 0x00020000);
-    const unsigned wbuf_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wbuf;
-    constexpr int NPIECE = WM * NSLOT;
-    // the waves WITHOUT a staging item issue them (a staging wave's window requests must stay in flight across the unit's
-    // end, and a wait for weight pieces would include every older request of the wave)
-    const int nstage = min(WX_NWAVES - 1, (W + 63) >> 6);              // staging waves: 0 .. nstage - 1
-    const bool stager = wave < nstage;                                 // (wave-uniform)
-    auto dma_piece = [&](int un, int ch, int j) __attribute__((always_inline)) {
-        const int g = j / NSLOT, f = j - g * NSLOT;
-        lds_dma16(wr, wbuf_lds + (un & 1) * WUNIT + j * HX_FRAG, lane * 16, ((g * nch + ch) * NSLOT + f) * HX_FRAG);
+                                (long)(blockIdx.y * WM + wave_m) * nch * NSLOT * HX_FRAG;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wsrc), 0, nch * NSLOT * HX_FRAG, 0x00020000);
+    u32x4 wreg[NSLOT];
+    int w_ch = 0;
+    int w_soff = 0;                                                    // scalar offset of the unit being requested
+    auto wload_begin = [&](int un) __attribute__((always_inline)) {    // (called once per unit, in unit order)
+        w_soff = un < nunits ? w_ch * (NSLOT * HX_FRAG) : nch * NSLOT * HX_FRAG;   // past the last unit: out of range, nothing fetched
+        w_ch = w_ch + 1 == nch ? 0 : w_ch + 1;
     };
-    auto dma_unit = [&](int un) __attribute__((always_inline)) {       // (the first unit's: in one go)
-        for (int j = wave - nstage; j < NPIECE; j += WX_NWAVES - nstage) dma_piece(un, un % nch, j);   // (wave-uniform; never entered by a staging wave)
+    auto wload_frag = [&](int f) __attribute__((always_inline)) {
+        wreg[f] = __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16, w_soff + f * HX_FRAG, 0);
+    };
+    auto wcommit_frag = [&](unsigned char* dst, int f) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(dst + f * HX_FRAG + lane * 16) = wreg[f];
+    };
+    auto wload = [&](int un) __attribute__((always_inline)) {
+        wload_begin(un);
+        #pragma unroll
+        for (int f = 0; f < NSLOT; ++f) wload_frag(f);
+    };
+    auto wcommit = [&](unsigned char* dst) __attribute__((always_inline)) {
+        #pragma unroll
+        for (int f = 0; f < NSLOT; ++f) wcommit_frag(dst, f);
     };
 
-    // ---- window staging: item = (octet of 8 channels, quad of 4 rows); waves without an item skip the code ----
+    // ---- window staging (waves 0-3): item = (octet of 8 channels, quad of 4 rows), one per lane ----
     const __amdgpu_buffer_rsrc_t xr = act_rsrc(p.x, (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
-    int it_oct[ITEMS], it_q[ITEMS];
-    bool it_in[ITEMS];
-    #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const int idx = i * WX_NT + tid;
-        it_oct[i] = idx & 3;
-        it_in[i] = (idx >> 2) < (W >> 2);
-        it_q[i] = it_in[i] ? (idx >> 2) : (W >> 2);                    // parked in the 4 spare rows behind the tile
-    }
-    const float slope = (flags & F_PRE_LRELU) ? LRELU_SLOPE : 1.0f;    // max(v, slope * v): identity for 1
+    const int it_oct = tid & 3;
+    const bool it_in = (tid >> 2) < (W >> 2);
+    const int it_q = it_in ? (tid >> 2) : (W >> 2);                    // (lanes without an item: parked in the 4 spare rows behind the tile)
+    const float slope = (PRO >= 1 && (flags & F_PRE_LRELU)) ? LRELU_SLOPE : 1.0f;    // max(v, slope * v): identity for 1
     int l_tl = 0, l_ch = 0, c_ch = 0;
-    // window w is requested into register set w & 1 two units before its commit (one unit of products is shorter than a
-    // memory round trip under load: with one set, requested at the top of the unit before, every unit waited for its window)
-    act4_t pxs[2][ITEMS][8];
-    unsigned tokmasks[2] = {0u, 0u};
-    auto pload = [&](auto SETC, int un) __attribute__((always_inline)) {
+    // window w is requested into register set w & 1 two units before its commit
+    act4_t pxs[2][8];
+    bool toks[2] = {false, false};
+    int p_voff[2] = {0, 0}, p_soff[2] = {0, 0};
+    auto pload_begin = [&](auto SETC, int un) __attribute__((always_inline)) {     // (called once per unit, in unit order)
         constexpr int SET = decltype(SETC)::value;
-        act4_t (&px)[ITEMS][8] = pxs[SET];
-        unsigned& tokmask = tokmasks[SET];
-        const int tl = l_tl, ch = l_ch;
+        const int tl_ = l_tl, ch_ = l_ch;
         { const bool wrap = l_ch + 1 == nch; l_ch = wrap ? 0 : l_ch + 1; l_tl += wrap ? 1 : 0; }
-        const int t_start = (tile0 + tl) * NT - halo_al;
-        const int soff = ch * HX_KC * p.ldx * 4;
-        const int rows_left = p.CIN - ch * HX_KC;
-        tokmask = 0;
+        const int t = (tile0 + tl_) * NT - halo_al + 4 * it_q;
+        const int rows_left = p.CIN - ch_ * HX_KC;
+        // (C_in is a multiple of 8: an octet lies inside the tensor or behind it as a whole)
+        const bool tok = it_in & ((unsigned)t < (unsigned)p.T) & (un < nunits) & (it_oct * 8 < rows_left);
+        toks[SET] = tok;
+        // ONE per-lane offset per item; the channel of the octet rides in the scalar offset
+        p_voff[SET] = tok ? (it_oct * 8 * p.ldx + t) * 4 : OOB_OFF;
+        p_soff[SET] = ch_ * HX_KC * p.ldx * 4;
+    };
+    auto pload_chan = [&](auto SETC, int c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(SETC)::value;
+        pxs[SET][c] = act_load4_raw(xr, p_voff[SET], p_soff[SET] + c * p.ldx * 4);
+    };
+    auto pload = [&](auto SETC, int un) __attribute__((always_inline)) {
+        pload_begin(SETC, un);
         #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int t = t_start + 4 * it_q[i];
-            // (C_in is a multiple of 8: an octet lies inside the tensor or behind it as a whole)
-            const bool tok = it_in[i] & ((unsigned)t < (unsigned)p.T) & (un < nunits) & (it_oct[i] * 8 < rows_left);
-            tokmask |= (tok ? 1u : 0u) << i;
-            // ONE per-lane offset per item; the channel of the octet rides in the scalar offset (eight per-lane offsets,
-            // kept across the loop, were what pushed the 3 x 8 instance past its 256 registers)
-            const int voff = tok ? (it_oct[i] * 8 * p.ldx + t) * 4 : OOB_OFF;
+        for (int c = 0; c < 8; ++c) pload_chan(SETC, c);
+    };
+    // commit of one row (time step j of the item's quad) of the window in set SET
+    float cA[8], cB[8];                                                // (PRO 2: the item's (A, Bc) coefficients, read once per commit)
+    auto pcommit_begin = [&](auto SETC) __attribute__((always_inline)) {
+        constexpr int SET = decltype(SETC)::value;
+        const int ch_ = c_ch;
+        c_ch = c_ch + 1 == nch ? 0 : c_ch + 1;
+        if constexpr (PRO == 2) {
+            // (A, Bc) of the item's 8 channels: InstanceNorm + speaker bias as ONE FMA u * A + Bc; rows outside the utterance
+            // are the conv's zero padding AFTER the prologue: their loads returned 0, so only the additive term has to go - such
+            // an item reads the (0, 0) coefficients behind the table
+            const f32x4* cf = reinterpret_cast<const f32x4*>(ncoef + (toks[SET] ? ch_ * HX_KC + it_oct * 8 : CINp));
+            const f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+            cA[0] = c0.x; cA[1] = c0.z; cA[2] = c1.x; cA[3] = c1.z; cA[4] = c2.x; cA[5] = c2.z; cA[6] = c3.x; cA[7] = c3.z;
+            cB[0] = c0.y; cB[1] = c0.w; cB[2] = c1.y; cB[3] = c1.w; cB[4] = c2.y; cB[5] = c2.w; cB[6] = c3.y; cB[7] = c3.w;
+        }
+    };
+    auto pcommit_row = [&](auto SETC, unsigned char* tile, int j) __attribute__((always_inline)) {
+        constexpr int SET = decltype(SETC)::value;
+        const act4_t (&px)[8] = pxs[SET];
+        // rows r, r + 1 of the quad swap places in every second quad (hx_lds_off): two addresses, rows 2 / 3 at +128 bytes
+        unsigned char* d = tile + hx_lds_off(4 * it_q + (j & 1), it_oct) + (j >> 1) * 2 * HX_ROW;
+        if constexpr (PRO == 0) {
+#ifdef FASTSVC_ACT_BF16
+            // the tensor is what the conv reads: rows outside the utterance and channel padding were fetched as zeros.
+            // 4 x 8 transpose of 16-bit values: dword k of row j = (channel 2k | channel 2k + 1 << 16) at time step j
+            u32x4 o;
             #pragma unroll
-            for (int c = 0; c < 8; ++c) px[i][c] = act_load4_raw(xr, voff, soff + c * p.ldx * 4);
+            for (int k = 0; k < 4; ++k) {
+                const unsigned a = j < 2 ? px[2 * k].x : px[2 * k].y, bb = j < 2 ? px[2 * k + 1].x : px[2 * k + 1].y;
+                o[k] = __builtin_amdgcn_perm(bb, a, (j & 1) ? 0x07060302u : 0x05040100u);
+            }
+            *reinterpret_cast<u32x4*>(d) = o;
+#endif
+        } else {
+            float e[8];
+            #pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float v = act_unpack4(px[c])[j];
+                if constexpr (PRO == 2) v = v * cA[c] + cB[c];
+                e[c] = fmaxf(v, v * slope);
+            }
+            hx_commit_slot(d, 0, lo_off, e);
         }
     };
     auto pcommit = [&](auto SETC, unsigned char* tile) __attribute__((always_inline)) {
-        constexpr int SET = decltype(SETC)::value;
-        const act4_t (&px)[ITEMS][8] = pxs[SET];
-        const unsigned tokmask = tokmasks[SET];
-        const int ch = c_ch;
-        c_ch = c_ch + 1 == nch ? 0 : c_ch + 1;
+        pcommit_begin(SETC);
         #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            // rows outside the utterance are the conv's zero padding AFTER the prologue: their loads returned 0, so only the
-            // additive term has to go - such an item reads the (0, 0) coefficients behind the table
-            const bool tok = ((tokmask >> i) & 1u) != 0;
-            const f32x4* cf = reinterpret_cast<const f32x4*>(ncoef + (tok ? ch * HX_KC + it_oct[i] * 8 : CINp));
-            const f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
-            const float A[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
-            const float Bc[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
-            // one time step at a time, unpacked where it is used: the 32 converted values never exist together (the unit's
-            // 96 accumulators and both register sets are live here)
-            #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float e[8];
-                #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    act4_t w = px[i][c];
-                    asm volatile("" : "+v"(w));                // (keeps hipcc from unpacking all four steps up front)
-                    e[c] = act_unpack4(w)[j] * A[c] + Bc[c];
-                    e[c] = fmaxf(e[c], e[c] * slope);
-                }
-                hx_commit_slot(tile, hx_lds_off(4 * it_q[i] + j, it_oct[i]), lo_off, e);
-            }
-        }
+        for (int j = 0; j < 4; ++j) pcommit_row(SETC, tile, j);
     };
 
     // ---- epilogue descriptors and per-lane constants ----
@@ -253,60 +373,52 @@ void conv_wx_kernel(const ConvParams p0) {
         k_bias[m] = cot < p.COUT ? p.bias[(long)sig * p.bias_sig + cot] : 0.f;
     }
     // (second bias / rank-1 constants: kinds this kernel does not have)
-    const EpiConst<MW, true, HX_NP == 2> K{k_bias, k_bias, k_bias, k_bias, s_inv + wave_m * (MW * 16) + (lane & 15), 16 * MW * WM};
+    const EpiConst<MW, true, false> K{k_bias, k_bias, k_bias, k_bias, s_inv, 0};
 
-    // ---- set-up: first window and first weights in flight, then the tables ----
-    typedef WxSet<0> Set0;
-    typedef WxSet<1> Set1;
-    // Workgroups dispatched together would run their tiles in lockstep: every CU multiplies at the same time (HBM idle) and
-    // every CU stores its tile at the same time (the epilogues of film.2.heads at 64 x 12000: 25 MB per tile period, 5.8 us of
-    // HBM time during which no CU multiplied - 30 % of the launch).  Workgroup i of an XCD (dispatch order: i / 8) starts
-    // (i % 8) / 8 of a tile late, so that at any time an eighth of the chip stores.
-    {
-        const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int late = ((wg >> 3) & 7) * nch * p.stagger;    // (p.stagger: an eighth of a unit's time in 64-cycle steps)
-        for (int k = 0; k < late; ++k) __builtin_amdgcn_s_sleep(1);
-    }
+    // ---- set-up: the first requests in flight, then the tables ----
+    typedef WxC<0> Set0;
+    typedef WxC<1> Set1;
     if (stager) { pload(Set0{}, 0); pload(Set1{}, 1); }
-    dma_unit(0);
+    else wload(0);
     {
-        // prologue coefficients of every input channel, applied by the staging code as ONE FMA u * A + Bc:
-        // InstanceNorm + speaker bias (u - mean) * rstd + p  ->  A = rstd, Bc = p - mean * rstd (fastsvc.py:134-139);
-        // no norm: (1, 0); channel padding: (0, 0)
+        // prologue coefficients of every input channel (PRO 2): InstanceNorm + speaker bias (u - mean) * rstd + p  ->
+        // A = rstd, Bc = p - mean * rstd (fastsvc.py:134-139); channel padding: (0, 0)
         const int c = tid;
-        double q1 = 0.0, q2 = 0.0;
-        float pc = 0.f;
-        if ((flags & F_PRE_NORM) && c < p.CIN) {
-            q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
-            q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
-            pc = p.spk[(long)b * p.CIN + c];
+        if constexpr (PRO == 2) {
+            double q1 = 0.0, q2 = 0.0;
+            float pc = 0.f;
+            if ((flags & F_PRE_NORM) && c < p.CIN) {
+                q1 = p.st_in[((long)b * p.CIN + c) * 2 + 0];
+                q2 = p.st_in[((long)b * p.CIN + c) * 2 + 1];
+                pc = p.spk[(long)b * p.CIN + c];
+            }
+            if (c < CINp) {
+                float2 ab = make_float2(0.f, 0.f);
+                if (c < p.CIN) {
+                    ab = make_float2(1.f, 0.f);
+                    if (flags & F_PRE_NORM) {
+                        const double inv_len = 1.0 / (double)p.x_T;
+                        const double mean = q1 * inv_len;
+                        double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
+                        var = var > 0.0 ? var : 0.0;
+                        const double rstd = 1.0 / sqrt(var + IN_EPS);
+                        ab.x = (float)rstd;
+                        ab.y = (float)((double)pc - mean * rstd);
+                    }
+                }
+                ncoef[c] = ab;
+            }
+            if (c < 8) ncoef[CINp + c] = make_float2(0.f, 0.f);       // what an item outside the utterance is staged with
         }
-        if constexpr (TRACKS) { if (tid == 0) { s_amax = 0u; s_cnt = 0u; } }
         if (flags & F_STATS) {
             for (int i = tid; i < 2 * 16 * MW * WM; i += WX_NT) sstat[i] = 0.0;
         }
-        if (c < CINp) {
-            float2 ab = make_float2(0.f, 0.f);
-            if (c < p.CIN) {
-                ab = make_float2(1.f, 0.f);
-                if (flags & F_PRE_NORM) {
-                    const double inv_len = 1.0 / (double)p.x_T;
-                    const double mean = q1 * inv_len;
-                    double var = q2 * inv_len - mean * mean;      // biased variance (InstanceNorm2d)
-                    var = var > 0.0 ? var : 0.0;
-                    const double rstd = 1.0 / sqrt(var + IN_EPS);
-                    ab.x = (float)rstd;
-                    ab.y = (float)((double)pc - mean * rstd);
-                }
-            }
-            ncoef[c] = ab;
-        }
-        if (c < 8) ncoef[CINp + c] = make_float2(0.f, 0.f);       // what an item outside the utterance is staged with
         __syncthreads();
     }
     if (stager) { pcommit(Set0{}, tiles); pload(Set0{}, 2); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // unit 0's weights have landed
+    else { wcommit(wbuf + wave_m * (NSLOT * HX_FRAG)); wload(1); }
     __syncthreads();
+    stamp(4);
 
     int aoff[3];
     #pragma unroll
@@ -321,12 +433,11 @@ void conv_wx_kernel(const ConvParams p0) {
         #pragma unroll
         for (int m = 0; m < MW; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
 #ifdef FASTSVC_ACT_BF16
-        if constexpr (NW % 2 == 0) hx_epilogue8<MW, NW / 2, EPI, false>(p, R, acc, s1, s2, sig, mg, tcolw, true, lane, K, nullptr, Xw);
-        else
-#endif
+        wx_epilogue_rows<EPI>(p, R, acc, k_bias, s1, s2, mg, tcolw, lane, patch);
+#else
         ws_epilogue_kind<MW, NW, EPI, false, 0, -1>(p, R, acc, s1, s2, sig, mg, tcolw, true, lane, K, nullptr);
-        if constexpr (TRACKS) { if (p.amax_out) amax_tile_flush(R); }
-        if (flags & F_STATS) {
+#endif
+        if (EPI == EPI_AFF && (flags & F_STATS)) {
             #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 float a1 = row_xsum(s1[m]), a2 = row_xsum(s2[m]);
@@ -339,27 +450,12 @@ void conv_wx_kernel(const ConvParams p0) {
         }
     };
     // One unit.  ROLE (compile time: each role runs its own copy of the loop, straight-line in what concerns its memory
-    // requests - a branch between a window request and its commit makes hipcc count the requests of the path WITHOUT the
-    // younger set and wait for both sets: the two-deep prefetch then runs one deep, see fastsvc_hx.hip):
-    //   0  no staging item: requests the next unit's weights (LDS-DMA, in one go: a piece per product step was measured slower)
-    //   1  stages EARLY (waves 0-3, one per SIMD): first commits the NEXT unit's window and requests the one two units on - the
-    //      partner on the SIMD multiplies meanwhile, and this wave multiplies while the partner commits or waits at the barrier
-    //      (committing after the products in every wave left the matrix pipe idle for the length of the commit, every unit)
-    //   2  stages LATE (waves 4..: windows of more than 256 rows): products first - both waves of a SIMD committing first was
-    //      what paced the 264-row windows (3.9k cycles per unit on SIMD 0 against 2.4k of products)
-    // Past the last unit the requests fetch nothing (offsets out of range) and the commit stages zeros into the buffer nobody
-    // reads.  SETC: the register set that holds window u + 1.
+    // requests): 1 = stages windows, 0 = brings weights.  At the top of unit u the wave hands over what unit u + 1 needs
+    // (buffers (u + 1) & 1 were last read in unit u - 1: behind a barrier) and requests what comes after; past the last unit
+    // the requests fetch nothing (offsets out of range) and what is handed over lands in the buffers nobody reads.
+    // SETC: the register set that holds window u + 1.
     auto unit = [&](auto ROLE, auto SETC, int u) __attribute__((always_inline)) {
         constexpr int ROLE_ID = decltype(ROLE)::value;
-        if constexpr (ROLE_ID == 1) {
-            if (!(FASTSVC_DBG_ON(p, DBG_NO_COMMIT))) { pcommit(SETC, tiles + ((u + 1) & 1) * bufsz); pload(SETC, u + 3); }
-            asm volatile("" ::: "memory");                     // (the requests go out HERE: hipcc otherwise sinks them below the products)
-            stamp(5);
-        }
-        if constexpr (ROLE_ID == 0) {
-            if (u + 1 < nunits && !(FASTSVC_DBG_ON(p, DBG_NO_WEIGHTS))) dma_unit(u + 1);   // (buffer (u + 1) & 1 was last read in unit u - 1: behind a barrier)
-            stamp(9);
-        }
         if (ch == 0) {
             if (tl > 0) { epilogue(tl - 1); stamp(8); }        // the tile that ended with the last barrier
             #pragma unroll
@@ -367,29 +463,39 @@ void conv_wx_kernel(const ConvParams p0) {
                 #pragma unroll
                 for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // The wave's memory work rides BETWEEN the product steps, a slice per step (18 steps of 3 products): handing over at the
+        // top of the unit - every wave at once, 52 KB of LDS stores per unit at ~79 B/clk - kept the matrix pipe idle for
+        // 1.0k (staging waves) to 2.7k (weight waves) cycles of a 4.6k-cycle unit (profiles/r6b_timeline_conv_wx_v2a.txt).
+        //   weights: step f < 9: fragment f of unit u + 1 -> LDS, then the register takes fragment f of unit u + 2
+        //   windows: steps 0-3: row j of window u + 1 -> LDS; steps 4-11: channel c of window u + 3 requested into the set
+        unsigned char* wdst = wbuf + ((u + 1) & 1) * WUNIT + wave_m * (NSLOT * HX_FRAG);
+        unsigned char* tdst = tiles + ((u + 1) & 1) * bufsz;
+        if constexpr (ROLE_ID == 1) pcommit_begin(SETC); else wload_begin(u + 2);
+        if constexpr (ROLE_ID == 1) pload_begin(SETC, u + 3);
+        auto work = [&](int st) __attribute__((always_inline)) {
+            if constexpr (ROLE_ID == 1) {
+                if (st < 4) { if (!(p.dbg & 128)) pcommit_row(SETC, tdst, st); }
+                else if (st < 12) { if (!(p.dbg & 256)) pload_chan(SETC, st - 4); }
+            } else {
+                if (st < NSLOT) { if (!(p.dbg & 32)) wcommit_frag(wdst, st); if (!(p.dbg & 64)) wload_frag(st); }
+            }
+        };
         if (u < nunits && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA)))
-            wx_unit<MW, NW>(acc, tiles + (u & 1) * bufsz, aoff, lo_off, wbuf + (u & 1) * WUNIT + wave_m * (NSLOT * HX_FRAG), lane, [](int) {});
-        if constexpr (ROLE_ID == 2) {
-            // late: commit the next unit's window and request the one two units on AFTER the products (the early wave of this
-            // SIMD committed while this one multiplied)
-            stamp(7);
-            if (!(FASTSVC_DBG_ON(p, DBG_NO_COMMIT))) { pcommit(SETC, tiles + ((u + 1) & 1) * bufsz); pload(SETC, u + 3); }
-            stamp(5);
-        } else stamp(7);
-        // unit u + 1's weights have landed (the waves that requested them hold no other request but an epilogue's stores)
-        if constexpr (ROLE_ID == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(10); }
+            wx_unit<MW, NW>(acc, tiles + (u & 1) * bufsz, aoff, lo_off, wbuf + (u & 1) * WUNIT + wave_m * (NSLOT * HX_FRAG), lane, work);
+        else {
+            #pragma unroll
+            for (int st = 0; st < 3 * NW; ++st) work(st);      // (the phantom unit of an odd count; keeps the sets' rotation)
+        }
+        stamp(7);
         __syncthreads();
         stamp(6);
         if (++ch == nch) { ch = 0; ++tl; }
     };
     // the loop always runs both halves (an odd count ends with a phantom unit: no products, but the last tile's epilogue)
     const int nun2 = (nunits + 1) & ~1;
-    const int role = !stager ? 0 : wave < 4 ? 1 : 2;
-    if (role == 1) { for (int u = 0; u < nun2; u += 2) { unit(WxSet<1>{}, Set1{}, u); unit(WxSet<1>{}, Set0{}, u + 1); } }
-    else if (role == 2) { for (int u = 0; u < nun2; u += 2) { unit(WxSet<2>{}, Set1{}, u); unit(WxSet<2>{}, Set0{}, u + 1); } }
-    else { for (int u = 0; u < nun2; u += 2) { unit(WxSet<0>{}, Set1{}, u); unit(WxSet<0>{}, Set0{}, u + 1); } }
+    if (stager) { for (int u = 0; u < nun2; u += 2) { unit(WxC<1>{}, Set1{}, u); unit(WxC<1>{}, Set0{}, u + 1); } }
+    else { for (int u = 0; u < nun2; u += 2) { unit(WxC<0>{}, Set1{}, u); unit(WxC<0>{}, Set0{}, u + 1); } }
     if (!(nunits & 1)) epilogue(ntiles - 1);
-    if constexpr (TRACKS) amax_flush(p, R, &s_amax, &s_cnt, WX_NWAVES, sig, b, lane, blockIdx.x);
     if (flags & F_STATS) {                                     // one f64 global atomic per channel per workgroup
         __syncthreads();
         for (int i = tid; i < 2 * 16 * MW * WM; i += WX_NT) {
@@ -399,18 +505,12 @@ void conv_wx_kernel(const ConvParams p0) {
     }
 }
 
-constexpr size_t WX_STATIC_LDS = 1024;
-template <int MW, int NW, int WM, int WN>
+constexpr size_t WX_STATIC_LDS = 256;
 static size_t wx_smem(const ConvParams& p) {
-    constexpr int NT = 16 * NW * WN;
     const int halo_al = (p.dil + 3) & ~3;
-    const int W = NT + 2 * halo_al;
-    size_t s = sizeof(double) * 2 * 16 * MW * WM + sizeof(float) * 2 * ((size_t)p.nch32 * HX_KC + 8) +
-               (size_t)2 * HX_NP * (W + 4) * HX_ROW + (size_t)2 * WM * 3 * MW * HX_NP * HX_FRAG;
-#ifdef FASTSVC_ACT_BF16
-    s += sizeof(float) * WX_NWAVES * 16 * 36;
-#endif
-    return s;
+    const int W = WX_TILE + 2 * halo_al;
+    return sizeof(double) * 2 * 16 * WX_MW * WX_WM + sizeof(float) * 2 * ((size_t)p.nch32 * HX_KC + 8) +
+           (size_t)2 * HX_NP * (W + 4) * HX_ROW + (size_t)2 * WX_WM * 3 * WX_MW * HX_NP * HX_FRAG + (size_t)WX_NWAVES * WX_PATCH;
 }
 
 template <auto KERNEL>
@@ -422,41 +522,34 @@ static hipError_t wx_launch_instance(dim3 grid, size_t smem, hipStream_t stream,
     return hipGetLastError();
 }
 
-template <int MW, int NW, int WM, int WN>
-static hipError_t wx_launch_shape(const ConvParams& p, int nsig, hipStream_t stream) {
-    constexpr int NT = 16 * NW * WN;
-    if (p.ngroups % WM != 0) return hipErrorInvalidValue;
-    const size_t smem = wx_smem<MW, NW, WM, WN>(p);
-    if (smem + WX_STATIC_LDS > 160 * 1024) return hipErrorInvalidValue;
-    const int ntx = (p.T + NT - 1) / NT;
-    const int tpw = p.tpw > 0 ? p.tpw : 1;
-    dim3 grid((ntx + tpw - 1) / tpw, p.ngroups / WM, nsig * p.B);
-    const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
-    const int kind = aff ? EPI_AFF : p.res ? EPI_RES : EPI_PLAIN;
-#define FASTSVC_WX(k) if (kind == k) return wx_launch_instance<&conv_wx_kernel<MW, NW, WM, WN, k>>(grid, smem, stream, p);
-    FASTSVC_WX(EPI_PLAIN) FASTSVC_WX(EPI_RES) FASTSVC_WX(EPI_AFF)
-#undef FASTSVC_WX
-    return hipErrorInvalidValue;
-}
-
 hipError_t launch_conv_wx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream) {
 #ifndef FASTSVC_ACT_BF16
-    return hipErrorInvalidValue;                               // (float32 storage: not built yet)
+    return hipErrorInvalidValue;                               // (float32 storage: not built)
 #else
     if (p.mode != MODE_DIRECT || p.ntaps != 3 || (p.T & 3) || !p.whx || p.nch32 * HX_KC > WX_NT || p.dil < 1 || p.dil > 28 ||
-        p.x2 || p.r1x || p.last_w || p.xsplit || (p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0)) || cfg.MW != 3)
+        p.x2 || p.r1x || p.last_w || p.xsplit || (p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0)) || (p.CIN & 7) ||
+        (p.flags & F_PRE_AFFINE) || cfg.MW != WX_MW || cfg.NW != WX_NW || cfg.WM != WX_WM || cfg.WN != WX_WN || p.ngroups % WX_WM != 0)
         return hipErrorInvalidValue;
-    if (cfg.NW == 8 && cfg.WM == 4 && cfg.WN == 2) return wx_launch_shape<3, 8, 4, 2>(p, cfg.nsig, stream);
-    if (cfg.NW == 6 && cfg.WM == 2 && cfg.WN == 4) return wx_launch_shape<3, 6, 2, 4>(p, cfg.nsig, stream);
-    if (cfg.NW == 4 && cfg.WM == 4 && cfg.WN == 2) return wx_launch_shape<3, 4, 4, 2>(p, cfg.nsig, stream);
+    const size_t smem = wx_smem(p);
+    if (smem + WX_STATIC_LDS > 160 * 1024) return hipErrorInvalidValue;
+    const int ntx = (p.T + WX_TILE - 1) / WX_TILE;
+    const int tpw = p.tpw > 0 ? p.tpw : 1;
+    dim3 grid((ntx + tpw - 1) / tpw, p.ngroups / WX_WM, cfg.nsig * p.B);
+    const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
+    const int kind = aff ? EPI_AFF : p.res ? EPI_RES : EPI_PLAIN;
+    const int pro = (p.flags & F_PRE_NORM) ? 2 : (p.flags & F_PRE_LRELU) ? 1 : 0;
+#define FASTSVC_WX(pr, k) if (pro == pr && kind == k) return wx_launch_instance<&conv_wx_kernel<pr, k>>(grid, smem, stream, p);
+    FASTSVC_WX(0, EPI_PLAIN) FASTSVC_WX(0, EPI_RES)
+    FASTSVC_WX(1, EPI_PLAIN) FASTSVC_WX(1, EPI_RES)
+    FASTSVC_WX(2, EPI_PLAIN) FASTSVC_WX(2, EPI_RES) FASTSVC_WX(2, EPI_AFF)
+#undef FASTSVC_WX
     return hipErrorInvalidValue;
 #endif
 }
 
 #ifndef FASTSVC_ACT_BF16      // storage-independent host query: defined once
 bool conv_wx_shape(int mode, int MW, int NW, int WM, int WN) {
-    if (mode != MODE_DIRECT || MW != 3) return false;
-    return (NW == 8 && WM == 4 && WN == 2) || (NW == 6 && WM == 2 && WN == 4) || (NW == 4 && WM == 4 && WN == 2);
+    return mode == MODE_DIRECT && MW == WX_MW && NW == WX_NW && WM == WX_WM && WN == WX_WN;
 }
 #endif
 
