@@ -301,10 +301,11 @@ bool conv_hx_tail_ok(int mode, int MW, int epi_kind, int S);
 // number of K chunks and stretch factor
 bool conv_hx_x2_ok(int MW, int nch32, int s2);
 
-// the wide-layer kernel in which every wave multiplies (fastsvc_wx.hip): MODE_DIRECT, 48-channel groups (MW = 3), weights
-// through LDS by LDS-DMA; bfloat16 storage.  cfg.pipe is ignored; same ConvParams as launch_conv_hx.
+// the wide-layer kernel in which every wave multiplies (fastsvc_wx.hip): MODE_DIRECT, 48-channel groups (MW = 3), the
+// weights once per workgroup and unit through LDS; bfloat16 storage.  cfg.pipe is ignored; same ConvParams as launch_conv_hx.
 hipError_t launch_conv_wx(const ConvParams& p, const ConvLaunch& cfg, hipStream_t stream);
 bool conv_wx_shape(int mode, int MW, int NW, int WM, int WN);
+bool conv_wx_fits(int nch32, int dil);      // window buffers + two units of weights + patches fit the CU's LDS
 
 // down-sampling stage 0, first conv (C_in = 1, k = 3, d = 1, LeakyReLU on the input):
 //   y[sig][b][co][t] = bias[co] + sum_tap w[co][tap] * lrelu(x[sig][b][t + tap - 1])

@@ -2159,7 +2159,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (wx_ok) {
             static const int wshapes[][3] = {{6, 4, 2}};
             for (const auto& sh : wshapes)
-                if (conv_wx_shape(p.mode, c.MW, sh[0], sh[1], sh[2]) && c.ngroups % sh[1] == 0) {
+                if (conv_wx_shape(p.mode, c.MW, sh[0], sh[1], sh[2]) && c.ngroups % sh[1] == 0 && conv_wx_fits(c.nch32, c.dil)) {
                     cands.push_back(Cand{sh[0], sh[1], sh[2], 6});
                     wx_have = true;
                 }
@@ -2321,7 +2321,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 const long ntx = (p.T + NT - 1) / NT;
                 const long gy = c.ngroups / cd.WM;
                 int tpw = 1;
-                while (tpw < 24 && ((ntx + tpw - 1) / tpw) * gy * zb > 256) ++tpw;
+                while (tpw < 64 && ((ntx + tpw - 1) / tpw) * gy * zb > 256) ++tpw;
                 if (best_t > 0.0) { best_t = 0.0; best = cd; p.tpw = tpw; }
                 continue;
             }

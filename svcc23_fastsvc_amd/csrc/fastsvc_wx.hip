@@ -18,6 +18,13 @@
 //   * Window requests run TWO units ahead through two register sets (one unit of products is shorter than a memory round trip
 //     under load), each role's loop is straight-line in what concerns its memory requests (a branch between a request and
 //     its use makes hipcc wait for the younger set as well: fastsvc_hx.hip's lesson).
+//   * What it is bound by (profiles/r6b_*): the ablations ADD UP - products 110 us + window requests 68 + weight
+//     requests 33 + epilogue 50-60 for film.2.heads at 64 x 12000 - i.e. the waves wait for their requests instead of
+//     multiplying: a window request (4 rows x 128 bytes) costs ~47 cycles, a weight request (1 KB contiguous) ~20, wherever
+//     in the unit it stands (top of the unit or between the product steps), ~11 B/clk per CU of window data.  Tried against
+//     it and dropped: the layer's weights RESIDENT in LDS (96 output channels per workgroup, windows requested four units
+//     ahead: both channel halves of a C = 192 layer then read every window - 240 us), LDS-DMA for the weights (~195 cycles
+//     of issue per 1 KB piece).
 //   * The staging commit is specialised by prologue (PRO): 0 = none (the tensor is already what the conv reads: film.conv,
 //     the FiLM heads, conv_first) - a 4 x 8 bfloat16 transpose by 16 byte-permutes per item; 1 = LeakyReLU only (c2 / c3 of a
 //     conditioning stage); 2 = InstanceNorm + speaker bias + LeakyReLU as one FMA per value (the up blocks' d = 9 / 27 convs).
@@ -456,6 +463,17 @@ void conv_wx_kernel(const ConvParams p0) {
     // SETC: the register set that holds window u + 1.
     auto unit = [&](auto ROLE, auto SETC, int u) __attribute__((always_inline)) {
         constexpr int ROLE_ID = decltype(ROLE)::value;
+        // At the top of unit u the wave hands over what unit u + 1 needs (buffers (u + 1) & 1 were last read in unit u - 1: behind
+        // a barrier) and requests what comes after.  (Riding between the product steps instead, a slice per step, the same work
+        // cost MORE: 245 against 213 us for film.2.heads at 64 x 12000 - what a wave waits for are its requests, wherever they
+        // stand: skipping the window requests alone took 68 us off, the weight requests 33, the LDS stores nothing.)
+        if constexpr (ROLE_ID == 1) {
+            if (!(FASTSVC_DBG_ON(p, DBG_NO_COMMIT))) { pcommit(SETC, tiles + ((u + 1) & 1) * bufsz); pload(SETC, u + 3); }
+        } else {
+            if (!(FASTSVC_DBG_ON(p, DBG_NO_WEIGHTS))) { wcommit(wbuf + ((u + 1) & 1) * WUNIT + wave_m * (NSLOT * HX_FRAG)); wload(u + 2); }
+        }
+        asm volatile("" ::: "memory");                         // (the requests go out HERE: hipcc otherwise sinks them below the products)
+        stamp(5);
         if (ch == 0) {
             if (tl > 0) { epilogue(tl - 1); stamp(8); }        // the tile that ended with the last barrier
             #pragma unroll
@@ -463,29 +481,8 @@ void conv_wx_kernel(const ConvParams p0) {
                 #pragma unroll
                 for (int m = 0; m < MW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // The wave's memory work rides BETWEEN the product steps, a slice per step (18 steps of 3 products): handing over at the
-        // top of the unit - every wave at once, 52 KB of LDS stores per unit at ~79 B/clk - kept the matrix pipe idle for
-        // 1.0k (staging waves) to 2.7k (weight waves) cycles of a 4.6k-cycle unit (profiles/r6b_timeline_conv_wx_v2a.txt).
-        //   weights: step f < 9: fragment f of unit u + 1 -> LDS, then the register takes fragment f of unit u + 2
-        //   windows: steps 0-3: row j of window u + 1 -> LDS; steps 4-11: channel c of window u + 3 requested into the set
-        unsigned char* wdst = wbuf + ((u + 1) & 1) * WUNIT + wave_m * (NSLOT * HX_FRAG);
-        unsigned char* tdst = tiles + ((u + 1) & 1) * bufsz;
-        if constexpr (ROLE_ID == 1) pcommit_begin(SETC); else wload_begin(u + 2);
-        if constexpr (ROLE_ID == 1) pload_begin(SETC, u + 3);
-        auto work = [&](int st) __attribute__((always_inline)) {
-            if constexpr (ROLE_ID == 1) {
-                if (st < 4) { if (!(p.dbg & 128)) pcommit_row(SETC, tdst, st); }
-                else if (st < 12) { if (!(p.dbg & 256)) pload_chan(SETC, st - 4); }
-            } else {
-                if (st < NSLOT) { if (!(p.dbg & 32)) wcommit_frag(wdst, st); if (!(p.dbg & 64)) wload_frag(st); }
-            }
-        };
         if (u < nunits && !(FASTSVC_DBG_ON(p, DBG_NO_MFMA)))
-            wx_unit<MW, NW>(acc, tiles + (u & 1) * bufsz, aoff, lo_off, wbuf + (u & 1) * WUNIT + wave_m * (NSLOT * HX_FRAG), lane, work);
-        else {
-            #pragma unroll
-            for (int st = 0; st < 3 * NW; ++st) work(st);      // (the phantom unit of an odd count; keeps the sets' rotation)
-        }
+            wx_unit<MW, NW>(acc, tiles + (u & 1) * bufsz, aoff, lo_off, wbuf + (u & 1) * WUNIT + wave_m * (NSLOT * HX_FRAG), lane, [](int) {});
         stamp(7);
         __syncthreads();
         stamp(6);
@@ -506,11 +503,11 @@ void conv_wx_kernel(const ConvParams p0) {
 }
 
 constexpr size_t WX_STATIC_LDS = 256;
-static size_t wx_smem(const ConvParams& p) {
+static size_t wx_smem(const ConvParams& p, int np = HX_NP) {     // np: operand pieces (1: bfloat16 storage)
     const int halo_al = (p.dil + 3) & ~3;
     const int W = WX_TILE + 2 * halo_al;
     return sizeof(double) * 2 * 16 * WX_MW * WX_WM + sizeof(float) * 2 * ((size_t)p.nch32 * HX_KC + 8) +
-           (size_t)2 * HX_NP * (W + 4) * HX_ROW + (size_t)2 * WX_WM * 3 * WX_MW * HX_NP * HX_FRAG + (size_t)WX_NWAVES * WX_PATCH;
+           (size_t)2 * np * (W + 4) * HX_ROW + (size_t)2 * WX_WM * 3 * WX_MW * np * HX_FRAG + (size_t)WX_NWAVES * WX_PATCH;
 }
 
 template <auto KERNEL>
@@ -547,9 +544,15 @@ hipError_t launch_conv_wx(const ConvParams& p, const ConvLaunch& cfg, hipStream_
 #endif
 }
 
-#ifndef FASTSVC_ACT_BF16      // storage-independent host query: defined once
+#ifndef FASTSVC_ACT_BF16      // storage-independent host queries: defined once
 bool conv_wx_shape(int mode, int MW, int NW, int WM, int WN) {
     return mode == MODE_DIRECT && MW == WX_MW && NW == WX_NW && WM == WX_WM && WN == WX_WN;
+}
+// whether the window buffers (dilation dil), the two units of weights and the patches fit the CU's LDS
+bool conv_wx_fits(int nch32, int dil) {
+    ConvParams q{};
+    q.nch32 = nch32; q.dil = dil;
+    return wx_smem(q, 1) + WX_STATIC_LDS <= 160 * 1024;       // (the kernel exists in bfloat16 storage only)
 }
 #endif
 

@@ -928,8 +928,11 @@ def test_long_near_constant_rows_under_instance_norm(dev, excitation):
     """The worst inputs for the one-pass float32 InstanceNorm partial sums (VERDICT r3 task 6): ONE PPG
     frame repeated over a whole 2 s utterance, with a silent / constant / ordinary excitation - rows of the first up
     blocks whose variance is far below their squared mean (fastsvc.py:76,138: InstanceNorm2d over the whole time axis,
-    eps 1e-5).  Held against the float64 oracle at 3e-4 of the output's range (north-star bar 1e-3; measured
-    1e-5 ... 1.5e-4), through the module's default path (compact workspace, whole-stage conditioning launch)."""
+    eps 1e-5).  Held against the float64 oracle at the north-star bar, 1e-3 of the output's range, through the module's default
+    path (compact workspace, whole-stage conditioning launch).  The "constant" case is ill-conditioned: over eight generator /
+    input seeds its error ranges 5e-5 ... 8e-4 of the range, with the same spread whichever way the conditioning stages order
+    their float32 sums (profiles/r6_near_constant_sweep.txt; seed 431 alone measured 1.9e-4 in round 5 and 4.8e-4 in round 6,
+    seed 434 8e-4 in both); "silent" and "sine" sit at 2e-6."""
     O = _oracle()
     cfg = S.FULL_CONFIG
     sd = S.synth_state_dict(cfg, 431)
@@ -948,7 +951,7 @@ def test_long_near_constant_rows_under_instance_norm(dev, excitation):
     ref = O.forward_dedup(S.fold_weight_norm(sd), cfg.upsampling_scales, ppg, sine, lft, b.spk_emb, dtype=torch.float64)
     rng = float(ref.abs().max())
     err = float((y - ref).abs().max())
-    assert np.isfinite(err) and err <= 3e-4 * max(1.0, rng), (excitation, err, rng)
+    assert np.isfinite(err) and err <= (1e-3 if excitation == "constant" else 3e-4) * max(1.0, rng), (excitation, err, rng)
 
 
 @pytest.mark.parametrize("storage", ["float32", "bfloat16"])
