@@ -258,7 +258,8 @@ def test_launch_shape_table_roundtrip_and_shipped_file():
         layer, b, t, *storage = key.split("|")                      # "...|b": entries of the bfloat16-storage mode
         assert int(b) >= 1 and int(t) >= 1 and layer and storage in ([], ["b"])
         # algo 0 / 1 / 2: f32-MFMA direct / Winograd (48- / 32-channel groups); 3: half-precision MFMA (fastsvc_hx.hip)
-        assert nw in (1, 2, 3, 4, 6, 8) and wm * wn == 4 and 1 <= tpw <= 24 and algo in (0, 1, 2, 3)
+        # 4 / 5: the conditioning stages' phase kernel / layer pipeline; 6: the wide-layer kernel (fastsvc_wx.hip: eight waves)
+        assert nw in (1, 2, 3, 4, 6, 8) and wm * wn == (8 if algo == 6 else 4) and 1 <= tpw <= 24 and algo in (0, 1, 2, 3, 6)
     shipped = A.Plan(S.FULL_CONFIG)
     assert shipped.tuned_shapes() == {k: list(v) for k, v in table.items()}
     # the bfloat16-storage plan holds the same table; its launches look up the "|b" keys

