@@ -98,7 +98,7 @@ SHORT_DTYPE = {"float32": "f32 (products as split-f16 MFMA x3, f32 accumulate; f
                "bfloat16": "bf16 (bf16 MFMA products, f32 accumulate; bf16 storage)"}
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "secondary", "detail")
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches_per_step",
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "kernel", "avg_launch_us", "launches_per_step",
                  "alg_bytes_per_launch", "alg_flops_per_launch", "e2e_frac", "most_time_lost")
 
 
@@ -143,6 +143,8 @@ def compact_secondary(sec):
         else:
             e2e = ((v.get("roofline") or {}).get("e2e") or {}).get("frac")
             out[k] = {"ms_per_step": v.get("ms_per_step"), "e2e_frac": e2e}
+            if "predicted_speedup_vs_1gpu" in v:                      # (a prediction from single-GPU legs, labelled as one)
+                out[k] = {"ms_per_step": v.get("ms_per_step"), "predicted_speedup_vs_1gpu": v["predicted_speedup_vs_1gpu"], "predicted": True}
             if v.get("n_gpus", 1) != 1:
                 out[k]["n_gpus"] = v["n_gpus"]
     return out
@@ -356,16 +358,43 @@ def cpu_baseline(budget_s: float):
                      "sample": f"8 x 4 s batch (768000 samples) per run, median of {n2} runs"}}
 
 
+PMC_TAG = "r6"       # profiles/<tag>_<workload>_<storage>_pmc_traffic.json: the counter passes `roofline.traffic` quotes
+
+
 def kernel_peak_tflops(kernel: str) -> float:
     """Dense MFMA peak of the arithmetic a kernel symbol runs, in ALGORITHMIC (direct-conv, 2*MAC)
     FLOP/s: f32-input MFMA for conv_mfma*; the split-half kernels (conv_hx<... P=3>) spend three
     f16 MFMA products per algorithmic MAC, the bf16 ones (P=1) one."""
-    if kernel.startswith("conv_hx"):
+    if kernel.startswith(("conv_hx", "conv_wx")):
         nprod = 3 if ",x3" in kernel else 1
         return PEAK_HALF_MFMA_TFLOPS / nprod
     if kernel.startswith("cond_stage"):                      # whole-stage conditioning launch (csrc/fastsvc_cond.hip)
         return PEAK_HALF_MFMA_TFLOPS / (3 if "x3" in kernel else 1)
     return PEAK_FP32_MFMA_TFLOPS
+
+
+def pmc_traffic(kern, shares, names, root=None):
+    """(HBM bytes per launch of kernel `kern`, where the figure comes from, stale?) from the first committed PMC summary of
+    `names` under profiles/ that exists.  `shares`: kernel symbol -> share of the step's time, of the kernels THIS run
+    launched.  The summary is stale when a kernel that takes >= 1 % of the step is not in it (a kernel was added, renamed or
+    re-instantiated since the counter passes were taken): the line then says so instead of quoting old counters silently."""
+    for name in names:
+        pmc = os.path.join(root or os.path.join(ROOT, "profiles"), name) if name else None
+        if not (pmc and os.path.exists(pmc)):
+            continue
+        try:
+            table = json.load(open(pmc))
+        except Exception:
+            continue
+        missing = sorted(k for k, share in shares.items() if share >= 0.01 and k not in table)
+        traffic = table.get(kern)
+        source = (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload, "
+                  "tools/collect_cfg3.sh + tools/summarize_profiles.py; FETCH_SIZE doubled per the guide's gfx950 "
+                  "correction; regenerated whenever a kernel changes) - not measured by this run")
+        if missing:
+            source += f"; STALE: not in the summary: {', '.join(missing[:6])}"
+        return traffic, source, bool(missing)
+    return None, None, False
 
 
 def roofline(plan, blob, args_dev, ms_per_step, n_prof=3, lengths=None, pmc_file=None):
@@ -401,27 +430,16 @@ def roofline(plan, blob, args_dev, ms_per_step, n_prof=3, lengths=None, pmc_file
     t_mfma = a["flops"] / (peak_tf * 1e12)
     t_hbm = a["bytes"] / (PEAK_HBM_GBS * 1e9)
     # HBM bytes per launch from the PMC counters: they need separate rocprofv3 --pmc passes (tools/pmc.sh), so the
-    # figure comes from the committed summary of the same command, not from this run - `traffic_source` says which
-    traffic, traffic_source = None, None
-    for name in (pmc_file, "pmc_traffic.json"):
-        pmc = os.path.join(ROOT, "profiles", name) if name else None
-        if pmc and os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(kern)
-            except Exception:
-                traffic = None
-            if traffic is not None:
-                traffic_source = (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload, "
-                                  "tools/collect_cfg3.sh + tools/summarize_profiles.py; FETCH_SIZE doubled per the guide's gfx950 "
-                                  "correction; regenerated whenever a kernel changes) - not measured by this run")
-                break
+    # figure comes from the committed summary of the same command, not from this run - `traffic_source` says which, and
+    # `traffic_stale` says whether that summary still describes the kernels this run launched
+    traffic, traffic_source, traffic_stale = pmc_traffic(kern, {k: v["ms"] / total_ms for k, v in agg.items()}, (pmc_file, "pmc_traffic.json"))
     if t_mfma >= t_hbm:
         out = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf}
     else:
         out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
     roof_step = roof_ms_total / n_prof
     out.update({
-        "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+        "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
         "kernel": kern, "kernel_choice": "most time per step",
         "most_time_lost": {"kernel": lost_k, "ms_per_step": lost_a["ms"] / n_prof, "roofline_ms": lost_a["roof_ms"] / n_prof,
                            "frac": lost_a["roof_ms"] / lost_a["ms"], "lost_ms_per_step": (lost_a["ms"] - lost_a["roof_ms"]) / n_prof},
@@ -474,10 +492,11 @@ def time_steps(step, drain, steps, warmup, dist, dev):
     return elapsed
 
 
-def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=True, n_prof=2):
-    """One extra workload on this GPU (the `secondary` block): device-generated utterances."""
+def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=True, n_prof=2, batch=None):
+    """One extra workload on this GPU (the `secondary` block): device-generated utterances.  batch: another batch size at the
+    workload's utterance length (cfg3 at B = 32: what each of 8 ranks runs twice for cfg4)."""
     wl = S.WORKLOADS[name]
-    B, F = wl["B"], wl["F"]
+    B, F = batch or wl["B"], wl["F"]
     T = F * cfg.hop
     plan = A.Plan(cfg, load_shipped_table=use_table, storage=storage, compact_workspace=True)
     blob = plan.pack(S.synth_state_dict(cfg, WEIGHT_SEED)).to(dev)
@@ -487,7 +506,7 @@ def run_single_gpu_workload(cfg, name, storage, dev, steps, warmup, use_table=Tr
     elapsed = time_steps(lambda i: plan.forward(blob, *args_dev, out=out, workspace=ws),
                          torch.cuda.synchronize, steps, warmup, None, dev)
     ms = elapsed / steps * 1e3
-    roof = roofline(plan, blob, args_dev, ms, n_prof=n_prof, pmc_file=f"r5c_{name}_{storage}_pmc_traffic.json")
+    roof = roofline(plan, blob, args_dev, ms, n_prof=n_prof, pmc_file=f"{PMC_TAG}_{name}_{storage}_pmc_traffic.json")
     top = sorted(roof["per_kernel"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]
     res = {"workload": f"{name}: {wl['desc']}, F={F}, T={T}", "storage": storage,
            "dtype": plan.arithmetic, "ms_per_step": ms, "value": B * T * steps / elapsed, "unit": "samples/s",
@@ -956,7 +975,7 @@ def main(argv=None):
             args_dev = roofline_batch()
         batch_share = B * T / (float(sum(n_frames[i] for i in mine)) * cfg.hop) if strong else 1.0
         roof = roofline(plan, blob, args_dev, ms_per_step * batch_share,
-                        pmc_file=f"r5c_{'cfg3' if strong else args.workload}_{args.storage}_pmc_traffic.json")
+                        pmc_file=f"{PMC_TAG}_{'cfg3' if strong else args.workload}_{args.storage}_pmc_traffic.json")
         secondary = None
         if world == 1 and not args.no_secondary and default_workload:
             del ws
@@ -966,6 +985,7 @@ def main(argv=None):
                     ("cfg2_float32", lambda: run_single_gpu_workload(cfg, "cfg2", "float32", dev, steps=200, warmup=50, use_table=not args.no_table)),
                     ("cfg2_bfloat16", lambda: run_single_gpu_workload(cfg, "cfg2", "bfloat16", dev, steps=200, warmup=50, use_table=not args.no_table)),
                     ("cfg1_float32", lambda: run_single_gpu_workload(cfg, "cfg1", "float32", dev, steps=200, warmup=50, use_table=not args.no_table)),
+                    ("cfg3_b32_bfloat16", lambda: run_single_gpu_workload(cfg, "cfg3", "bfloat16", dev, steps=20, warmup=5, use_table=not args.no_table, batch=32)),
                     ("cfg4_bfloat16_n1", lambda: run_cfg4_single_gpu(cfg, dev, storage="bfloat16")),
                     ("cfg4_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev)),
                     ("cfg4var_float32_n1", lambda: run_cfg4_single_gpu(cfg, dev, name="cfg4var")),
@@ -978,6 +998,22 @@ def main(argv=None):
                     secondary[key] = fn()
                 except Exception as e:        # an extra block must never take the headline line down
                     secondary[key] = {"error": repr(e)}
+            # What 8 ranks would take for cfg4 (512 x 10 s, 64 utterances per rank in two half-batches of 32 so that the first
+            # half's all-gather overlaps the second half's kernels, distributed.GatherSchedule): two 32-utterance forwards plus
+            # the non-overlapped gather of the LAST half - 8 x 32 x 240000 float32 samples, priced at the per-link bound of a
+            # ring over xGMI ((N-1)/N of the gathered bytes at 153 GB/s; a direct all-to-all over 7 links would be 7x
+            # shorter).  A prediction from single-GPU measurements: no 8-GPU node was available to this build.
+            try:
+                t32 = secondary["cfg3_b32_bfloat16"]["ms_per_step"]
+                t1 = secondary["cfg4_bfloat16_n1"]["ms_per_step"]
+                gather_ms = (7.0 / 8.0) * (8 * 32 * 240000 * 4) / 153e9 * 1e3
+                secondary["cfg4_predicted_8rank_bfloat16"] = {
+                    "ms_per_step": 2.0 * t32 + gather_ms, "half_batch_ms": t32, "gather_tail_ms": gather_ms,
+                    "predicted_speedup_vs_1gpu": t1 / (2.0 * t32 + gather_ms),
+                    "note": "2 x (32 x 10 s forward on one GPU) + ring all-gather tail at the xGMI per-link bound; "
+                            "measured on ONE GPU, not an 8-GPU run"}
+            except Exception:
+                pass
         if weak is not None:
             secondary = {"weak_cfg2": weak}
         cpu = None

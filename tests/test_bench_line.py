@@ -87,3 +87,23 @@ def test_gpus_n_refuses_fewer_devices():
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_pmc_traffic_lookup_flags_a_stale_summary(tmp_path):
+    """`roofline.traffic` quotes a committed counter summary keyed by kernel symbol: when a kernel that
+    takes >= 1 % of the step is not in it - added, renamed or re-instantiated since the passes - the line says
+    `traffic_stale: true` instead of quoting old counters silently."""
+    import json
+    import bench
+    (tmp_path / "x_pmc_traffic.json").write_text(json.dumps({"conv_hx<2,2,1,4,0,4,1,x1>": 3.0e9, "spk_proj": 6.0e6}))
+    shares = {"conv_hx<2,2,1,4,0,4,1,x1>": 0.6, "spk_proj": 0.002}
+    t, src, stale = bench.pmc_traffic("conv_hx<2,2,1,4,0,4,1,x1>", shares, ("x_pmc_traffic.json",), root=str(tmp_path))
+    assert t == 3.0e9 and stale is False and "STALE" not in src
+    shares["conv_wx<3,6,4,2,1,x1>"] = 0.03                   # a new kernel takes 3 % of the step
+    t, src, stale = bench.pmc_traffic("conv_hx<2,2,1,4,0,4,1,x1>", shares, ("x_pmc_traffic.json",), root=str(tmp_path))
+    assert t == 3.0e9 and stale is True and "conv_wx<3,6,4,2,1,x1>" in src
+    shares["tiny_kernel"] = 0.001                            # below 1 %: ignored
+    del shares["conv_wx<3,6,4,2,1,x1>"]
+    assert bench.pmc_traffic("spk_proj", shares, ("missing.json", "x_pmc_traffic.json"), root=str(tmp_path))[2] is False
+    assert bench.pmc_traffic("spk_proj", shares, ("missing.json",), root=str(tmp_path)) == (None, None, False)
+    assert "traffic_stale" in bench.ROOFLINE_KEYS

@@ -56,6 +56,13 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
         n0 = merged.get(key, 0)
         js[key] = (js.get(key, 0.0) * n0 + hbm * fetch[k][1]) / (n0 + fetch[k][1])
         merged[key] = n0 + fetch[k][1]
+    # the wide-layer kernel (csrc/fastsvc_wx.hip): PRO, EPI template arguments; bench.py names it by shape and epilogue kind
+    m = re.search(r"conv_wx_kernel<(\d+), (\d+)>", k)
+    if m:
+        key = "conv_wx<3,6,4,2,%s,x1>" % m.group(2)
+        n0 = merged.get(key, 0)
+        js[key] = (js.get(key, 0.0) * n0 + hbm * fetch[k][1]) / (n0 + fetch[k][1])
+        merged[key] = n0 + fetch[k][1]
     # whole-stage conditioning launches (csrc/fastsvc_cond.hip)
     m = re.search(r"cond_stage(\d)(_pipe)?_kernel", k)
     if m:
