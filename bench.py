@@ -791,10 +791,15 @@ def run_cfg5(args, dist, world, rank, dev, extras=True):
 def run_cfg5_secondary(storage, dev, steps=10, warmup=6, discriminator="melgan"):
     """BASELINE config 5's train step inside the default line: 10 timed steps at the recipe batch on this GPU."""
     ns = argparse.Namespace(storage=storage, steps=steps, warmup=warmup, no_cpu_baseline=True, cpu_seconds=0.0, discriminator=discriminator)
+    from svcc23_fastsvc_amd import conv_grad as _cg, gconv as _gc
+    before = (dict(_cg.ROUTES), dict(_gc.ROUTES))
     full = run_cfg5(ns, None, 1, 0, dev, extras=False)
     torch.cuda.empty_cache()
+    # how the step's convolution nodes were routed (HIP kernels vs the stock operator for shapes they decline): a table or shape
+    # change that moves the step back onto the stock operators shows here
+    routes = {"conv1d": {k: _cg.ROUTES[k] - before[0][k] for k in before[0]}, "grouped_conv1d": {k: _gc.ROUTES[k] - before[1][k] for k in before[1]}}
     return {"workload": full["config"]["workload"], "ms_per_step": full["ms_per_step"], "value": full["value"],
-            "unit": full["unit"], "steps": steps, "warmup": warmup, "dtype": full["dtype"]}
+            "unit": full["unit"], "steps": steps, "warmup": warmup, "dtype": full["dtype"], "conv_routes_all_steps": routes}
 
 
 def main(argv=None):

@@ -88,6 +88,10 @@ class _Conv1dFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+# calls of conv1d() by route since import (bench.py reports them next to the train step)
+ROUTES = {"hip": 0, "stock": 0}
+
+
 def conv1d_supported(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) -> bool:
     """What csrc/fastsvc_convgrad.hip takes: k = 1 or 3, halo (k // 2) * dilation <= 27, every tensor below 2 GiB."""
     k = int(weight.shape[-1])
@@ -103,10 +107,12 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if x.dim() != 3 or weight.dim() != 3 or weight.shape[1] != x.shape[1]:
         raise ValueError(f"conv1d: x {tuple(x.shape)} / weight {tuple(weight.shape)} do not fit")
     if not conv1d_supported(x, weight, dilation):
+        ROUTES["stock"] += 1
         # shapes the kernels decline (FASTSVC_E_UNSUPPORTED: other tap counts, halos past 27, tensors of 2 GiB and more): the
         # stock operator on the same GPU tensors - still no CPU route
         import torch.nn.functional as F
         return F.conv1d(x, weight, bias, padding=(weight.shape[-1] // 2) * int(dilation), dilation=int(dilation))
+    ROUTES["hip"] += 1
     return _Conv1dFn.apply(x, weight, bias, int(dilation))
 
 

@@ -1743,8 +1743,11 @@ hipError_t run_d3x(const UpStage& u, const float* blob, ConvParams p, hipStream_
     if (what == 2) {
         if (have || !g_tune.tuning || !g_tune.plan) return hipSuccess;
         static const int tpws[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24};
-        hipEvent_t e0, e1;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return hipErrorUnknown;
+        struct EventPair {                                 // (destroyed on every way out of the timing loop: ADVICE r5)
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~EventPair() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+        } ev;
+        if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess) return hipErrorUnknown;
         float best_ms = 1e30f;
         ConvParams q = p;
         q.flags &= ~F_STATS;                               // (the trial launches do not accumulate InstanceNorm sums)
@@ -1755,18 +1758,20 @@ hipError_t run_d3x(const UpStage& u, const float* blob, ConvParams p, hipStream_
                 ConvLaunch Lq{c.MW, cd.NW, cd.WM, cd.WN, 1, 2};
                 hipError_t e = launch(q, Lq);
                 if (e != hipSuccess) return e;
-                hipEventRecord(e0, stream);
+                hipEventRecord(ev.e0, stream);
                 for (int r = 0; r < 3; ++r) { e = launch(q, Lq); if (e != hipSuccess) return e; }
-                hipEventRecord(e1, stream);
-                if (hipEventSynchronize(e1) != hipSuccess) return hipErrorUnknown;
+                hipEventRecord(ev.e1, stream);
+                if (hipEventSynchronize(ev.e1) != hipSuccess) return hipErrorUnknown;
                 float ms = 0.f;
-                hipEventElapsedTime(&ms, e0, e1);
+                hipEventElapsedTime(&ms, ev.e0, ev.e1);
                 ++g_tune.trials;
                 if (ms < best_ms) { best_ms = ms; best = cd; p.tpw = tpw; }
                 if (tpw >= ntx) break;
             }
         }
-        hipEventDestroy(e0); hipEventDestroy(e1);
+        // (sep_ms times the two separate launches back to back on ONE stream; in production the residual conv runs on the side
+        // stream under up_stretch, so this comparison favours the fused launch by at most the residual conv's own time - the
+        // fused launch also saves that tensor's write and read, which the whole-forward timing of tools/tune_shapes.py sees)
         fused = sep_ms <= 0.0 || best_ms / 3.0 < sep_ms;
         std::lock_guard<std::mutex> lock(g_tune.plan->tune_mu);
         g_tune.plan->tuned[key] = fastsvc_plan::Choice{best.NW, best.WM, best.WN, p.tpw, fused ? 3 : 0};
@@ -2999,6 +3004,10 @@ static int forward_impl(const fastsvc_plan* plan, const void* dev_blob,
         if (d3_fused) {
             bool ran = false;
             HIP_TRY(run_d3x(u, blob, pd3, stream, prof, nd3x.c_str(), 1, 0.0, ran));
+            // (the route was decided by the query call in front of conv_first - the separate residual launch was skipped on its
+            // word; a launch table that changed in between - another thread's load_tuned on this plan - must not leave xmid / u2
+            // unwritten: ADVICE r5)
+            if (!ran) return fail(FASTSVC_E_INVALID, "up." + s + ".d3x: the launch table changed between the route decision and the launch");
         } else {
         HIP_TRY(order_after(s_side, stream));                      // xr is ready
         HIP_TRY(run_conv(u.d3, blob, p, 1, 0, 0, stream, prof, ("up." + s + ".d3").c_str()));

@@ -22,6 +22,9 @@ from .conv_grad import _guard, _lib, _ptr
 from .engine import FastSVCError
 
 USE_HIP = True            # module switch (A/B timing, tests of the stock route)
+# how often a call took which route since import (bench.py reports them: a shape or table change that moves the step back onto
+# the stock operators must not go unnoticed)
+ROUTES = {"hip": 0, "stock": 0}
 
 
 def supported(conv: nn.Conv1d) -> bool:
@@ -90,10 +93,15 @@ class GroupedConv1d(nn.Conv1d):
     """``nn.Conv1d`` whose call may fuse the LeakyReLU behind it: ``conv(x, act_slope=0.2)``."""
 
     def forward(self, input: torch.Tensor, act_slope: Optional[float] = None) -> torch.Tensor:  # noqa: A002
-        if (USE_HIP and input.is_cuda and input.dtype == torch.float32 and self.weight.dtype == torch.float32 and
+        # (the fused backward takes the activation's derivative from the sign of the ACTIVATED output: right for slopes in
+        # (0, 1] only - a negative slope flips the sign, slope 0 loses it - every other slope runs the stock pair)
+        slope_ok = act_slope is None or 0.0 < float(act_slope) <= 1.0
+        if (USE_HIP and slope_ok and input.is_cuda and input.dtype == torch.float32 and self.weight.dtype == torch.float32 and
                 not torch.is_autocast_enabled() and input.dim() == 3 and supported(self)):
+            ROUTES["hip"] += 1
             return _GroupedConvActFn.apply(input, self.weight, self.bias, self.groups, self.stride[0], self.padding[0],
                                            1.0 if act_slope is None else float(act_slope))
+        ROUTES["stock"] += 1
         y = super().forward(input)
         return y if act_slope is None else F.leaky_relu(y, act_slope)
 

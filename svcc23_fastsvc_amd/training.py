@@ -209,12 +209,14 @@ class HiFiGANPeriodDiscriminator(nn.Module):
         self.convs = nn.ModuleList()
         c_in, c_out = in_channels, channels
         for sc in downsample_scales:
-            self.convs.append(nn.Sequential(nn.Conv2d(c_in, c_out, (k0, 1), (int(sc), 1), padding=((k0 - 1) // 2, 0), bias=bias),
+            self.convs.append(nn.Sequential(nn.Conv2d(c_in, c_out, (k0, 1), (int(sc), 1), padding=((k0 - 1) // 2, 0)),
                                             _activation(nonlinear_activation, act)))
             c_in, c_out = c_out, min(c_out * 4, max_downsample_channels)
         # (c_out has already been advanced once more: the reference's output conv reads `out_chs`, not `in_chs` - equal
         # whenever the last hidden width sits at the cap, which the constructor requires of a loadable configuration)
-        self.output_conv = nn.Conv2d(c_out, out_channels, (k1 - 1, 1), 1, padding=((k1 - 1) // 2, 0), bias=bias)
+        self.output_conv = nn.Conv2d(c_out, out_channels, (k1 - 1, 1), 1, padding=((k1 - 1) // 2, 0))
+        # (the reference never hands `bias` to these Conv2d layers, fastsvc.py:631-700: they always have one - a
+        # period_discriminator_params with bias=False must give the same module tree and state-dict keys as the reference's)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 if use_weight_norm:

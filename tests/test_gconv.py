@@ -78,7 +78,12 @@ def test_discriminator_same_outputs_and_gradients_with_the_kernels_on_and_off():
         try:
             d.zero_grad()
             x.grad = None
+            before = dict(GC.ROUTES)
             outs = d(x)
+            # (with the switch on, the nine grouped k = 41 layers must really take the HIP node - were they declined,
+            # both runs would be the stock operators and the comparison below would pass on nothing)
+            took = {k: GC.ROUTES[k] - before[k] for k in before}
+            assert took == ({"hip": 9, "stock": 0} if on else {"hip": 0, "stock": 9}), (on, took)
             loss = sum(((o[-1] - 1.0) ** 2).mean() for o in outs) + sum(f.abs().mean() for o in outs for f in o[:-1])
             loss.backward()
             res[on] = (float(loss), [o[-1].detach().clone() for o in outs], x.grad.clone(),
@@ -91,3 +96,31 @@ def test_discriminator_same_outputs_and_gradients_with_the_kernels_on_and_off():
     assert float((res[True][2] - res[False][2]).abs().max()) <= 1e-4 * float(res[False][2].abs().max())
     for k, gr in res[False][3].items():
         assert float((res[True][3][k] - gr).abs().max()) <= 1e-4 * max(1e-6, float(gr.abs().max())), k
+
+
+@pytest.mark.gpu
+def test_slopes_outside_zero_one_run_the_stock_pair():
+    """The fused backward recovers LeakyReLU' from the sign of the ACTIVATED output: right for slopes in (0, 1] only.
+    A negative slope or slope 0 must take the stock operators - and give their gradients."""
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    conv = GC.GroupedConv1d(16, 64, kernel_size=41, stride=4, padding=20, groups=4).to(dev)
+    assert GC.supported(conv)
+    x = (torch.randn((2, 16, 1024), device=dev) * 0.5).requires_grad_(True)
+    for slope in (-0.3, 0.0, 0.2):
+        before = dict(GC.ROUTES)
+        x.grad = None
+        conv.zero_grad()
+        y = conv(x, act_slope=slope)
+        y.square().sum().backward()
+        took = {k: GC.ROUTES[k] - before[k] for k in before}
+        assert took == ({"hip": 1, "stock": 0} if 0.0 < slope <= 1.0 else {"hip": 0, "stock": 1}), (slope, took)
+        gx, gw = x.grad.clone(), conv.weight.grad.clone()
+        x.grad = None
+        conv.zero_grad()
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(x, conv.weight, conv.bias, stride=4, padding=20, groups=4), slope)
+        ref.square().sum().backward()
+        assert float((y - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+        assert float((gx - x.grad).abs().max()) <= 1e-4 * max(1e-6, float(x.grad.abs().max())), slope
+        assert float((gw - conv.weight.grad).abs().max()) <= 1e-4 * max(1e-6, float(conv.weight.grad.abs().max())), slope
