@@ -585,6 +585,20 @@ __device__ __forceinline__ void hx_last_reduce(const ConvParams& p, const f32x4 
 // prologue (the conv's zero padding), the epilogue keeps it out of the InstanceNorm sums and the running max and
 // stores the straddling float4 whole (between the row end and the pitch lies nobody's data).  Its own instances:
 // folded into the others it cost the 128-register variants their spill-free allocation.
+// bfloat16 storage, plain windows (a direct conv's or the stretched conv's input): the staging waves request 16 bytes per
+// lane - 8 time steps of one channel - instead of 8.  A CU's vector-memory pipe takes a wave's request in about the same
+// time whatever its width (tools/micro/cu_pull.hip, profiles/r6_cu_pull_microbench.txt: 8 B per lane requests stop at
+// ~13 B/clk per CU even out of L2, 16 B ones reach 19-47), and the windows were the only 8 B requests left in the
+// bfloat16 path.  Item = (quad of 4 channels, octet of 8 rows): 4 requests of 8 rows x 128 B per item, the same 16
+// registers per set; the window's halo is aligned to 8 rows so that an item lies inside the utterance or outside it
+// (its first 4 rows inside: row ends are multiples of 4).
+#ifndef FASTSVC_HX_W8
+#define FASTSVC_HX_W8 1
+#endif
+constexpr bool hx_w8(int MODE, bool tailk, int S) {      // (the decimating pair: its compact-input instance, S = 2)
+    return FASTSVC_HX_W8 != 0 && HX_NP == 1 && !tailk && (MODE == MODE_DIRECT || MODE == MODE_POLY || (MODE == MODE_DEC2 && S == 2));
+}
+
 template <int MW, int NW, int WM, int WN, int MODE, int EPI, int S, bool WSTATIC, bool TAILK = false>
 __global__ __launch_bounds__(512, (hx_min_waves<MW, NW, MODE, EPI, S>()))
 void conv_hx_kernel(const ConvParams p0) {
@@ -605,7 +619,9 @@ void conv_hx_kernel(const ConvParams p0) {
     constexpr int NTV = CHAIN ? NT + 16 : NT;                          // columns the staged window serves
     constexpr int HB = CHAIN ? 4 : 0;                                  // aligned halo of the second conv
     constexpr int NPROD_T = 256;                                       // producer threads
-    constexpr int MAXW = NTV + (MODE == MODE_DIRECT ? 56 : 8);         // halo <= 28 rows per side (POLY / DEC2: 1, CHAIN: <= 4)
+    constexpr bool W8 = hx_w8(MODE, TAILK, S);                            // 16-byte window requests (see hx_w8)
+    constexpr int SPARE = W8 ? 8 : 4;                                  // rows behind the tile where item-less threads park
+    constexpr int MAXW = NTV + (MODE == MODE_DIRECT ? (W8 ? 64 : 56) : (W8 ? 16 : 8));   // halo <= 28 rows per side (POLY / DEC2: 1, CHAIN: <= 4)
     constexpr int ITEMS = (MAXW + NPROD_T - 1) / NPROD_T;              // (octet, 4 time steps) items per producer thread
     constexpr int NWS = DEC2 ? 4 : 3;                                  // weight slots per unit and channel tile
     constexpr int NVAR = DEC2 ? 2 : 1;                                 // tile variants: LeakyReLU'd (+ raw)
@@ -633,7 +649,7 @@ void conv_hx_kernel(const ConvParams p0) {
     const int mg = blockIdx.y * WM + wave_m;
     const bool active = !producer && mg < p.ngroups;
     const int halo = (MODE == MODE_DIRECT || CHAIN) ? p.dil : 1;
-    const int halo_al = (halo + 3) & ~3;
+    const int halo_al = W8 ? ((halo + 7) & ~7) : ((halo + 3) & ~3);
     const int W = NTV + 2 * halo_al;                                   // tile rows
     const int nch = p.nch32;
     const int CINp = nch * HX_KC;
@@ -720,9 +736,9 @@ void conv_hx_kernel(const ConvParams p0) {
         }
 #endif
     };
-    const int lo_off = (W + 4) * HX_ROW;                               // hi tile (+ 4 spare rows), then lo tile
-    const int raw_off = HX_NP * (W + 4) * HX_ROW;                      // DEC2: the raw tile behind the LeakyReLU'd one
-    const int bufsz = NVAR * HX_NP * (W + 4) * HX_ROW;
+    const int lo_off = (W + SPARE) * HX_ROW;                           // hi tile (+ the spare rows), then lo tile
+    const int raw_off = HX_NP * (W + SPARE) * HX_ROW;                  // DEC2: the raw tile behind the LeakyReLU'd one
+    const int bufsz = NVAR * HX_NP * (W + SPARE) * HX_ROW;
     // MODE_CHAIN: the intermediate tile behind the two window buffers, [32-channel chunk][hi, lo][NT + 16 rows]
     constexpr int T2ROWS = NT + 16;
     constexpr int T2CHUNK = HX_NP * T2ROWS * HX_ROW;
@@ -814,9 +830,15 @@ void conv_hx_kernel(const ConvParams p0) {
         #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const int idx = i * NPROD_T + ptid;
-            it_oct[i] = idx & 3;
-            it_in[i] = (idx >> 2) < (W >> 2);
-            it_q[i] = it_in[i] ? (idx >> 2) : (W >> 2);
+            if constexpr (W8) {                          // (quad of 4 channels, octet of 8 rows)
+                it_oct[i] = idx & 7;
+                it_in[i] = (idx >> 3) < (W >> 3);
+                it_q[i] = it_in[i] ? (idx >> 3) : (W >> 3);
+            } else {
+                it_oct[i] = idx & 3;
+                it_in[i] = (idx >> 2) < (W >> 2);
+                it_q[i] = it_in[i] ? (idx >> 2) : (W >> 2);
+            }
         }
         const float slope = (DEC2 || (flags & F_PRE_LRELU)) ? LRELU_SLOPE : 1.0f;     // max(v, slope * v): identity for 1
         const bool tail_rows = TAILK && (p.T & 3) != 0;    // this utterance's rows end inside a float4 (ragged batch)
@@ -849,6 +871,25 @@ void conv_hx_kernel(const ConvParams p0) {
             const int soff = ch * HX_KC * p.ldx * 4;
             const int rows_left = p.CIN - ch * HX_KC;
             tokmask = 0;
+#ifdef FASTSVC_ACT_BF16
+            if constexpr (W8) {
+                #pragma unroll
+                for (int i = 0; i < ITEMS; ++i) {
+                    const int t = t_start + 8 * it_q[i];                       // a multiple of 8: the item starts inside the row or not at all
+                    const bool live = it_in[i] & ((unsigned)t < (unsigned)p.T) & (un < nunits) & !(FASTSVC_DBG_ON(p, DBG_NO_LOAD));
+                    tokmask |= (live ? (unsigned)min(8, p.T - t) : 0u) << (4 * i);      // 8, or 4 at the row's end
+                    #pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int r = it_oct[i] * 4 + c;
+                        typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+                        const u32x4w w = __builtin_amdgcn_raw_buffer_load_b128(xr, (live & (r < rows_left)) ? (r * p.ldx + t) * 2 : OOB_OFF, soff >> 1, FASTSVC_LD_AUX);
+                        px[i][2 * c] = act4_t{w.x, w.y};
+                        px[i][2 * c + 1] = act4_t{w.z, w.w};
+                    }
+                }
+                return;
+            }
+#endif
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const int t = t_start + 4 * it_q[i];
@@ -919,6 +960,51 @@ void conv_hx_kernel(const ConvParams p0) {
                 }
                 return;
             }
+#ifdef FASTSVC_ACT_BF16
+            if constexpr (W8) {
+                const bool row_end = (p.T & 7) != 0;           // (wave-uniform) the last item of a row holds 4 rows of it
+                #pragma unroll
+                for (int i = 0; i < ITEMS; ++i) {
+                    const int nvi = (int)((tokmask >> (4 * i)) & 15u);
+                    const f32x4* cf = reinterpret_cast<const f32x4*>(ncoef + (nvi != 0 ? ch * HX_KC + it_oct[i] * 4 : CINp));
+                    const f32x4 c0 = cf[0], c1 = cf[1];
+                    const float A[4] = {c0.x, c0.z, c1.x, c1.z};
+                    const float Bc[4] = {c0.y, c0.w, c1.y, c1.w};
+                    f32x4 px[8];
+                    #pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        act4_t w = pw[i][c];
+                        asm volatile("" : "+v"(w));            // (the conversion stays behind the unit barrier, see below)
+                        px[c] = act_unpack4(w);
+                    }
+                    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float e[4];
+                        #pragma unroll
+                        for (int c = 0; c < 4; ++c) e[c] = px[2 * c + (j >> 2)][j & 3] * A[c] + Bc[c];
+                        if (j >= 4 && row_end) {
+                            #pragma unroll
+                            for (int c = 0; c < 4; ++c) e[c] = nvi > 4 ? e[c] : 0.f;
+                        }
+                        const int off = hx_lds_off(8 * it_q[i] + j, it_oct[i] >> 1) + (it_oct[i] & 1) * 8;
+                        if constexpr (DEC2) {                  // the raw copy for the 1x1 residual conv (see below)
+                            u32x2v hr;
+                            hr.x = bf16_pack2(e[0], e[1]);
+                            hr.y = bf16_pack2(e[2], e[3]);
+                            *reinterpret_cast<u32x2v*>(tile + raw_off + off) = hr;
+                        }
+                        #pragma unroll
+                        for (int c = 0; c < 4; ++c) e[c] = fmaxf(e[c], e[c] * slope);
+                        u32x2v h;
+                        h.x = bf16_pack2(e[0], e[1]);
+                        h.y = bf16_pack2(e[2], e[3]);
+                        *reinterpret_cast<u32x2v*>(tile + off) = h;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                return;
+            }
+#endif
             #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 // (A, Bc) of the item's 8 channels: 64 contiguous bytes
@@ -980,7 +1066,37 @@ void conv_hx_kernel(const ConvParams p0) {
         const __amdgpu_buffer_rsrc_t x2r = XR ? act_rsrc(p.x2, (long)b * p.x2_b, (long)p.CIN * p.ldx2) : xr;
         const int x2T = !XR ? 0 : p0.lens ? p0.lens[b] * p0.x2len_mul : p.x2_T;
         const int xoct = ptid & 3, xg = ptid >> 2;
+        // 16-byte-window instances (hx_w8), S = 2: item = (quad of 4 channels, group of 4 input columns) - FOUR 8-byte requests
+        // per item where the element loads below are 8 two-byte ones per column (a wave's request costs the CU's memory pipe
+        // about the same whatever its width: this operand, half of the main one's bytes, took two thirds of the staging
+        // waves' requests); 32 groups per tile cover window + halo for every shape.  The words are bfloat16 already: the
+        // commit is two byte-permutes per column and S 8-byte LDS writes; rows outside the window go to the lane's own
+        // 8 bytes of the spare rows.  Measured at cfg3 (round 6): up.0.d3x (S = 2, C = 192) 210 -> 186 us; S = 4: 259 -> 260
+        // (C = 96), 508 -> 518 (C = 48); S = 5 (C = 24): 885 -> 910 - there ONE wave commits 4 S rows per lane where four
+        // shared S each, and the staging waves' instruction count is what paces the narrow layers: S = 2 only.
+        constexpr bool XW = XR && W8 && S == 2;
+        const int xq4 = ptid & 7, xg4 = ptid >> 3;
         auto ploadX = [&](int un, act1_t (&px)[XJ][8]) {
+#ifdef FASTSVC_ACT_BF16
+            if constexpr (XW) {
+                const int tl = xl_tl, ch = xl_ch;
+                pos_next(xl_tl, xl_ch);
+                const int t_start = (tile0 + tl) * NT - halo_al;                  // >= -8
+                const int j = ((((t_start + 8 * S) / S) - 8) & ~3) + 4 * xg4;     // floor(t_start / S), down to a multiple of 4
+                // (row ends are multiples of 4 in these instances: a group lies inside the utterance or outside it)
+                const bool ok = ((unsigned)j < (unsigned)x2T) & (un < nunits);
+                const int rows_left = p.CIN - ch * HX_KC;
+                #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = xq4 * 4 + c;
+                    const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(x2r, (ok & (r < rows_left)) ? (r * p.ldx2 + j) * 2 : OOB_OFF,
+                                                                         ch * HX_KC * p.ldx2 * 2, FASTSVC_LD_AUX);
+                    px[0][2 * c] = w.x;
+                    px[0][2 * c + 1] = w.y;
+                }
+                return;
+            }
+#endif
             if constexpr (XR) {
                 const int tl = xl_tl, ch = xl_ch;        // (the odd units)
                 pos_next(xl_tl, xl_ch);
@@ -1001,6 +1117,29 @@ void conv_hx_kernel(const ConvParams p0) {
             }
         };
         auto pcommitX = [&](int un, const act1_t (&pw)[XJ][8], unsigned char* tile) {
+#ifdef FASTSVC_ACT_BF16
+            if constexpr (XW) {
+                const int tl = xc_tl;
+                pos_next(xc_tl, xc_ch);
+                const int t_start = (tile0 + tl) * NT - halo_al;
+                const int j = ((((t_start + 8 * S) / S) - 8) & ~3) + 4 * xg4;
+                const int r0 = j * S - t_start;
+                const int park = W * HX_ROW + (ptid & 63) * 8;
+                #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    u32x2v h;
+                    h.x = __builtin_amdgcn_perm(pw[0][2 + (k >> 1)], pw[0][0 + (k >> 1)], (k & 1) ? 0x07060302u : 0x05040100u);
+                    h.y = __builtin_amdgcn_perm(pw[0][6 + (k >> 1)], pw[0][4 + (k >> 1)], (k & 1) ? 0x07060302u : 0x05040100u);
+                    #pragma unroll
+                    for (int ph = 0; ph < S; ++ph) {
+                        const int r = r0 + k * S + ph;
+                        const int off = (unsigned)r < (unsigned)W ? hx_lds_off(r, xq4 >> 1) + (xq4 & 1) * 8 : park;
+                        *reinterpret_cast<u32x2v*>(tile + off) = h;
+                    }
+                }
+                return;
+            }
+#endif
             if constexpr (XR) {
                 const int tl = xc_tl;
                 pos_next(xc_tl, xc_ch);
@@ -1692,10 +1831,14 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
     const int tpw = p.tpw > 0 ? p.tpw : 1;
     dim3 grid((ntx + tpw - 1) / tpw, (p.ngroups + WM - 1) / WM, nsig * p.B);
     constexpr bool CHAIN = MODE == MODE_CHAIN || MODE == MODE_CHAIN1 || MODE == MODE_UPHEAD;
-    const int halo_al = (MODE == MODE_DIRECT || CHAIN) ? ((p.dil + 3) & ~3) : 4;
+    const bool w8 = hx_w8(MODE, p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0),     // (the instance hx_launch_kind picks)
+                          MODE == MODE_DEC2 ? ((p.s == 1 && (p.ldx & 3) == 0) ? 2 : 1) : 0);
+    const int halo = (MODE == MODE_DIRECT || CHAIN) ? p.dil : 1;
+    const int halo_al = w8 ? ((halo + 7) & ~7) : ((halo + 3) & ~3);
     const int W = NT + (CHAIN ? 16 : 0) + 2 * halo_al;
+    const int spare = w8 ? 8 : 4;
     const size_t smem = sizeof(double) * 2 * 16 * MW * WM + sizeof(float) * 2 * ((size_t)p.nch32 * HX_KC + 8) +
-                        (size_t)2 * (MODE == MODE_DEC2 ? 2 : 1) * HX_NP * (W + 4) * HX_ROW +
+                        (size_t)2 * (MODE == MODE_DEC2 ? 2 : 1) * HX_NP * (W + spare) * HX_ROW +
                         (CHAIN ? (size_t)(MODE == MODE_UPHEAD ? 2 : 1) * p.nch32b * HX_NP * (NT + 16) * HX_ROW : 0);
     const bool aff = (p.flags & (F_STATS | F_AFF_OUT)) != 0;
     if constexpr (MODE == MODE_UPHEAD) {
@@ -1752,6 +1895,7 @@ static hipError_t hx_launch_shape(const ConvParams& p, int nsig, hipStream_t str
             // stretch factors of the recipe's blocks per channel-tile count (C = 24: x5, one K chunk; C >= 48: x2 / x4)
             if (kind != EPI_AFF || p.res || p.x2_T * p.s2 != p.T || (p.lens && (((p.len_mul | p.xlen_mul) & 3) != 0)))
                 return hipErrorInvalidValue;
+            if (w8 && p.s2 == 2 && W / p.s2 + 5 > 128) return hipErrorInvalidValue;   // (the second operand's 32 groups of 4 columns per tile)
 #define FASTSVC_HXX(sv, stat) if (p.s2 == sv) return hx_launch_instance<&conv_hx_kernel<MW, NW, WM, WN, MODE_DIRECT, EPI_AFF, sv, stat>>(grid, smem + est, stream, p);
             if constexpr (MW * NW <= 12) {                                         // (larger tiles spill with this epilogue)
                 if constexpr (MW == 2) { if (p.nch32 == 1) { FASTSVC_HXX(5, true) } }

@@ -182,6 +182,7 @@ __device__ __forceinline__ void wx_epilogue_rows(const ConvParams& p, const EpiR
 }
 #endif
 
+#ifdef FASTSVC_ACT_BF16           // (bfloat16 storage only: the float32 unit keeps the host queries below)
 // PRO: staging prologue (0 none, 1 LeakyReLU, 2 InstanceNorm + speaker bias + LeakyReLU); EPI: epilogue kind (fastsvc_device.inc)
 template <int PRO, int EPI>
 __global__ __launch_bounds__(WX_NT, 2)
@@ -211,8 +212,8 @@ void conv_wx_kernel(const ConvParams p0) {
     }
     const int mg = blockIdx.y * WM + wave_m;                           // (ngroups is a multiple of WM: every wave is active)
     const int halo = p.dil;
-    const int halo_al = (halo + 3) & ~3;
-    const int W = NT + 2 * halo_al;                                    // window rows (<= 248)
+    const int halo_al = (halo + 7) & ~7;                               // (8-row items, see the staging)
+    const int W = NT + 2 * halo_al;                                    // window rows (<= 256)
     const int nch = p.nch32;
     const int CINp = nch * HX_KC;
     const int flags = p.flags;
@@ -224,9 +225,9 @@ void conv_wx_kernel(const ConvParams p0) {
 
     double* sstat = reinterpret_cast<double*>(smem_raw);                               // [WM*MW*16][2]
     float2* ncoef = reinterpret_cast<float2*>(smem_raw + sizeof(double) * 2 * 16 * MW * WM);   // [CINp + 8]: the last 8 are (0, 0)
-    unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp + 8);         // [2][W + 4 rows][64 B]
-    const int lo_off = (W + 4) * HX_ROW;
-    const int bufsz = HX_NP * (W + 4) * HX_ROW;
+    unsigned char* tiles = reinterpret_cast<unsigned char*>(ncoef + CINp + 8);         // [2][W + 8 rows][64 B]
+    const int lo_off = (W + 8) * HX_ROW;
+    const int bufsz = HX_NP * (W + 8) * HX_ROW;
     unsigned char* wbuf = tiles + 2 * bufsz;                                           // [2][WM][tap][m] fragments
     unsigned char* patch = wbuf + 2 * WUNIT + wave * WX_PATCH;                         // this wave's epilogue patch (>= hx_pair's 16 x 36 floats)
     float* Xw = reinterpret_cast<float*>(patch);
@@ -277,87 +278,93 @@ void conv_wx_kernel(const ConvParams p0) {
         for (int f = 0; f < NSLOT; ++f) wcommit_frag(dst, f);
     };
 
-    // ---- window staging (waves 0-3): item = (octet of 8 channels, quad of 4 rows), one per lane ----
+    // ---- window staging (waves 0-3): item = (quad of 4 channels, octet of 8 rows), one per lane: four 16-byte requests
+    // (8 time steps of one channel each, 8 rows x 128 B per wave request).  A CU's vector-memory pipe takes a wave's
+    // request in about the same time whatever its width (tools/micro/cu_pull.hip: 8 B per lane stops at ~13 B/clk per CU
+    // even out of L2, 16 B per lane reaches 19-47): half the requests for the same window.  The halo is aligned to 8 rows,
+    // so an item starts inside the utterance or lies outside it; at a row's end (a multiple of 4) its last 4 rows may.
     const __amdgpu_buffer_rsrc_t xr = act_rsrc(p.x, (long)sig * p.x_sig + (long)b * p.x_b, (long)p.CIN * p.ldx);
-    const int it_oct = tid & 3;
-    const bool it_in = (tid >> 2) < (W >> 2);
-    const int it_q = it_in ? (tid >> 2) : (W >> 2);                    // (lanes without an item: parked in the 4 spare rows behind the tile)
+    const int it_cq = tid & 7;
+    const bool it_in = (tid >> 3) < (W >> 3);
+    const int it_ro = it_in ? (tid >> 3) : (W >> 3);                   // (lanes without an item: parked in the 8 spare rows behind the tile)
     const float slope = (PRO >= 1 && (flags & F_PRE_LRELU)) ? LRELU_SLOPE : 1.0f;    // max(v, slope * v): identity for 1
+    const bool row_end = (p.T & 7) != 0;                               // (uniform) the last item of a row holds 4 rows of it
     int l_tl = 0, l_ch = 0, c_ch = 0;
     // window w is requested into register set w & 1 two units before its commit
-    act4_t pxs[2][8];
-    bool toks[2] = {false, false};
+    u32x4 pxs[2][4];
+    int nvs[2] = {0, 0};                                               // rows of the item inside the utterance: 0, 4 or 8
     int p_voff[2] = {0, 0}, p_soff[2] = {0, 0};
     auto pload_begin = [&](auto SETC, int un) __attribute__((always_inline)) {     // (called once per unit, in unit order)
         constexpr int SET = decltype(SETC)::value;
         const int tl_ = l_tl, ch_ = l_ch;
         { const bool wrap = l_ch + 1 == nch; l_ch = wrap ? 0 : l_ch + 1; l_tl += wrap ? 1 : 0; }
-        const int t = (tile0 + tl_) * NT - halo_al + 4 * it_q;
+        const int t = (tile0 + tl_) * NT - halo_al + 8 * it_ro;
         const int rows_left = p.CIN - ch_ * HX_KC;
-        // (C_in is a multiple of 8: an octet lies inside the tensor or behind it as a whole)
-        const bool tok = it_in & ((unsigned)t < (unsigned)p.T) & (un < nunits) & (it_oct * 8 < rows_left);
-        toks[SET] = tok;
-        // ONE per-lane offset per item; the channel of the octet rides in the scalar offset
-        p_voff[SET] = tok ? (it_oct * 8 * p.ldx + t) * 4 : OOB_OFF;
-        p_soff[SET] = ch_ * HX_KC * p.ldx * 4;
+        // (C_in is a multiple of 8: a quad lies inside the tensor or behind it as a whole)
+        const bool tok = it_in & ((unsigned)t < (unsigned)p.T) & (un < nunits) & (it_cq * 4 < rows_left);
+        nvs[SET] = tok ? min(8, p.T - t) : 0;
+        // ONE per-lane offset per item (bytes); the channel of the quad rides in the scalar offset
+        p_voff[SET] = tok ? (it_cq * 4 * p.ldx + t) * 2 : OOB_OFF;
+        p_soff[SET] = ch_ * HX_KC * p.ldx * 2;
     };
     auto pload_chan = [&](auto SETC, int c) __attribute__((always_inline)) {
         constexpr int SET = decltype(SETC)::value;
-        pxs[SET][c] = act_load4_raw(xr, p_voff[SET], p_soff[SET] + c * p.ldx * 4);
+        pxs[SET][c] = __builtin_amdgcn_raw_buffer_load_b128(xr, p_voff[SET], p_soff[SET] + c * p.ldx * 2, FASTSVC_LD_AUX);
     };
     auto pload = [&](auto SETC, int un) __attribute__((always_inline)) {
         pload_begin(SETC, un);
         #pragma unroll
-        for (int c = 0; c < 8; ++c) pload_chan(SETC, c);
+        for (int c = 0; c < 4; ++c) pload_chan(SETC, c);
     };
-    // commit of one row (time step j of the item's quad) of the window in set SET
-    float cA[8], cB[8];                                                // (PRO 2: the item's (A, Bc) coefficients, read once per commit)
+    // commit of one row (time step j of the item's octet) of the window in set SET
+    float cA[4], cB[4];                                                // (PRO 2: the item's (A, Bc) coefficients, read once per commit)
     auto pcommit_begin = [&](auto SETC) __attribute__((always_inline)) {
         constexpr int SET = decltype(SETC)::value;
         const int ch_ = c_ch;
         c_ch = c_ch + 1 == nch ? 0 : c_ch + 1;
         if constexpr (PRO == 2) {
-            // (A, Bc) of the item's 8 channels: InstanceNorm + speaker bias as ONE FMA u * A + Bc; rows outside the utterance
+            // (A, Bc) of the item's 4 channels: InstanceNorm + speaker bias as ONE FMA u * A + Bc; rows outside the utterance
             // are the conv's zero padding AFTER the prologue: their loads returned 0, so only the additive term has to go - such
             // an item reads the (0, 0) coefficients behind the table
-            const f32x4* cf = reinterpret_cast<const f32x4*>(ncoef + (toks[SET] ? ch_ * HX_KC + it_oct * 8 : CINp));
-            const f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
-            cA[0] = c0.x; cA[1] = c0.z; cA[2] = c1.x; cA[3] = c1.z; cA[4] = c2.x; cA[5] = c2.z; cA[6] = c3.x; cA[7] = c3.z;
-            cB[0] = c0.y; cB[1] = c0.w; cB[2] = c1.y; cB[3] = c1.w; cB[4] = c2.y; cB[5] = c2.w; cB[6] = c3.y; cB[7] = c3.w;
+            const f32x4* cf = reinterpret_cast<const f32x4*>(ncoef + (nvs[SET] != 0 ? ch_ * HX_KC + it_cq * 4 : CINp));
+            const f32x4 c0 = cf[0], c1 = cf[1];
+            cA[0] = c0.x; cA[1] = c0.z; cA[2] = c1.x; cA[3] = c1.z;
+            cB[0] = c0.y; cB[1] = c0.w; cB[2] = c1.y; cB[3] = c1.w;
         }
     };
     auto pcommit_row = [&](auto SETC, unsigned char* tile, int j) __attribute__((always_inline)) {
         constexpr int SET = decltype(SETC)::value;
-        const act4_t (&px)[8] = pxs[SET];
-        // rows r, r + 1 of the quad swap places in every second quad (hx_lds_off): two addresses, rows 2 / 3 at +128 bytes
-        unsigned char* d = tile + hx_lds_off(4 * it_q + (j & 1), it_oct) + (j >> 1) * 2 * HX_ROW;
+        const u32x4 (&px)[4] = pxs[SET];
+        unsigned char* d = tile + hx_lds_off(8 * it_ro + j, it_cq >> 1) + (it_cq & 1) * 8;
+        u32x2v o;
         if constexpr (PRO == 0) {
-#ifdef FASTSVC_ACT_BF16
             // the tensor is what the conv reads: rows outside the utterance and channel padding were fetched as zeros.
             // 4 x 8 transpose of 16-bit values: dword k of row j = (channel 2k | channel 2k + 1 << 16) at time step j
-            u32x4 o;
             #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned a = j < 2 ? px[2 * k].x : px[2 * k].y, bb = j < 2 ? px[2 * k + 1].x : px[2 * k + 1].y;
-                o[k] = __builtin_amdgcn_perm(bb, a, (j & 1) ? 0x07060302u : 0x05040100u);
-            }
-            *reinterpret_cast<u32x4*>(d) = o;
-#endif
+            for (int k = 0; k < 2; ++k)
+                o[k] = __builtin_amdgcn_perm(px[2 * k + 1][j >> 1], px[2 * k][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
         } else {
-            float e[8];
+            float e[4];
             #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float v = act_unpack4(px[c])[j];
+            for (int c = 0; c < 4; ++c) {
+                const unsigned w = px[c][j >> 1];
+                float v = __builtin_bit_cast(float, (j & 1) ? (w & 0xffff0000u) : (w << 16));
                 if constexpr (PRO == 2) v = v * cA[c] + cB[c];
                 e[c] = fmaxf(v, v * slope);
             }
-            hx_commit_slot(d, 0, lo_off, e);
+            o.x = bf16_pack2(e[0], e[1]);
+            o.y = bf16_pack2(e[2], e[3]);
         }
+        if (j >= 4 && row_end) {                                       // (what lies behind the row's end is nobody's data)
+            o.x = nvs[SET] > 4 ? o.x : 0u;
+            o.y = nvs[SET] > 4 ? o.y : 0u;
+        }
+        *reinterpret_cast<u32x2v*>(d) = o;
     };
     auto pcommit = [&](auto SETC, unsigned char* tile) __attribute__((always_inline)) {
         pcommit_begin(SETC);
         #pragma unroll
-        for (int j = 0; j < 4; ++j) pcommit_row(SETC, tile, j);
+        for (int j = 0; j < 8; ++j) pcommit_row(SETC, tile, j);
     };
 
     // ---- epilogue descriptors and per-lane constants ----
@@ -501,13 +508,14 @@ void conv_wx_kernel(const ConvParams p0) {
         }
     }
 }
+#endif
 
 constexpr size_t WX_STATIC_LDS = 256;
 static size_t wx_smem(const ConvParams& p, int np = HX_NP) {     // np: operand pieces (1: bfloat16 storage)
-    const int halo_al = (p.dil + 3) & ~3;
+    const int halo_al = (p.dil + 7) & ~7;
     const int W = WX_TILE + 2 * halo_al;
     return sizeof(double) * 2 * 16 * WX_MW * WX_WM + sizeof(float) * 2 * ((size_t)p.nch32 * HX_KC + 8) +
-           (size_t)2 * np * (W + 4) * HX_ROW + (size_t)2 * WX_WM * 3 * WX_MW * np * HX_FRAG + (size_t)WX_NWAVES * WX_PATCH;
+           (size_t)2 * np * (W + 8) * HX_ROW + (size_t)2 * WX_WM * 3 * WX_MW * np * HX_FRAG + (size_t)WX_NWAVES * WX_PATCH;
 }
 
 template <auto KERNEL>
