@@ -2201,8 +2201,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
                 q.whx_inv = (prec == 0 && inv_off) ? blob + inv_off : nullptr; q.whx_inv_sig = c.hx_inv_pair;
                 static const int stagger = std::getenv("FASTSVC_STAGGER") ? std::atoi(std::getenv("FASTSVC_STAGGER")) : 2;
                 // (conv_wx: start delay between the workgroups of an XCD, in 64-cycle steps per K chunk - an eighth of a unit)
-                static const int wx_stagger = std::getenv("FASTSVC_WX_STAGGER") ? std::atoi(std::getenv("FASTSVC_WX_STAGGER")) : 6;
-                q.stagger = cd.algo == 6 ? wx_stagger : stagger;
+                q.stagger = stagger;
                 q.xs = 0; q.ps = 0;
             } else if (cd.algo >= 1) {
                 const int NTo = 32 * cd.NW * cd.WN, D = c.dil;
