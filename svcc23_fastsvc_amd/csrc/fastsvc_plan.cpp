@@ -2412,6 +2412,7 @@ hipError_t run_conv(const PackedConv& c, const float* blob, ConvParams p, int ns
         if (p.mode == MODE_STRETCH || poly) in_cols = (double)p.x_T;
         double el = (double)c.cin * in_cols;
         if (p.y) el += (double)c.cout * T_out;
+        if (p.mode == MODE_DEC2 && p.y2) el += (double)c.cout * T_out;     // the decimating pair's second output (the 1x1 residual conv's)
         if (p.flags & F_AFF_OUT) el += (double)c.cout * T_out;
         if (p.flags & F_PRE_AFFINE) el += 2.0 * c.cin * T_out;
         if (p.res) el += (double)c.cout * T_out;

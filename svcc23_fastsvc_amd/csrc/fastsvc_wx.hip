@@ -9,7 +9,9 @@
 //     staging work and epilogue sit under the other's products.  conv_hx's consumer wave is alone on its SIMD's pipe: its serial
 //     fragment-read -> product chain kept the pipe 21-32 % busy on these layers (profiles/r5c_cfg3_bfloat16_sq_counters.csv).
 //   * Roles by wave, one of each per SIMD: waves 0-3 STAGE the activation window of the next unit (a 192-column tile plus its
-//     halo is at most 248 rows: one (octet of 8 channels, quad of 4 rows) item per lane), waves 4-7 bring the next unit's
+//     halo, aligned to 8 rows, is at most 256 rows: one (quad of 4 channels, octet of 8 rows) item per lane = four 16-byte
+//     requests; until the end of round 6 (octet, quad) items of eight 8-byte requests: a CU takes 8-byte requests at ~13 B/clk
+//     at most, even out of L2 - tools/micro/cu_pull.hip -, film.2.heads 217 -> 196 us), waves 4-7 bring the next unit's
 //     WEIGHTS - wave 4 + g the nine KB-sized fragments of channel group g: global -> registers a unit ahead, registers -> LDS
 //     (lane-linear ds_write_b128) at the top of the unit.  Every wave reads its group's fragments back with conflict-free
 //     ds_read_b128: the weights cross L2 -> CU ONCE per workgroup (conv_hx: once per consumer wave and tile).
@@ -20,8 +22,9 @@
 //     its use makes hipcc wait for the younger set as well: fastsvc_hx.hip's lesson).
 //   * What it is bound by (profiles/r6b_*): the ablations ADD UP - products 110 us + window requests 68 + weight
 //     requests 33 + epilogue 50-60 for film.2.heads at 64 x 12000 - i.e. the waves wait for their requests instead of
-//     multiplying: a window request (4 rows x 128 bytes) costs ~47 cycles, a weight request (1 KB contiguous) ~20, wherever
-//     in the unit it stands (top of the unit or between the product steps), ~11 B/clk per CU of window data.  Tried against
+//     multiplying: an 8-byte-per-lane window request (4 rows x 128 bytes) cost ~47 cycles, a weight request (1 KB contiguous)
+//     ~20, wherever in the unit it stood (top of the unit or between the product steps), ~11 B/clk per CU of window data -
+//     hence the 16-byte requests above.  Tried against
 //     it and dropped: the layer's weights RESIDENT in LDS (96 output channels per workgroup, windows requested four units
 //     ahead: both channel halves of a C = 192 layer then read every window - 240 us), LDS-DMA for the weights (~195 cycles
 //     of issue per 1 KB piece).

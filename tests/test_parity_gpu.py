@@ -1098,3 +1098,32 @@ def test_residual_conv_folded_into_d3(dev, storage):
             assert float((y_r[j:j + 1, :, :n * cfg.hop] - alone).abs().mean()) <= 1e-2
         if n < F:
             assert float(y_r[j, :, n * cfg.hop:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("storage", ["float32", "bfloat16"])
+def test_layer_pipelines_run_to_run_identical_at_cfg3(dev, storage):
+    """The shape that exposed round 5's VALU -> MFMA C-operand hazard in the float32 pipeline (64 x 1500 frames: ~10^6 tiles
+    per launch, a handful of them differed from run to run).  Since round 6 no VALU result is an MFMA's C operand in
+    csrc/fastsvc_cond.hip (accumulators start from the bias register, the rank-1 / residual term joins after the products):
+    six forwards, the conditioning tensors of stages 0 / 1 and the waveform bit-identical every time."""
+    cfg = S.FULL_CONFIG
+    B, F = 64, 1500
+    plan = A.Plan(cfg, storage=storage, compact_workspace=True)
+    blob = plan.pack(S.synth_state_dict(cfg, 71)).to(dev)
+    ins = list(S.device_batch(cfg, B, F, 72, dev))
+    ws = torch.empty(plan.workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+    names = ("ss.0", "down_hd.1", "ss.1", "down_hd.2")
+    first = None
+    for run in range(6):
+        recs = []
+        y = plan.forward(blob, *ins, workspace=ws, profile=recs if run == 0 else None)
+        torch.cuda.synchronize()
+        if run == 0:
+            assert [r["kernel"] for r in recs if r["layer"] == "cond.0"][0].startswith("cond_stage0_pipe")
+        cur = [plan.tap(t, B, F, ws).clone() for t in names] + [y.clone()]
+        if first is None:
+            first = cur
+        else:
+            for t, a_, b_ in zip(names + ("y",), cur, first):
+                assert torch.equal(a_, b_), (t, run, int((a_ != b_).sum()))
+
