@@ -104,6 +104,9 @@ def main():
     dev = torch.device("cuda:0")
     storage = os.environ.get("FASTSVC_TIMELINE_STORAGE", "float32")
     plan = A.Plan(cfg, storage=storage, compact_workspace=True)
+    if os.environ.get("TL_TABLE"):                  # extra launch-table entries as JSON (e.g. another tpw for the layer looked at)
+        import json
+        plan.load_tuned(json.loads(os.environ["TL_TABLE"]))
     blob = plan.pack(S.synth_state_dict(cfg, 201)).to(dev)
     if wl["B"] * wl["F"] > 20000:
         ins = list(S.device_batch(cfg, wl["B"], wl["F"], wl["seed"], dev))
